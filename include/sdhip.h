@@ -1,0 +1,140 @@
+/*
+ * sdhip.h -- C ABI of libsdhip.so, the MI355X (gfx950) implementation of the
+ * speaker-diarization hot path of leohuang2013/pyannote-audio_speaker-diarization_cpp.
+ *
+ * Every entry point names the reference interface it replaces ("sd.cpp" =
+ * pipeline/src/speakerDiarizer.cpp, "cl.h/.cpp" = pipeline/src/clustering/).
+ * Plain pointers and sizes only; no C++/torch types; no exceptions cross the
+ * boundary.  All functions return SD_OK (0) or an SD_ERR_* code; the message is
+ * available from sd_last_error().  A context is bound to one GPU and is not
+ * thread-safe (same as the reference's static Ort::Env, onnx_model.cc:21-24).
+ *
+ * Pointer naming: h_* = host memory, d_* = device (HBM) memory of the ctx's GPU.
+ */
+#ifndef SDHIP_H
+#define SDHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sd_ctx sd_ctx;
+
+/* one speaker turn; replaces Annotation::Result (sd.cpp:866-876) */
+typedef struct sd_turn { double start, end; int32_t label; int32_t _pad; } sd_turn;
+
+enum {
+    SD_OK = 0,
+    SD_ERR_ARG = 1,      /* bad argument                                          */
+    SD_ERR_HIP = 2,      /* HIP runtime failure / no GPU                          */
+    SD_ERR_MODEL = 3,    /* weight file missing or malformed (reference: Ort::Exception) */
+    SD_ERR_SHORT = 4,    /* audio too short for one segmentation frame (reference: UB, sd.cpp:2997) */
+    SD_ERR_NUMERIC = 5   /* zero-norm centroid (reference throws, sd.cpp:493-495) */
+};
+
+/* fixed geometry of the reference */
+#define SD_SAMPLE_RATE 16000
+#define SD_CHUNK 80000      /* 5.0 s, sd.cpp:1335,1411 */
+#define SD_HOP 8000         /* 0.5 s, sd.cpp:1336,1412 */
+#define SD_FRAMES 293       /* sd.cpp:1415 */
+#define SD_SPEAKERS 3       /* sd.cpp:1351 */
+#define SD_EMB_DIM 192      /* sd.cpp:2484 */
+#define SD_EMB_BATCH 32     /* sd.cpp:2429 */
+
+/* ---- context ------------------------------------------------------------
+ * replaces OnnxModel::OnnxModel(path) x2 (onnx_model.cc:41-105) + SegmentModel /
+ * EmbeddingModel1 construction (sd.cpp:2958, 3043).  Model files are ".sdw"
+ * weight packs (tools/make_weights.py; an ONNX initializer reader is the next
+ * row of SURVEY section 8f).  Either path may be NULL when only the other
+ * network (or only clustering) is used. */
+sd_ctx* sd_create(const char* seg_model_path, const char* emb_model_path, int device_id);
+void sd_destroy(sd_ctx*);
+const char* sd_last_error(const sd_ctx*);     /* "" when no error */
+const char* sd_create_error(void);            /* reason for the last NULL from sd_create */
+
+/* ---- a2: chunk rule of SegmentModel::slide (sd.cpp:1419, 1457) ---------- */
+int64_t sd_num_chunks(int64_t n_samples, int64_t* last_chunk_len);
+
+/* ---- a2+a3: SegmentModel::slide + ::infer (sd.cpp:1352-1504) ------------
+ * wav: n float samples already scaled to [-1,1).  out: [chunks][293][3] f32. */
+int sd_segment(sd_ctx*, const float* h_wav, int64_t n, float* h_out, int64_t* chunks);
+int sd_segment_dev(sd_ctx*, const float* d_wav, int64_t n, float* d_out, int64_t chunks);
+
+/* ---- a4-a6: binarize_swf, speaker_count, cleanSegmentations + mask choice
+ * (sd.cpp:1506-1639, 1665-1738, 710-743, 3047-3078).
+ * seg [chunks][293][3] -> binarized u8 [chunks][293][3], masks f32 [chunks*3][293],
+ * count i32 [*n_count] (capacity cap_count).  Any output pointer may be NULL. */
+int sd_postseg(sd_ctx*, const float* h_seg, int64_t chunks, uint8_t* h_bin,
+               float* h_masks, int32_t* h_count, int64_t cap_count, int64_t* n_count);
+int64_t sd_count_frames(int64_t chunks);      /* frames speaker_count produces */
+
+/* ---- a6-a9: crop + getEmbedding + EmbeddingModel1::infer (sd.cpp:1641-1662,
+ * 2436-2561, 1977-2040, 1889-1970).  Item i = (chunk i/3, local speaker i%3)
+ * reads wav[chunk*8000 .. +80000) (zero padded) with mask row i.  Batches of 32
+ * consecutive items share max_len exactly as the reference's batches do.
+ * out: [items][192] f32, NaN rows for too-short items. */
+int sd_embed(sd_ctx*, const float* h_wav, int64_t n, const float* h_masks,
+             int64_t items, float* h_emb);
+int sd_embed_dev(sd_ctx*, const float* d_wav, int64_t n, const float* d_masks,
+                 int64_t items, int64_t first_item, float* d_emb);
+
+/* ---- a8 + head of a9 alone (operator seam for parity tests): compaction +
+ * STFT + power + mel + dB + mean-norm.  signals-level inputs as for sd_embed;
+ * out feats [items][501][80] f32, wav_lens [items] f32 (reference layout). */
+int sd_frontend(sd_ctx*, const float* h_wav, int64_t n, const float* h_masks,
+                int64_t items, float* h_feats, float* h_wav_lens);
+/* ECAPA-TDNN body alone: feats [items][501][80], wav_lens [items] -> [items][192] */
+int sd_ecapa(sd_ctx*, const float* h_feats, const float* h_wav_lens, int64_t items, float* h_emb);
+
+/* ---- a12: Clustering::linkage (cl.h:8, cl.cpp:417-440): X[N][d] f64 -> Z[N-1][4] */
+int sd_linkage(sd_ctx*, const double* h_X, int64_t N, int d, double* h_Z);
+/* ---- a12+a13: Clustering::cluster (cl.h:7, cl.cpp:459-468): 1-based labels */
+int sd_cluster(sd_ctx*, const double* h_X, int64_t N, int d, double cutoff, int32_t* h_labels1);
+/* ---- a10+a11+a14: Cluster::clustering (sd.cpp:2063-2116): emb [chunks][3][d]
+ * f64 with NaN rows -> hard clusters i32 [chunks][3]; *n_clusters = K */
+int sd_clustering(sd_ctx*, const double* h_emb, int64_t chunks, int d, int32_t* h_hard, int32_t* n_clusters);
+
+/* ---- a15-a17: inactive mask, reconstruct, to_diarization, to_annotation
+ * (sd.cpp:3172-3191, 2789-2848, 2638-2764, 2852-2935).  Returns malloc'd turns
+ * sorted by start (Annotation::finalResult, sd.cpp:962-978). */
+int sd_reconstruct(sd_ctx*, const float* h_seg, const uint8_t* h_bin, const int32_t* h_hard,
+                   const int32_t* h_count, int64_t n_count, int64_t chunks, int64_t n_samples,
+                   sd_turn** turns, int64_t* n_turns);
+
+/* ---- whole path: speakerDiarization() (sd.cpp:2937-3234) -----------------
+ * pcm: 16-bit mono 16 kHz samples as WavReader yields them (wav.h:107-111);
+ * scaling by 1/32768 (sd.cpp:2950) happens on the GPU. */
+int sd_diarize(sd_ctx*, const int16_t* h_pcm, int64_t n, sd_turn** turns, int64_t* n_turns);
+int sd_diarize_dev(sd_ctx*, const int16_t* d_pcm, int64_t n, sd_turn** turns, int64_t* n_turns);
+void sd_free_turns(sd_turn*);
+
+/* ---- multi-GPU split of the same path: ranks run infer on their
+ * contiguous chunk range (multiple of 32 chunks), all-gather d_seg / d_emb with
+ * RCCL (torch.distributed), then any rank finalizes. */
+int sd_shard_infer_dev(sd_ctx*, const int16_t* d_pcm, int64_t n, int64_t chunk_lo, int64_t chunk_hi,
+                       float* d_seg /*[hi-lo][293][3]*/, float* d_emb /*[(hi-lo)*3][192]*/);
+int sd_finalize_dev(sd_ctx*, const float* d_seg, const float* d_emb, int64_t chunks, int64_t n,
+                    sd_turn** turns, int64_t* n_turns);
+
+/* ---- a1: wav::WavReader::Open (wav.h:62-126).  Returns malloc'd pcm (free with
+ * sd_free_pcm); only 16-bit PCM is accepted (README.md:37), channels are read
+ * interleaved-as-mono exactly like the reference (wav.h:95-97). */
+int sd_read_wav(const char* path, int16_t** pcm, int64_t* n, int32_t* sample_rate, int32_t* channels);
+void sd_free_pcm(int16_t*);
+
+/* ---- a18: the reference's output line (sd.cpp:3439) */
+int sd_format_turn(const sd_turn* t, char* buf, int cap);
+
+/* ---- measurement hooks (bench.py): per-stage wall ms of the last sd_diarize*
+ * [0]=segmentation [1]=embedding [2]=clustering [3]=total (labels of sd.cpp:3028,
+ * 3110, 3231, 3434); GPU time of named kernels measured with hipEvents on the
+ * library's own stream. */
+int sd_stage_ms(const sd_ctx*, double* ms4);
+int sd_kernel_stats(const sd_ctx*, const char* kernel, double* total_ms, int64_t* launches, double* flops, double* bytes);
+void sd_reset_stats(sd_ctx*);
+int sd_set_option(sd_ctx*, const char* key, int64_t value);   /* "emb_batch_items", "seg_batch_chunks", "profile" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

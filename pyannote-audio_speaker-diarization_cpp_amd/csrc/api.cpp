@@ -1,0 +1,225 @@
+// api.cpp -- the C ABI of libsdhip.so (include/sdhip.h): context, host-buffer wrappers
+// around the device pipelines, whole-path driver (speakerDiarization(), sd.cpp:2937-3234),
+// wav reader (wav.h:62-126) and the measurement hooks.
+#include "common.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+
+static std::string g_create_err;
+
+extern "C" const char* sd_create_error(void) { return g_create_err.c_str(); }
+extern "C" const char* sd_last_error(const sd_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" sd_ctx* sd_create(const char* seg_path, const char* emb_path, int device)
+{
+    g_create_err.clear();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_err = "no HIP device available (libsdhip has no CPU fallback)"; return nullptr; }
+    if (device < 0 || device >= ndev) { g_create_err = "device id out of range"; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return nullptr; }
+    sd_ctx* c = new sd_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete c; return nullptr; }
+    auto fail = [&](const std::string& m) { g_create_err = m; sd_destroy(c); return (sd_ctx*)nullptr; };
+    if (seg_path && seg_path[0]) {
+        Pack p; std::string e;
+        if (load_pack(seg_path, p, e)) return fail(e);
+        if (build_seg_weights(c, p)) return fail(c->err);
+    }
+    if (emb_path && emb_path[0]) {
+        Pack p; std::string e;
+        if (load_pack(emb_path, p, e)) return fail(e);
+        if (build_ecapa_weights(c, p)) return fail(c->err);
+    }
+    c->err.clear();
+    return c;
+}
+
+extern "C" void sd_destroy(sd_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    sd_flush_profile(c);
+    for (void* p : c->owned) (void)hipFree(p);
+    for (auto& kv : c->ws) kv.second.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void sd_flush_profile(sd_ctx* c)
+{
+    for (auto& t : c->pending) {
+        hipEvent_t e0 = std::get<1>(t), e1 = std::get<2>(t);
+        float ms = 0;
+        if (hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+        KernelStat& s = c->stats[std::get<0>(t)];
+        s.ms += ms; s.launches++; s.flops += std::get<3>(t); s.bytes += std::get<4>(t);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    c->pending.clear();
+}
+
+extern "C" int sd_kernel_stats(const sd_ctx* cc, const char* kernel, double* total_ms, int64_t* launches, double* flops, double* bytes)
+{
+    sd_ctx* c = const_cast<sd_ctx*>(cc);
+    if (!c || !kernel) return SD_ERR_ARG;
+    (void)hipStreamSynchronize(c->stream);
+    sd_flush_profile(c);
+    auto it = c->stats.find(kernel);
+    KernelStat s; if (it != c->stats.end()) s = it->second;
+    if (total_ms) *total_ms = s.ms; if (launches) *launches = s.launches; if (flops) *flops = s.flops; if (bytes) *bytes = s.bytes;
+    return SD_OK;
+}
+extern "C" void sd_reset_stats(sd_ctx* c) { if (!c) return; (void)hipStreamSynchronize(c->stream); sd_flush_profile(c); c->stats.clear(); }
+extern "C" int sd_stage_ms(const sd_ctx* c, double* ms4) { if (!c || !ms4) return SD_ERR_ARG; for (int i = 0; i < 4; ++i) ms4[i] = c->stage_ms[i]; return SD_OK; }
+extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
+{
+    if (!c || !key) return SD_ERR_ARG;
+    std::string k(key);
+    if (k == "emb_batch_items") c->emb_batch_items = v;
+    else if (k == "seg_batch_chunks") c->seg_batch_chunks = v;
+    else if (k == "profile") c->profile = v != 0;
+    else SD_FAIL(c, SD_ERR_ARG, "unknown option %s", key);
+    return SD_OK;
+}
+
+// ------------------------------------------------------------------ helpers
+extern "C" int64_t sd_num_chunks(int64_t n, int64_t* last_len)
+{
+    int64_t i = 0, cnt = 0;
+    if (n > SD_CHUNK) { cnt = (n - SD_CHUNK + SD_HOP - 1) / SD_HOP; i = cnt * SD_HOP; }   // while (i + window < n), sd.cpp:1419
+    int64_t ll = 0;
+    if (i + 1 < n) { ll = n - i; cnt++; }                                                  // sd.cpp:1457
+    if (last_len) *last_len = ll;
+    return cnt;
+}
+
+struct DevTmp {   // RAII device scratch for the host-pointer wrappers
+    void* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : 1; }
+};
+#define DTMP(ctx, var, bytes) DevTmp var; if (var.alloc(bytes)) SD_FAIL(ctx, SD_ERR_HIP, "hipMalloc(%zu) failed", (size_t)(bytes))
+#define ENTER(ctx) do { if (!(ctx)) return SD_ERR_ARG; (ctx)->err.clear(); if (hipSetDevice((ctx)->device) != hipSuccess) SD_FAIL(ctx, SD_ERR_HIP, "hipSetDevice failed"); } while (0)
+
+// ------------------------------------------------------------------ embedding path
+extern "C" int sd_embed_dev(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item, float* d_emb)
+{
+    ENTER(c);
+    if (!d_wav || !d_masks || !d_emb || n <= 0 || items < 0) SD_FAIL(c, SD_ERR_ARG, "sd_embed_dev: bad argument");
+    int rc = run_embed(c, d_wav, n, d_masks, items, first_item, d_emb);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SD_OK;
+}
+
+extern "C" int sd_embed(sd_ctx* c, const float* h_wav, int64_t n, const float* h_masks, int64_t items, float* h_emb)
+{
+    ENTER(c);
+    if (!h_wav || !h_masks || !h_emb || n <= 0 || items < 0) SD_FAIL(c, SD_ERR_ARG, "sd_embed: bad argument");
+    DTMP(c, dw, n * sizeof(float)); DTMP(c, dm, items * SD_FRAMES * sizeof(float)); DTMP(c, de, items * SD_EMB_DIM * sizeof(float));
+    HIPCHK(c, hipMemcpy(dw.p, h_wav, n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dm.p, h_masks, items * SD_FRAMES * sizeof(float), hipMemcpyHostToDevice));
+    int rc = run_embed(c, (const float*)dw.p, n, (const float*)dm.p, items, 0, (float*)de.p);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h_emb, de.p, items * SD_EMB_DIM * sizeof(float), hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+extern "C" int sd_frontend(sd_ctx* c, const float* h_wav, int64_t n, const float* h_masks, int64_t items, float* h_feats, float* h_lens)
+{
+    ENTER(c);
+    if (!h_wav || !h_masks || n <= 0 || items <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_frontend: bad argument");
+    DTMP(c, dw, n * sizeof(float)); DTMP(c, dm, items * SD_FRAMES * sizeof(float));
+    DTMP(c, df, items * SD_TP * SD_FEAT_LD * sizeof(float)); DTMP(c, dl, items * sizeof(float));
+    DTMP(c, dn, items * sizeof(int)); DTMP(c, dv, items * sizeof(int)); DTMP(c, dg, items * sizeof(int));
+    HIPCHK(c, hipMemcpy(dw.p, h_wav, n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dm.p, h_masks, items * SD_FRAMES * sizeof(float), hipMemcpyHostToDevice));
+    int rc = run_frontend(c, (const float*)dw.p, n, (const float*)dm.p, items, 0, (float*)df.p, (float*)dl.p, (int*)dn.p, (int*)dv.p, (int*)dg.p);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_feats) {
+        std::vector<float> tmp((size_t)items * SD_TP * SD_FEAT_LD);
+        HIPCHK(c, hipMemcpy(tmp.data(), df.p, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < items; ++i)
+            for (int t = 0; t < SD_T; ++t)
+                memcpy(h_feats + ((size_t)i * SD_T + t) * SD_NMELS, &tmp[((size_t)i * SD_TP + t) * SD_FEAT_LD], SD_NMELS * sizeof(float));
+    }
+    if (h_lens) HIPCHK(c, hipMemcpy(h_lens, dl.p, items * sizeof(float), hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+extern "C" int sd_ecapa(sd_ctx* c, const float* h_feats, const float* h_lens, int64_t items, float* h_emb)
+{
+    ENTER(c);
+    if (!h_feats || !h_lens || !h_emb || items <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_ecapa: bad argument");
+    std::vector<float> tmp((size_t)items * SD_TP * SD_FEAT_LD, 0.0f);
+    std::vector<int> nv(items), fl(items, 0);
+    for (int64_t i = 0; i < items; ++i) {
+        for (int t = 0; t < SD_T; ++t)
+            memcpy(&tmp[((size_t)i * SD_TP + t) * SD_FEAT_LD], h_feats + ((size_t)i * SD_T + t) * SD_NMELS, SD_NMELS * sizeof(float));
+        float lt = h_lens[i] * (float)SD_T;
+        int v = (int)ceilf(lt); if (v > SD_T) v = SD_T; if (v < 1) v = 1;
+        nv[i] = v;
+    }
+    DTMP(c, df, tmp.size() * sizeof(float)); DTMP(c, dv, items * sizeof(int)); DTMP(c, dg, items * sizeof(int)); DTMP(c, de, items * SD_EMB_DIM * sizeof(float));
+    HIPCHK(c, hipMemcpy(df.p, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dv.p, nv.data(), items * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dg.p, fl.data(), items * sizeof(int), hipMemcpyHostToDevice));
+    int rc = run_ecapa(c, (const float*)df.p, (const int*)dv.p, (const int*)dg.p, items, (float*)de.p);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h_emb, de.p, items * SD_EMB_DIM * sizeof(float), hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+// ------------------------------------------------------------------ wav reader (a1)
+extern "C" int sd_read_wav(const char* path, int16_t** pcm, int64_t* n, int32_t* sample_rate, int32_t* channels)
+{
+    if (!path || !pcm || !n) return SD_ERR_ARG;
+    *pcm = nullptr; *n = 0;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return SD_ERR_ARG;                       // reference ignores this (wav.h:60) and crashes later
+    unsigned char h[44];
+    if (fread(h, 1, 44, fp) != 44) { fclose(fp); return SD_ERR_ARG; }
+    uint32_t fmt_size, sr, dsz; uint16_t ch, bits; char tag[4];
+    memcpy(&fmt_size, h + 16, 4); memcpy(&ch, h + 22, 2); memcpy(&sr, h + 24, 4); memcpy(&bits, h + 34, 2);
+    memcpy(tag, h + 36, 4); memcpy(&dsz, h + 40, 4);
+    if (fmt_size < 16) { fclose(fp); return SD_ERR_ARG; }
+    unsigned char t8[8];
+    if (fmt_size > 16) {                               // wav.h:75-79
+        fseek(fp, 44 - 8 + (long)fmt_size - 16, SEEK_SET);
+        if (fread(t8, 1, 8, fp) != 8) { fclose(fp); return SD_ERR_ARG; }
+        memcpy(tag, t8, 4); memcpy(&dsz, t8 + 4, 4);
+    }
+    while (strncmp(tag, "data", 4) != 0) {             // wav.h:85-90 skip LIST/fact chunks
+        fseek(fp, (long)dsz, SEEK_CUR);
+        if (fread(t8, 1, 8, fp) != 8) { fclose(fp); return SD_ERR_ARG; }
+        memcpy(tag, t8, 4); memcpy(&dsz, t8 + 4, 4);
+    }
+    if (bits != 16) { fclose(fp); return SD_ERR_ARG; } // README.md:37: 16 kHz / mono / 16 bit only
+    int64_t num = dsz / 2;
+    int16_t* buf = (int16_t*)malloc((size_t)(num > 0 ? num : 1) * sizeof(int16_t));
+    int64_t got = (int64_t)fread(buf, 2, (size_t)num, fp);
+    for (int64_t i = got; i < num; ++i) buf[i] = 0;
+    fclose(fp);
+    *pcm = buf;
+    *n = num / (ch ? ch : 1);                          // wav.h:97 (interleaved data read as mono)
+    if (sample_rate) *sample_rate = (int32_t)sr;
+    if (channels) *channels = ch;
+    return SD_OK;
+}
+extern "C" void sd_free_pcm(int16_t* p) { free(p); }
+extern "C" void sd_free_turns(sd_turn* t) { free(t); }
+extern "C" int sd_format_turn(const sd_turn* t, char* buf, int cap)
+{
+    if (!t || !buf) return SD_ERR_ARG;
+    snprintf(buf, (size_t)cap, "[%g -- %g] --> Speaker_%d", t->start, t->end, t->label);   // sd.cpp:3439, iostream default precision
+    return SD_OK;
+}

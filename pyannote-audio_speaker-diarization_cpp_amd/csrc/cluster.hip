@@ -1,0 +1,450 @@
+// cluster.hip -- agglomerative clustering of the speaker embeddings on the GPU
+// (compiled with -ffp-contract=off: every fp64 result is bit-identical to the reference's
+// x86 build, which decides merge order and therefore speaker numbering).
+//   a10 filter_embeddings                      sd.cpp:2214-2259
+//   a11 Cluster::cluster (normalise, size split, small->large reassign, renumber)  sd.cpp:2300-2422
+//   a12 Clustering::linkage = euclidean pdist + scipy-generic centroid linkage     cl.cpp:289-440
+//   a13 Clustering::fcluster(criterion=distance)                                   cl.cpp:121-232, 442-457
+//   a14 assign_embeddings (centroids, cosine cdist, argmax)                        sd.cpp:2119-2212
+//
+// Design: the condensed fp64 distance matrix (N(N-1)/2 doubles, 1.86 GB at N = 21 573) stays
+// resident in HBM.  k_pdist builds it from LDS tiles with the reference's sequential
+// per-pair summation order.  k_linkage is one persistent 1024-thread workgroup that performs
+// the N-1 dependent merges: per merge a parallel arg-min over the per-row lower bounds
+// (replacing the reference's binary heap), lazy validation of the candidate exactly as
+// fast_linkage does it, the Lance-Williams centroid update of row/column y, the neighbour
+// patches, and the nearest-neighbour refresh of row y.  Equal lower bounds are resolved to
+// the lowest row index (the heap's order for exact ties is not reproduced; distinct merge
+// heights give a bit-identical Z).  fcluster is O(N) pointer chasing and runs on the host.
+#include "common.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+__host__ __device__ __forceinline__ int64_t cidx(int64_t n, int64_t i, int64_t j)     // cl.cpp:236-242
+{
+    if (i < j) return n * i - (i * (i + 1) / 2) + (j - i - 1);
+    return n * j - (j * (j + 1) / 2) + (i - j - 1);
+}
+
+// ---------------------------------------------------------------- row gather + L2 normalise (a10/a11)
+// Xout[i] = X[tidx[i]] (un-normalised copy), Xn[i] = row / (double)(float)sqrt(sum x^2)
+// Helper::L2Norm returns float (sd.cpp:332-340): the norm is rounded to f32 before the divide.
+__global__ void k_gather_normalize(const double* __restrict__ X, const int* __restrict__ tidx, int64_t N, int d,
+                                   double* __restrict__ Xout, double* __restrict__ Xn)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double* r = X + (size_t)tidx[i] * d;
+    double s = 0.0;
+    for (int q = 0; q < d; ++q) s += r[q] * r[q];
+    const double nrm = (double)(float)sqrt(s);
+    for (int q = 0; q < d; ++q) {
+        const double v = r[q];
+        if (Xout) Xout[(size_t)i * d + q] = v;
+        Xn[(size_t)i * d + q] = (nrm != 0.0) ? v / nrm : v;
+    }
+}
+
+// ---------------------------------------------------------------- k_pdist (cl.cpp:408-431)
+#define PT 64
+__global__ __launch_bounds__(256) void k_pdist(const double* __restrict__ X, int64_t N, int d, double* __restrict__ D)
+{
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj < ti) return;
+    __shared__ double Xi[PT][33], Xj[PT][33];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+    for (int q0 = 0; q0 < d; q0 += 32) {
+        for (int e = tid; e < PT * 32; e += 256) {
+            const int r = e >> 5, q = e & 31;
+            int64_t gi = (int64_t)ti * PT + r; if (gi > N - 1) gi = N - 1;
+            int64_t gj = (int64_t)tj * PT + r; if (gj > N - 1) gj = N - 1;
+            const bool in = (q0 + q) < d;
+            Xi[r][q] = in ? X[(size_t)gi * d + q0 + q] : 0.0;
+            Xj[r][q] = in ? X[(size_t)gj * d + q0 + q] : 0.0;
+        }
+        __syncthreads();
+        for (int q = 0; q < 32; ++q) {          // sequential in q: same summation order as the reference
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = Xi[ty + 16 * u][q]; b[u] = Xj[tx + 16 * u][q]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { const double df = a[u] - b[v]; acc[u][v] += df * df; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int64_t i = (int64_t)ti * PT + ty + 16 * u, j = (int64_t)tj * PT + tx + 16 * v;
+            if (i < j && j < N) D[cidx(N, i, j)] = sqrt(acc[u][v]);
+        }
+}
+
+// ---------------------------------------------------------------- nearest active neighbour above a row (cl.cpp:259-276)
+struct MinIdx { double v; int i; };
+__device__ __forceinline__ MinIdx better(MinIdx a, MinIdx b)
+{
+    // smaller value wins; equal values -> lower index (== "first strictly smaller" of a sequential scan); -1 = none
+    if (b.i < 0) return a;
+    if (a.i < 0) return b;
+    if (b.v < a.v) return b;
+    if (b.v == a.v && b.i < a.i) return b;
+    return a;
+}
+__device__ __forceinline__ MinIdx wave_min(MinIdx m)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        MinIdx t; t.v = __shfl_xor(m.v, o); t.i = __shfl_xor(m.i, o);
+        m = better(m, t);
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_row_nn(const double* __restrict__ D, int64_t n, int* __restrict__ nb, double* __restrict__ md)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t x = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (x >= n - 1) return;
+    const double* row = D + cidx(n, x, x + 1);
+    const int64_t cnt = n - 1 - x;
+    MinIdx m; m.v = INFINITY; m.i = -1;
+    for (int64_t t = lane; t < cnt; t += 64) {
+        const double v = row[t];
+        if (v < m.v) { m.v = v; m.i = (int)(x + 1 + t); }
+    }
+    m = wave_min(m);
+    if (lane == 0) { nb[x] = m.i; md[x] = (m.i < 0) ? INFINITY : m.v; }
+}
+
+// Lance-Williams centroid update with the reference's operation order, cl.cpp:250-256
+__device__ __forceinline__ double lw_centroid(double d_xi, double d_yi, double d_xy, int sx, int sy)
+{
+    return sqrt(((((double)sx * d_xi * d_xi) + ((double)sy * d_yi * d_yi)) -
+                 ((double)(sx * sy) * d_xy * d_xy) / (double)(sx + sy)) / (double)(sx + sy));
+}
+
+#define LT 1024
+__device__ __forceinline__ MinIdx block_min(MinIdx m, MinIdx* sh)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    m = wave_min(m);
+    __syncthreads();                 // sh may still be read from the previous use
+    if (lane == 0) sh[w] = m;
+    __syncthreads();
+    MinIdx r = sh[0];
+#pragma unroll
+    for (int k = 1; k < LT / 64; ++k) r = better(r, sh[k]);
+    return r;
+}
+
+// ---------------------------------------------------------------- k_linkage : persistent single workgroup (cl.cpp:289-406)
+// (no __restrict__: every array here is written by one thread and re-read by others across barriers)
+__global__ __launch_bounds__(LT) void k_linkage(double* D, int n, int* size, int* cid, int* nb, double* md, double* Z)
+{
+    __shared__ MinIdx sh[LT / 64];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x;
+    const int64_t N = n;
+    for (int k = 0; k < n - 1; ++k) {
+        int x, y; double dist;
+        for (int guard = 0; guard <= n - k; ++guard) {
+            MinIdx m; m.v = INFINITY; m.i = -1;
+            for (int r = tid; r < n - 1; r += LT)
+                if (size[r] > 0) { const double v = md[r]; if (m.i < 0 || v < m.v) { m.v = v; m.i = r; } }
+            m = block_min(m, sh);
+            x = m.i; dist = m.v; y = nb[x];
+            if (tid == 0) s_ok = (y >= 0) && (dist == D[cidx(N, x, y)]);          // cl.cpp:329
+            __syncthreads();
+            if (s_ok) break;
+            // stale candidate: recompute row x's true nearest neighbour (cl.cpp:333-338)
+            MinIdx q; q.v = INFINITY; q.i = -1;
+            const double* row = D + cidx(N, x, (int64_t)x + 1);
+            for (int j = x + 1 + tid; j < n; j += LT)
+                if (size[j] != 0) { const double v = row[j - x - 1]; if (v < q.v) { q.v = v; q.i = j; } }
+            q = block_min(q, sh);
+            if (tid == 0) { nb[x] = q.i; md[x] = (q.i < 0) ? INFINITY : q.v; }
+            __syncthreads();
+        }
+        const int nx = size[x], ny = size[y];
+        __syncthreads();
+        if (tid == 0) {
+            int ix = cid[x], iy = cid[y];
+            if (ix > iy) { const int t = ix; ix = iy; iy = t; }
+            Z[(size_t)k * 4 + 0] = (double)ix; Z[(size_t)k * 4 + 1] = (double)iy;
+            Z[(size_t)k * 4 + 2] = dist;       Z[(size_t)k * 4 + 3] = (double)(nx + ny);
+            size[x] = 0; size[y] = nx + ny; cid[y] = n + k;
+        }
+        __syncthreads();
+        for (int z = tid; z < n; z += LT) {
+            if (z == y || size[z] == 0) continue;
+            const int64_t izy = cidx(N, z, y);
+            const double nd = lw_centroid(D[cidx(N, z, x)], D[izy], dist, nx, ny);   // cl.cpp:367
+            D[izy] = nd;
+            if (z < x && nb[z] == x) nb[z] = y;                                       // cl.cpp:374-378
+            if (z < y && nd < md[z]) { nb[z] = y; md[z] = nd; }                       // cl.cpp:381-392
+        }
+        __syncthreads();
+        if (y < n - 1) {                                                              // cl.cpp:395-404
+            MinIdx q; q.v = INFINITY; q.i = -1;
+            const double* row = D + cidx(N, y, (int64_t)y + 1);
+            for (int j = y + 1 + tid; j < n; j += LT)
+                if (size[j] != 0) { const double v = row[j - y - 1]; if (v < q.v) { q.v = v; q.i = j; } }
+            q = block_min(q, sh);
+            if (tid == 0 && q.i >= 0) { nb[y] = q.i; md[y] = q.v; }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_fill_i32(int* p, int v, int64_t n, int iota)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = iota ? (int)i : v;
+}
+
+// X[N][d] (rows as given; Clustering::linkage does not normalise) -> Z[N-1][4] on the device
+int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
+{
+    if (N < 2) return SD_OK;
+    const int64_t m = N * (N - 1) / 2;
+    if (N > 0x7fffffff / 4 || (double)m * 8.0 > 230e9) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs a %.0f GB condensed matrix (limit 230 GB)", (long long)N, (double)m * 8e-9);
+    WS(c, double, D, "cl_D", m);
+    WS(c, int, size, "cl_size", N);
+    WS(c, int, cid, "cl_cid", N);
+    WS(c, int, nb, "cl_nb", N);
+    WS(c, double, md, "cl_md", N);
+    const int tiles = (int)((N + PT - 1) / PT);
+    {
+        ProfScope ps(c, "pdist", (double)m * d * 3.0, (double)m * 8.0 + (double)N * d * 8.0);
+        hipLaunchKernelGGL(k_pdist, dim3(tiles, tiles), dim3(256), 0, c->stream, d_X, N, d, D);
+        KCHECK(c);
+    }
+    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, size, 1, N, 0);
+    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, cid, 0, N, 1);
+    KCHECK(c);
+    {
+        ProfScope ps(c, "row_nn", 0, (double)m * 8.0);
+        hipLaunchKernelGGL(k_row_nn, dim3((unsigned)((N - 1 + 3) / 4)), dim3(256), 0, c->stream, D, N, nb, md);
+        KCHECK(c);
+    }
+    {
+        ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
+        hipLaunchKernelGGL(k_linkage, dim3(1), dim3(LT), 0, c->stream, D, (int)N, size, cid, nb, md, d_Z);
+        KCHECK(c);
+    }
+    return SD_OK;
+}
+
+// fcluster(criterion="distance"), cl.cpp:121-232 + 442-457.  Node ids grow with merge order, so the
+// per-node max merge height is a forward pass; labels follow the reference's visiting order: internal
+// left subtree, internal right subtree, then the leaf children of the node.
+void fcluster_host(const std::vector<double>& Z, int64_t n, double cutoff, std::vector<int>& T)
+{
+    T.assign((size_t)n, 0);
+    if (n == 1) { T[0] = 1; return; }
+    if (n < 2) return;
+    std::vector<double> MD((size_t)n - 1);
+    for (int64_t k = 0; k < n - 1; ++k) {
+        double mx = Z[k * 4 + 2];
+        const int64_t lc = (int64_t)Z[k * 4 + 0], rc = (int64_t)Z[k * 4 + 1];
+        if (lc >= n && MD[lc - n] > mx) mx = MD[lc - n];
+        if (rc >= n && MD[rc - n] > mx) mx = MD[rc - n];
+        MD[k] = mx;
+    }
+    struct Fr { int64_t node; int label; int state; };
+    std::vector<Fr> st;
+    st.push_back({2 * n - 2, 0, 0});
+    int ncl = 0;
+    while (!st.empty()) {
+        Fr& f = st.back();
+        const int64_t k = f.node - n;
+        const int64_t lc = (int64_t)Z[k * 4 + 0], rc = (int64_t)Z[k * 4 + 1];
+        if (f.state == 0) {
+            if (f.label == 0 && MD[k] <= cutoff) f.label = ++ncl;
+            f.state = 1;
+            if (lc >= n) { const int lab = f.label; st.push_back({lc, lab, 0}); continue; }
+        }
+        if (f.state == 1) {
+            f.state = 2;
+            if (rc >= n) { const int lab = f.label; st.push_back({rc, lab, 0}); continue; }
+        }
+        if (lc < n) T[lc] = f.label ? f.label : ++ncl;
+        if (rc < n) T[rc] = f.label ? f.label : ++ncl;
+        st.pop_back();
+    }
+}
+
+int run_cluster_labels(sd_ctx* c, const double* d_Xn, int64_t N, int d, double cutoff, std::vector<int>& labels1)
+{
+    labels1.assign((size_t)N, 0);
+    if (N == 1) { labels1[0] = 1; return SD_OK; }
+    if (N < 2) return SD_OK;
+    WS(c, double, dZ, "cl_Z", (N - 1) * 4);
+    int rc = run_linkage(c, d_Xn, N, d, dZ);
+    if (rc) return rc;
+    std::vector<double> Z((size_t)(N - 1) * 4);
+    HIPCHK(c, hipMemcpyAsync(Z.data(), dZ, Z.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fcluster_host(Z, N, cutoff, labels1);
+    return SD_OK;
+}
+
+// ---------------------------------------------------------------- cluster means (sequential in member order)
+// members of cluster k are order[off[k] .. off[k+1]) in ascending row index: same summation order as
+// Helper::calculateClusterMeans (sd.cpp:442-473) and the centroid loop of assign_embeddings (sd.cpp:2149-2167)
+__global__ void k_cluster_means(const double* __restrict__ X, int d, const int* __restrict__ order, const int* __restrict__ off,
+                                double* __restrict__ cen)
+{
+    const int k = blockIdx.x, q = threadIdx.x;
+    if (q >= d) return;
+    double s = 0.0;
+    const int a = off[k], b = off[k + 1];
+    for (int t = a; t < b; ++t) s += X[(size_t)order[t] * d + q];
+    cen[(size_t)k * d + q] = s / (double)(b - a);
+}
+
+// cosine distance with the reference's sequential sums (sd.cpp:476-498); soft = 2 - d; argmax first-max-wins
+__global__ __launch_bounds__(64) void k_assign(const double* __restrict__ E, int64_t M, int d, const double* __restrict__ cen, int K,
+                                               int* __restrict__ hard, int* __restrict__ err)
+{
+    extern __shared__ double soft[];
+    const int64_t row = blockIdx.x;
+    const double* e = E + (size_t)row * d;
+    for (int k = threadIdx.x; k < K; k += 64) {
+        const double* cc = cen + (size_t)k * d;
+        double dot = 0.0, m1 = 0.0, m2 = 0.0;
+        for (int i = 0; i < d; ++i) { dot += e[i] * cc[i]; m1 += e[i] * e[i]; m2 += cc[i] * cc[i]; }
+        if (m1 == 0.0 || m2 == 0.0) { *err = 1; soft[k] = NAN; }
+        else soft[k] = 2.0 - (1.0 - (dot / (sqrt(m1) * sqrt(m2))));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0; double mv = -DBL_MAX;
+        for (int k = 0; k < K; ++k) if (soft[k] > mv) { mv = soft[k]; best = k; }
+        hard[row] = best;
+    }
+}
+
+static double cos_dist_host(const double* a, const double* b, int d, bool* err)      // sd.cpp:476-498
+{
+    double dot = 0.0, m1 = 0.0, m2 = 0.0;
+    for (int i = 0; i < d; ++i) { dot += a[i] * b[i]; m1 += a[i] * a[i]; m2 += b[i] * b[i]; }
+    if (m1 == 0.0 || m2 == 0.0) { *err = true; return NAN; }
+    return 1.0 - (dot / (sqrt(m1) * sqrt(m2)));
+}
+
+// group rows by label (ascending row order inside each group)
+static void group_by_label(const std::vector<int>& lab, int nl, std::vector<int>& order, std::vector<int>& off)
+{
+    off.assign((size_t)nl + 1, 0);
+    for (int v : lab) off[(size_t)v + 1]++;
+    for (int k = 0; k < nl; ++k) off[(size_t)k + 1] += off[(size_t)k];
+    order.resize(lab.size());
+    std::vector<int> pos(off.begin(), off.end() - 1);
+    for (size_t i = 0; i < lab.size(); ++i) order[(size_t)pos[(size_t)lab[i]]++] = (int)i;
+}
+
+// d_emb: [M][d] f64 (NaN rows = no embedding), M = chunks*3.  hard: [M]
+int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector<int>& hard, int* Kout)
+{
+    hard.assign((size_t)M, 0);
+    if (Kout) *Kout = 1;
+    if (M <= 0) return SD_OK;
+    // a10: rows whose first element is not NaN (sd.cpp:2224)
+    std::vector<double> first((size_t)M);
+    HIPCHK(c, hipMemcpy2DAsync(first.data(), sizeof(double), d_emb, (size_t)d * sizeof(double), sizeof(double), (size_t)M, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int> tidx;
+    for (int64_t i = 0; i < M; ++i) if (!std::isnan(first[(size_t)i])) tidx.push_back((int)i);
+    const int64_t N = (int64_t)tidx.size();
+    if (N < 2) return SD_OK;                                        // max_clusters < 2 -> all zeros (sd.cpp:2081-2088)
+    WS(c, int, d_tidx, "cl_tidx", N);
+    WS(c, double, X, "cl_X", N * d);
+    WS(c, double, Xn, "cl_Xn", N * d);
+    HIPCHK(c, hipMemcpyAsync(d_tidx, tidx.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_gather_normalize, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, c->stream, d_emb, d_tidx, N, d, X, Xn);
+    KCHECK(c);
+    // a12+a13 with the reference's float-typed threshold (sd.cpp:2049) promoted to double
+    const float thr = 0.7153814381597874;
+    std::vector<int> lab;
+    int rc = run_cluster_labels(c, Xn, N, d, (double)thr, lab);
+    if (rc) return rc;
+    int nl = 0;
+    for (auto& v : lab) { v -= 1; if (v + 1 > nl) nl = v + 1; }
+    // a11: size split
+    size_t mcs = std::min<size_t>(15, std::max<size_t>(1, (size_t)std::round(0.1 * (double)N)));     // sd.cpp:2308
+    std::vector<int> order, off;
+    group_by_label(lab, nl, order, off);
+    std::vector<int> large, small;
+    for (int k = 0; k < nl; ++k) {
+        const size_t cnt = (size_t)(off[(size_t)k + 1] - off[(size_t)k]);
+        if (cnt == 0) continue;
+        if (cnt >= mcs) large.push_back(k); else small.push_back(k);
+    }
+    if (large.empty()) {
+        // reference: assert(false) in assert-enabled builds (sd.cpp:2368), all-zero labels otherwise (sd.cpp:2371-2375)
+        std::fill(lab.begin(), lab.end(), 0);
+        nl = 1;
+    } else if (!small.empty()) {
+        WS(c, int, d_order, "cl_order", N);
+        WS(c, int, d_off, "cl_off", nl + 1);
+        WS(c, double, d_cen, "cl_cen", (size_t)nl * d);
+        HIPCHK(c, hipMemcpyAsync(d_order, order.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_off, off.data(), (size_t)(nl + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_cluster_means, dim3(nl), dim3(((d + 63) / 64) * 64), 0, c->stream, X, d, d_order, d_off, d_cen);   // means of UN-normalised rows (sd.cpp:2386)
+        KCHECK(c);
+        std::vector<double> cen((size_t)nl * d);
+        HIPCHK(c, hipMemcpyAsync(cen.data(), d_cen, cen.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        bool err = false;
+        std::vector<int> remap((size_t)nl);
+        for (int k = 0; k < nl; ++k) remap[(size_t)k] = k;
+        for (int sk : small) {
+            float minVal = FLT_MAX; int best = -1;                                      // float accumulator, sd.cpp:2396
+            for (size_t a = 0; a < large.size(); ++a) {
+                const double dd = cos_dist_host(&cen[(size_t)large[a] * d], &cen[(size_t)sk * d], d, &err);
+                if (dd < minVal) { minVal = (float)dd; best = (int)a; }
+            }
+            if (best >= 0) remap[(size_t)sk] = large[(size_t)best];
+        }
+        if (err) SD_FAIL(c, SD_ERR_NUMERIC, "zero-magnitude cluster centroid (reference throws, sd.cpp:493-495)");
+        for (auto& v : lab) v = remap[(size_t)v];
+        // findUniqueClusters: renumber 0..K-1 in sorted-id order (sd.cpp:519-548)
+        std::vector<int> seen((size_t)nl, -1);
+        for (int v : lab) seen[(size_t)v] = 0;
+        int nk = 0;
+        for (int k = 0; k < nl; ++k) if (seen[(size_t)k] == 0) seen[(size_t)k] = nk++;
+        for (auto& v : lab) v = seen[(size_t)v];
+        nl = nk;
+    }
+    // a14: centroids of the final clusters (un-normalised train rows), cosine cdist of ALL rows, argmax
+    group_by_label(lab, nl, order, off);
+    WS(c, int, d_order2, "cl_order", N);
+    WS(c, int, d_off2, "cl_off", nl + 1);
+    WS(c, double, d_cen2, "cl_cen", (size_t)nl * d);
+    WS(c, int, d_hard, "cl_hard", M);
+    WS(c, int, d_err, "cl_err", 4);
+    HIPCHK(c, hipMemcpyAsync(d_order2, order.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_off2, off.data(), (size_t)(nl + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_cluster_means, dim3(nl), dim3(((d + 63) / 64) * 64), 0, c->stream, X, d, d_order2, d_off2, d_cen2);
+    KCHECK(c);
+    hipLaunchKernelGGL(k_assign, dim3((unsigned)M), dim3(64), (size_t)nl * sizeof(double), c->stream, d_emb, M, d, d_cen2, nl, d_hard, d_err);
+    KCHECK(c);
+    int herr = 0;
+    HIPCHK(c, hipMemcpyAsync(hard.data(), d_hard, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (herr) SD_FAIL(c, SD_ERR_NUMERIC, "zero-magnitude embedding or centroid in assignment (reference throws, sd.cpp:493-495)");
+    if (Kout) *Kout = nl;
+    return SD_OK;
+}

@@ -1,0 +1,151 @@
+// common.h -- internal declarations shared by the HIP translation units of libsdhip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/sdhip.h"
+
+#define SD_T 501          // STFT frames per item (1 + 80000/160), sd.cpp:1980-2008
+#define SD_TP 512         // rows per item in activation buffers (T padded)
+#define SD_NBINS 201
+#define SD_NMELS 80
+#define SD_FEAT_LD 96     // mel channels padded to a multiple of 32
+
+struct KernelStat { double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + (bytes >> 3) + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return 1; }
+        cap = want; return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+// a conv / linear layer in device layout
+struct ConvLayer {
+    float* W = nullptr;       // [KT][Cout][CinPad] (Cin contiguous)
+    float* bias = nullptr;    // [Cout] or null
+    float* scale = nullptr;   // folded BatchNorm (applied after act1) or null
+    float* shift = nullptr;
+    int Cin = 0, CinPad = 0, Cout = 0, KT = 1, dil = 1;
+};
+
+struct ConvArgs {
+    const float* X; const float* X2; const float* W; float* Y;
+    const float* bias; const float* scale; const float* shift; const float* item_bias; const float* R;
+    int x_ld, x2_ld, y_ld, r_ld, ib_ld;
+    int M;                 // total output rows
+    int TpIn, TpOut;       // rows per item in input / output buffers
+    int Tin, T;            // valid rows per item in input / output
+    int Cin, Cout, KT, dil;
+    int pad_mode;          // 0 = "same" with reflect padding, 1 = "valid" (src row = t + kk*dil)
+    int act1, act2;        // act1: 0 none 1 relu 2 leaky(0.01); act2 (after BN): 0 none 1 tanh 2 sigmoid
+    int m_tiles, n_tiles;
+};
+
+struct EcapaWeights {
+    bool loaded = false;
+    float* mel_w = nullptr; int* mel_lo = nullptr; int* mel_cnt = nullptr; int* mel_off = nullptr; int mel_nnz = 0;
+    float* window = nullptr;          // [400] f32 periodic Hamming
+    double* tw_cos = nullptr;         // [400] cos(2 pi k/400)
+    double* tw_nsin = nullptr;        // [400] -sin(2 pi k/400)
+    ConvLayer block0;
+    struct SERes { ConvLayer tdnn1, res[7], tdnn2, se1, se2; int dil; } blk[3];
+    ConvLayer mfa, asp_tdnn_x, asp_tdnn_ms, asp_conv, fc;
+    int C = 1024;
+};
+
+struct SegWeights {
+    bool loaded = false;
+    float wn_w = 1, wn_b = 0;          // InstanceNorm1d(1) affine on the waveform
+    ConvLayer conv0, conv1, conv2;     // sincnet convs (conv0: Cin = 256 padded taps, x_ld = 10)
+    float* in_w[3] = {nullptr, nullptr, nullptr};   // InstanceNorm affine per stage
+    float* in_b[3] = {nullptr, nullptr, nullptr};
+    ConvLayer lstm_ih[4];              // [1024][in] both directions stacked, bias = b_ih + b_hh
+    float* lstm_hh[4][2] = {};         // [512][128] per layer, direction (PyTorch gate order i,f,g,o)
+    ConvLayer lin0, lin1;
+    float* cls_w = nullptr; float* cls_b = nullptr;   // [3][128], [3]
+};
+
+struct sd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    EcapaWeights ew;
+    SegWeights sw;
+    std::vector<void*> owned;                  // device allocations freed in sd_destroy
+    std::map<std::string, DevBuf> ws;          // named workspaces
+    std::map<std::string, KernelStat> stats;
+    bool profile = false;
+    std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t, double, double>> pending;
+    double stage_ms[4] = {0, 0, 0, 0};
+    int64_t emb_batch_items = 768;             // multiple of 96
+    int64_t seg_batch_chunks = 512;
+    int num_cu = 256;
+};
+
+#define SD_FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (ctx)->err = _b; return (code); } while (0)
+#define HIPCHK(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { SD_FAIL(ctx, SD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
+#define KCHECK(ctx) HIPCHK(ctx, hipGetLastError())
+
+// workspace helper
+template <class T> inline T* ws_get(sd_ctx* c, const char* name, size_t count) {
+    DevBuf& b = c->ws[name];
+    if (b.reserve(count * sizeof(T))) return nullptr;
+    return b.as<T>();
+}
+#define WS(ctx, T, var, name, count) T* var = ws_get<T>(ctx, name, (size_t)(count)); if (!var) SD_FAIL(ctx, SD_ERR_HIP, "hipMalloc of workspace %s (%zu bytes) failed", name, (size_t)(count) * sizeof(T))
+
+// profiling bracket: records events around one launch when ctx->profile is set
+struct ProfScope {
+    sd_ctx* c; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr; double flops, bytes;
+    ProfScope(sd_ctx* ctx, const char* n, double fl = 0, double by = 0) : c(ctx), name(n), flops(fl), bytes(by) {
+        if (c->profile) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream); }
+    }
+    ~ProfScope() {
+        if (c->profile) { (void)hipEventRecord(e1, c->stream); c->pending.emplace_back(name, e0, e1, flops, bytes); }
+        else { KernelStat& s = c->stats[name]; s.launches++; s.flops += flops; s.bytes += bytes; }
+    }
+};
+void sd_flush_profile(sd_ctx* c);   // api.cpp: resolves pending event pairs into stats
+
+// ---- conv_gemm.hip
+int launch_conv_gemm(sd_ctx* c, const ConvArgs& a, const char* tag);
+// ---- weights.cpp
+struct PackTensor { std::vector<int64_t> dims; std::vector<float> data; };
+typedef std::map<std::string, PackTensor> Pack;
+int load_pack(const char* path, Pack& out, std::string& err);
+int build_ecapa_weights(sd_ctx* c, const Pack& p);
+int build_seg_weights(sd_ctx* c, const Pack& p);
+// ---- frontend.hip
+int run_frontend(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item,
+                 float* d_feats /*[items][512][96]*/, float* d_wav_lens, int* d_nnorm, int* d_nvalid, int* d_flags);
+// ---- ecapa.hip
+int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_flags, int64_t items, float* d_emb);
+int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item, float* d_emb);
+// ---- pyannet.hip
+int run_segment(sd_ctx* c, const float* d_wav, int64_t n, int64_t chunk_lo, int64_t chunk_hi, float* d_seg);
+// ---- postseg.hip
+int run_postseg(sd_ctx* c, const float* d_seg, int64_t chunks, uint8_t* d_bin, float* d_masks, int* d_nact);
+int run_count(sd_ctx* c, const uint8_t* d_bin, int64_t chunks, int32_t* d_count, int64_t n_count);
+int64_t count_frames_host(int64_t chunks);
+int sd_np_rint_host(double v);
+int64_t closest_frame_host(double w_start, double w_step, double w_dur, double t);
+// ---- cluster.hip
+int run_linkage(sd_ctx* c, const double* d_Xn, int64_t N, int d, double* d_Z);
+int run_cluster_labels(sd_ctx* c, const double* d_Xn, int64_t N, int d, double cutoff, std::vector<int>& labels1);
+int run_clustering(sd_ctx* c, const double* d_emb /*[M][d] f64*/, int64_t M, int d, std::vector<int>& hard, int* K);
+void fcluster_host(const std::vector<double>& Z, int64_t n, double cutoff, std::vector<int>& T);
+// ---- reconstruct.hip
+int run_reconstruct(sd_ctx* c, const float* d_seg, const int* d_nact, const int* d_hard, const int32_t* d_count,
+                    int64_t n_count, int64_t chunks, int64_t n_samples, int K, std::vector<sd_turn>& turns);

@@ -1,0 +1,209 @@
+// ecapa.hip -- ECAPA-TDNN (C=1024, attention 128, 192-d) body of the embedding model.
+// Replaces EmbeddingModel1::_infer's Ort::Session::Run on emd4.onnx (sd.cpp:1889-1970);
+// architecture = speechbrain 0.5.14 ECAPA_TDNN as exported by embeddings/export3.py:151-190.
+//
+// All dense contractions run through conv_gemm.hip (f32 MFMA).  This file holds the
+// HBM-bound glue kernels (masked SE mean, SE apply + residual, ASP statistics and the
+// attentive softmax pooling) and the layer schedule.  Activations are channels-last
+// [item][512][C]; rows >= 501 are kept at zero.
+#include "common.h"
+
+// masked mean over the first nvalid[item] frames  -> out[item][C]   (SEBlock, lengths given)
+__global__ void k_masked_mean(const float* __restrict__ x, int ld, const int* __restrict__ nvalid, float* __restrict__ out, int C)
+{
+    const int item = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= C) return;
+    const int nv = nvalid[item];
+    const float* p = x + (size_t)item * SD_TP * ld + ch;
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int t = 0;
+    for (; t + 3 < nv; t += 4) { s0 += p[(size_t)t * ld]; s1 += p[(size_t)(t + 1) * ld]; s2 += p[(size_t)(t + 2) * ld]; s3 += p[(size_t)(t + 3) * ld]; }
+    for (; t < nv; ++t) s0 += p[(size_t)t * ld];
+    out[(size_t)item * C + ch] = ((s0 + s1) + (s2 + s3)) / (float)nv;
+}
+
+// y = gate[item][c] * t2 + residual   (SERes2NetBlock tail), float4 over channels
+__global__ void k_se_apply(const float* __restrict__ t2, const float* __restrict__ gate, const float* __restrict__ res, int res_ld,
+                           float* __restrict__ y, int y_ld, int C, int64_t rows)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4n = C / 4;
+    if (idx >= rows * c4n) return;
+    const int64_t row = idx / c4n;
+    const int c = (int)(idx - row * c4n) * 4;
+    const int64_t item = row / SD_TP;
+    const float4 a = *(const float4*)(t2 + row * C + c);
+    const float4 g = *(const float4*)(gate + item * C + c);
+    const float4 r = *(const float4*)(res + row * res_ld + c);
+    float4 o;
+    o.x = g.x * a.x + r.x; o.y = g.y * a.y + r.y; o.z = g.z * a.z + r.z; o.w = g.w * a.w + r.w;
+    *(float4*)(y + row * y_ld + c) = o;
+}
+
+// copy a channel slice [rows][w] between strided buffers (Res2Net first sub-band is identity)
+__global__ void k_copy_slice(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld, int w, int64_t rows)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w4 = w / 4;
+    if (idx >= rows * w4) return;
+    const int64_t row = idx / w4;
+    const int c = (int)(idx - row * w4) * 4;
+    *(float4*)(dst + row * dst_ld + c) = *(const float4*)(src + row * src_ld + c);
+}
+
+// ASP global-context statistics: mean / std over valid frames -> ms[item][2C]
+__global__ void k_asp_stats(const float* __restrict__ x, int ld, const int* __restrict__ nvalid, float* __restrict__ ms, int C)
+{
+    const int item = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= C) return;
+    const int nv = nvalid[item];
+    const float* p = x + (size_t)item * SD_TP * ld + ch;
+    const float inv = 1.0f / (float)nv;
+    float s = 0;
+    for (int t = 0; t < nv; ++t) s += p[(size_t)t * ld] * inv;
+    float v = 0;
+    for (int t = 0; t < nv; ++t) { const float d = p[(size_t)t * ld] - s; v += inv * d * d; }
+    ms[(size_t)item * 2 * C + ch] = s;
+    ms[(size_t)item * 2 * C + C + ch] = sqrtf(fmaxf(v, 1e-12f));
+}
+
+// attentive statistics pooling: masked softmax over time of the logits, weighted mean/std of x
+__global__ void k_asp_pool(const float* __restrict__ x, const float* __restrict__ logit, int ld, const int* __restrict__ nvalid,
+                           float* __restrict__ pooled, int C)
+{
+    const int item = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= C) return;
+    const int nv = nvalid[item];
+    const float* px = x + (size_t)item * SD_TP * ld + ch;
+    const float* pl = logit + (size_t)item * SD_TP * ld + ch;
+    float mx = -INFINITY;
+    for (int t = 0; t < nv; ++t) mx = fmaxf(mx, pl[(size_t)t * ld]);
+    float z = 0, s1 = 0;
+    for (int t = 0; t < nv; ++t) { const float e = expf(pl[(size_t)t * ld] - mx); z += e; s1 += e * px[(size_t)t * ld]; }
+    const float mean = s1 / z;
+    float s2 = 0;
+    for (int t = 0; t < nv; ++t) { const float e = expf(pl[(size_t)t * ld] - mx); const float d = px[(size_t)t * ld] - mean; s2 += e * d * d; }
+    pooled[(size_t)item * 2 * C + ch] = mean;
+    pooled[(size_t)item * 2 * C + C + ch] = sqrtf(fmaxf(s2 / z, 1e-12f));
+}
+
+// rows flagged too-short become NaN (sd.cpp:2541-2549)
+__global__ void k_nan_rows(float* __restrict__ emb, const int* __restrict__ flags, int64_t items)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= items * SD_EMB_DIM) return;
+    if (flags[idx / SD_EMB_DIM]) emb[idx] = __int_as_float(0x7fc00000);
+}
+
+static ConvArgs conv_args(const ConvLayer& L, const float* X, int x_ld, float* Y, int y_ld, int64_t M, bool per_item)
+{
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = X; a.x_ld = x_ld; a.Y = Y; a.y_ld = y_ld; a.W = L.W;
+    a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.M = (int)M;
+    if (per_item) { a.TpIn = a.TpOut = SD_TP; a.Tin = a.T = SD_T; }
+    else { a.TpIn = a.TpOut = (int)M; a.Tin = a.T = (int)M; }
+    a.Cin = L.CinPad; a.Cout = L.Cout; a.KT = L.KT; a.dil = L.dil;
+    a.pad_mode = 0;
+    return a;
+}
+
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+
+int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_flags, int64_t items, float* d_emb)
+{
+    const EcapaWeights& E = c->ew;
+    if (!E.loaded) SD_FAIL(c, SD_ERR_MODEL, "embedding model not loaded");
+    if (items <= 0) return SD_OK;
+    const int C = E.C, C3 = 3 * C;
+    const int64_t M = items * SD_TP;
+    if (M > 0x7fffffff / 2) SD_FAIL(c, SD_ERR_ARG, "ecapa batch too large");
+    WS(c, float, x0, "ec_x0", M * C);
+    WS(c, float, t1, "ec_t1", M * C);
+    WS(c, float, rr, "ec_r", M * C);
+    WS(c, float, t2, "ec_t2", M * C);
+    WS(c, float, cat, "ec_cat", M * C3);
+    WS(c, float, mfa, "ec_mfa", M * C3);
+    WS(c, float, hid, "ec_hid", M * 128);
+    WS(c, float, se_s, "ec_se_s", items * C);
+    WS(c, float, se_h, "ec_se_h", items * 128);
+    WS(c, float, se_g, "ec_se_g", items * C);
+    WS(c, float, ms, "ec_ms", items * 2 * C3);
+    WS(c, float, ib, "ec_ib", items * 128);
+    WS(c, float, pooled, "ec_pooled", items * 2 * C3);
+    int rc;
+    hipStream_t st = c->stream;
+
+    // blocks[0]: TDNNBlock(80 -> C, k5)
+    { ConvArgs a = conv_args(E.block0, d_feats, SD_FEAT_LD, x0, C, M, true); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "block0"))) return rc; }
+
+    for (int b = 0; b < 3; ++b) {
+        const auto& B = E.blk[b];
+        const float* xin = (b == 0) ? x0 : cat + (size_t)(b - 1) * C;
+        const int xin_ld = (b == 0) ? C : C3;
+        { ConvArgs a = conv_args(B.tdnn1, xin, xin_ld, t1, C, M, true); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "tdnn1"))) return rc; }
+        const int S = C / 8;
+        hipLaunchKernelGGL(k_copy_slice, GRID1(M * (S / 4)), 0, st, t1, C, rr, C, S, M);
+        KCHECK(c);
+        for (int i = 1; i < 8; ++i) {
+            ConvArgs a = conv_args(B.res[i - 1], t1 + i * S, C, rr + i * S, C, M, true);
+            a.act1 = 1;
+            if (i >= 2) { a.X2 = rr + (i - 1) * S; a.x2_ld = C; }
+            if ((rc = launch_conv_gemm(c, a, "res2net"))) return rc;
+        }
+        { ConvArgs a = conv_args(B.tdnn2, rr, C, t2, C, M, true); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "tdnn2"))) return rc; }
+        {
+            ProfScope ps(c, "se_mean", 0, (double)items * SD_T * C * 4.0);
+            hipLaunchKernelGGL(k_masked_mean, dim3((C + 255) / 256, (unsigned)items), dim3(256), 0, st, t2, C, d_nvalid, se_s, C);
+            KCHECK(c);
+        }
+        { ConvArgs a = conv_args(B.se1, se_s, C, se_h, 128, items, false); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "se1"))) return rc; }
+        { ConvArgs a = conv_args(B.se2, se_h, 128, se_g, C, items, false); a.act2 = 2; if ((rc = launch_conv_gemm(c, a, "se2"))) return rc; }
+        {
+            ProfScope ps(c, "se_apply", 0, (double)M * C * 12.0);
+            hipLaunchKernelGGL(k_se_apply, GRID1(M * (C / 4)), 0, st, t2, se_g, xin, xin_ld, cat + (size_t)b * C, C3, C, M);
+            KCHECK(c);
+        }
+    }
+    // mfa: TDNNBlock(3C -> 3C, k1) over cat(x1,x2,x3)
+    { ConvArgs a = conv_args(E.mfa, cat, C3, mfa, C3, M, true); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
+    // ASP with global context: cat[x, mean, std] @ W == x @ Wx + (mean,std) @ Wms  (per-item bias)
+    {
+        ProfScope ps(c, "asp_stats", 0, (double)items * SD_T * C3 * 8.0);
+        hipLaunchKernelGGL(k_asp_stats, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, C3, d_nvalid, ms, C3);
+        KCHECK(c);
+    }
+    { ConvArgs a = conv_args(E.asp_tdnn_ms, ms, 2 * C3, ib, 128, items, false); if ((rc = launch_conv_gemm(c, a, "asp_ms"))) return rc; }
+    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, C3, hid, 128, M, true); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
+    float* logits = cat;   // cat is dead after mfa
+    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, M, true); if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
+    {
+        ProfScope ps(c, "asp_pool", 0, (double)items * SD_T * C3 * 8.0 * 2.0);
+        hipLaunchKernelGGL(k_asp_pool, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, C3, d_nvalid, pooled, C3);
+        KCHECK(c);
+    }
+    // asp_bn folded into fc
+    { ConvArgs a = conv_args(E.fc, pooled, 2 * C3, d_emb, SD_EMB_DIM, items, false); if ((rc = launch_conv_gemm(c, a, "fc"))) return rc; }
+    hipLaunchKernelGGL(k_nan_rows, GRID1(items * SD_EMB_DIM), 0, st, d_emb, d_flags, items);
+    KCHECK(c);
+    return SD_OK;
+}
+
+int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item, float* d_emb)
+{
+    int64_t nb = c->emb_batch_items;
+    nb = (nb / 96) * 96; if (nb < 96) nb = 96;
+    int rc;
+    for (int64_t i0 = 0; i0 < items; i0 += nb) {
+        const int64_t cnt = (items - i0 < nb) ? items - i0 : nb;
+        WS(c, float, feats, "emb_feats", nb * SD_TP * SD_FEAT_LD);
+        WS(c, float, lens, "emb_lens", nb);
+        WS(c, int, nnorm, "emb_nnorm", nb);
+        WS(c, int, nvalid, "emb_nvalid", nb);
+        WS(c, int, flags, "emb_flags", nb);
+        if ((rc = run_frontend(c, d_wav, n, d_masks + (size_t)i0 * SD_FRAMES, cnt, first_item + i0, feats, lens, nnorm, nvalid, flags))) return rc;
+        if ((rc = run_ecapa(c, feats, nvalid, flags, cnt, d_emb + (size_t)i0 * SD_EMB_DIM))) return rc;
+    }
+    return SD_OK;
+}

@@ -1,0 +1,278 @@
+// pipeline.cpp -- stage wrappers and the whole-path driver behind the C ABI.
+// speakerDiarization() (sd.cpp:2937-3234) re-stated as: scale pcm -> segmentation -> post-seg ->
+// embeddings -> [multi-GPU: all-gather here] -> count, clustering, reconstruction, annotation.
+#include "common.h"
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+
+struct DevTmp {
+    void* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : 1; }
+};
+#define DTMP(ctx, var, bytes) DevTmp var; if (var.alloc(bytes)) SD_FAIL(ctx, SD_ERR_HIP, "hipMalloc(%zu) failed", (size_t)(bytes))
+#define ENTER(ctx) do { if (!(ctx)) return SD_ERR_ARG; (ctx)->err.clear(); if (hipSetDevice((ctx)->device) != hipSuccess) SD_FAIL(ctx, SD_ERR_HIP, "hipSetDevice failed"); } while (0)
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+
+// a1 tail: input_wav[i] = sample * 1.0f / 32768.0 (sd.cpp:2948-2951); division by 2^15 is exact in f32
+__global__ void k_pcm_to_f32(const int16_t* __restrict__ pcm, float* __restrict__ wav, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) wav[i] = (float)pcm[i] * (1.0f / 32768.0f);
+}
+// embeddings are widened to double before clustering (sd.cpp:2555)
+__global__ void k_f32_to_f64(const float* __restrict__ a, double* __restrict__ b, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = (double)a[i];
+}
+__global__ void k_mark_inactive(int* __restrict__ hard, const int* __restrict__ nact, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && nact[i] == 0) hard[i] = -2;                                  // sd.cpp:3172-3191
+}
+
+static double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------ a2+a3
+extern "C" int sd_segment_dev(sd_ctx* c, const float* d_wav, int64_t n, float* d_out, int64_t chunks)
+{
+    ENTER(c);
+    if (!d_wav || !d_out || n <= 1) SD_FAIL(c, SD_ERR_ARG, "sd_segment_dev: bad argument");
+    if (chunks != sd_num_chunks(n, nullptr)) SD_FAIL(c, SD_ERR_ARG, "sd_segment_dev: chunks must equal sd_num_chunks(n)");
+    int rc = run_segment(c, d_wav, n, 0, chunks, d_out);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SD_OK;
+}
+
+extern "C" int sd_segment(sd_ctx* c, const float* h_wav, int64_t n, float* h_out, int64_t* chunks)
+{
+    ENTER(c);
+    if (!h_wav || !h_out || !chunks) SD_FAIL(c, SD_ERR_ARG, "sd_segment: bad argument");
+    const int64_t nc = sd_num_chunks(n, nullptr);
+    *chunks = nc;
+    if (nc <= 0) SD_FAIL(c, SD_ERR_SHORT, "audio of %lld samples yields no chunk", (long long)n);
+    DTMP(c, dw, n * sizeof(float)); DTMP(c, ds, nc * SD_FRAMES * 3 * sizeof(float));
+    HIPCHK(c, hipMemcpy(dw.p, h_wav, n * sizeof(float), hipMemcpyHostToDevice));
+    int rc = run_segment(c, (const float*)dw.p, n, 0, nc, (float*)ds.p);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h_out, ds.p, nc * SD_FRAMES * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+// ------------------------------------------------------------------ a4-a6
+extern "C" int sd_postseg(sd_ctx* c, const float* h_seg, int64_t chunks, uint8_t* h_bin, float* h_masks,
+                          int32_t* h_count, int64_t cap_count, int64_t* n_count)
+{
+    ENTER(c);
+    if (!h_seg || chunks <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_postseg: bad argument");
+    const int64_t ne = chunks * SD_FRAMES * 3;
+    const int64_t nf = count_frames_host(chunks);
+    if (n_count) *n_count = nf;
+    if (h_count && cap_count < nf) SD_FAIL(c, SD_ERR_ARG, "sd_postseg: count capacity %lld < %lld", (long long)cap_count, (long long)nf);
+    DTMP(c, ds, ne * sizeof(float)); DTMP(c, db, ne); DTMP(c, dm, ne * sizeof(float)); DTMP(c, dn, chunks * 3 * sizeof(int)); DTMP(c, dc, nf * sizeof(int32_t));
+    HIPCHK(c, hipMemcpy(ds.p, h_seg, ne * sizeof(float), hipMemcpyHostToDevice));
+    int rc = run_postseg(c, (const float*)ds.p, chunks, (uint8_t*)db.p, (float*)dm.p, (int*)dn.p);
+    if (rc) return rc;
+    if ((rc = run_count(c, (const uint8_t*)db.p, chunks, (int32_t*)dc.p, nf))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_bin) HIPCHK(c, hipMemcpy(h_bin, db.p, ne, hipMemcpyDeviceToHost));
+    if (h_masks) HIPCHK(c, hipMemcpy(h_masks, dm.p, ne * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_count) HIPCHK(c, hipMemcpy(h_count, dc.p, nf * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+// ------------------------------------------------------------------ a12-a14
+extern "C" int sd_linkage(sd_ctx* c, const double* h_X, int64_t N, int d, double* h_Z)
+{
+    ENTER(c);
+    if (!h_X || !h_Z || N < 2 || d <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_linkage: need N >= 2");
+    DTMP(c, dx, N * d * sizeof(double)); DTMP(c, dz, (N - 1) * 4 * sizeof(double));
+    HIPCHK(c, hipMemcpy(dx.p, h_X, N * d * sizeof(double), hipMemcpyHostToDevice));
+    int rc = run_linkage(c, (const double*)dx.p, N, d, (double*)dz.p);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h_Z, dz.p, (N - 1) * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+extern "C" int sd_cluster(sd_ctx* c, const double* h_X, int64_t N, int d, double cutoff, int32_t* h_labels1)
+{
+    ENTER(c);
+    if (!h_X || !h_labels1 || N < 1 || d <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_cluster: bad argument");
+    DTMP(c, dx, N * d * sizeof(double));
+    HIPCHK(c, hipMemcpy(dx.p, h_X, N * d * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<int> lab;
+    int rc = run_cluster_labels(c, (const double*)dx.p, N, d, cutoff, lab);
+    if (rc) return rc;
+    for (int64_t i = 0; i < N; ++i) h_labels1[i] = lab[(size_t)i];
+    return SD_OK;
+}
+
+extern "C" int sd_clustering(sd_ctx* c, const double* h_emb, int64_t chunks, int d, int32_t* h_hard, int32_t* n_clusters)
+{
+    ENTER(c);
+    if (!h_emb || !h_hard || chunks <= 0 || d <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_clustering: bad argument");
+    const int64_t M = chunks * SD_SPEAKERS;
+    DTMP(c, de, M * d * sizeof(double));
+    HIPCHK(c, hipMemcpy(de.p, h_emb, M * d * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<int> hard; int K = 1;
+    int rc = run_clustering(c, (const double*)de.p, M, d, hard, &K);
+    if (rc) return rc;
+    for (int64_t i = 0; i < M; ++i) h_hard[i] = hard[(size_t)i];
+    if (n_clusters) *n_clusters = K;
+    return SD_OK;
+}
+
+static int turns_out(sd_ctx* c, const std::vector<sd_turn>& v, sd_turn** turns, int64_t* n_turns)
+{
+    sd_turn* t = (sd_turn*)malloc(sizeof(sd_turn) * (v.size() ? v.size() : 1));
+    if (!t) SD_FAIL(c, SD_ERR_ARG, "out of host memory");
+    for (size_t i = 0; i < v.size(); ++i) t[i] = v[i];
+    *turns = t; *n_turns = (int64_t)v.size();
+    return SD_OK;
+}
+
+// ------------------------------------------------------------------ a15-a17
+extern "C" int sd_reconstruct(sd_ctx* c, const float* h_seg, const uint8_t* h_bin, const int32_t* h_hard, const int32_t* h_count,
+                              int64_t n_count, int64_t chunks, int64_t n_samples, sd_turn** turns, int64_t* n_turns)
+{
+    ENTER(c);
+    if (!h_seg || !h_bin || !h_hard || !h_count || !turns || !n_turns || chunks <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_reconstruct: bad argument");
+    const int64_t ne = chunks * SD_FRAMES * 3;
+    std::vector<int> hard((size_t)chunks * 3);
+    int K = 0;
+    for (int64_t i = 0; i < chunks; ++i)
+        for (int k = 0; k < 3; ++k) {
+            int s = 0;
+            for (int f = 0; f < SD_FRAMES; ++f) s += h_bin[(i * SD_FRAMES + f) * 3 + k];
+            int h = h_hard[i * 3 + k];
+            if (s == 0) h = -2;
+            hard[(size_t)(i * 3 + k)] = h;
+            if (h > K) K = h;
+        }
+    K += 1;                                                                   // sd.cpp:2803-2812
+    DTMP(c, ds, ne * sizeof(float)); DTMP(c, dh, chunks * 3 * sizeof(int)); DTMP(c, dc, (n_count > 0 ? n_count : 1) * sizeof(int32_t));
+    HIPCHK(c, hipMemcpy(ds.p, h_seg, ne * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dh.p, hard.data(), chunks * 3 * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dc.p, h_count, n_count * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::vector<sd_turn> v;
+    int rc = run_reconstruct(c, (const float*)ds.p, nullptr, (const int*)dh.p, (const int32_t*)dc.p, n_count, chunks, n_samples, K, v);
+    if (rc) return rc;
+    return turns_out(c, v, turns, n_turns);
+}
+
+// ------------------------------------------------------------------ sharded inference + finalize
+static int get_wav(sd_ctx* c, const int16_t* d_pcm, int64_t n, float** d_wav)
+{
+    WS(c, float, w, "wav_f32", n + 512);
+    hipLaunchKernelGGL(k_pcm_to_f32, GRID1(n), 0, c->stream, d_pcm, w, n);
+    KCHECK(c);
+    *d_wav = w;
+    return SD_OK;
+}
+
+static int shard_infer(sd_ctx* c, const float* d_wav, int64_t n, int64_t lo, int64_t hi, float* d_seg, float* d_emb)
+{
+    const int64_t nc = hi - lo;
+    if (nc <= 0) return SD_OK;
+    if ((lo * SD_SPEAKERS) % SD_EMB_BATCH != 0) SD_FAIL(c, SD_ERR_ARG, "shard start %lld must be a multiple of 32 chunks", (long long)lo);
+    int rc;
+    const double t0 = now_ms();
+    if ((rc = run_segment(c, d_wav, n, lo, hi, d_seg))) return rc;
+    WS(c, float, d_masks, "sh_masks", nc * 3 * SD_FRAMES);
+    if ((rc = run_postseg(c, d_seg, nc, nullptr, d_masks, nullptr))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double t1 = now_ms();
+    c->stage_ms[0] += t1 - t0;
+    if ((rc = run_embed(c, d_wav, n, d_masks, nc * 3, lo * 3, d_emb))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stage_ms[1] += now_ms() - t1;
+    return SD_OK;
+}
+
+static int finalize(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t chunks, int64_t n, std::vector<sd_turn>& v)
+{
+    int rc;
+    const double t0 = now_ms();
+    const int64_t M = chunks * SD_SPEAKERS;
+    const int64_t nf = count_frames_host(chunks);
+    WS(c, uint8_t, d_bin, "fin_bin", chunks * SD_FRAMES * 3);
+    WS(c, int, d_nact, "fin_nact", M);
+    WS(c, int32_t, d_count, "fin_count", nf);
+    WS(c, double, d_e64, "fin_e64", M * SD_EMB_DIM);
+    WS(c, int, d_hard, "fin_hard", M);
+    if ((rc = run_postseg(c, d_seg, chunks, d_bin, nullptr, d_nact))) return rc;
+    if ((rc = run_count(c, d_bin, chunks, d_count, nf))) return rc;
+    hipLaunchKernelGGL(k_f32_to_f64, GRID1(M * SD_EMB_DIM), 0, c->stream, d_emb, d_e64, M * SD_EMB_DIM);
+    KCHECK(c);
+    std::vector<int> hard; int K = 1;
+    if ((rc = run_clustering(c, d_e64, M, SD_EMB_DIM, hard, &K))) return rc;
+    HIPCHK(c, hipMemcpyAsync(d_hard, hard.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_mark_inactive, GRID1(M), 0, c->stream, d_hard, d_nact, M);
+    KCHECK(c);
+    HIPCHK(c, hipMemcpyAsync(hard.data(), d_hard, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int Kr = 0;
+    for (int h : hard) if (h > Kr) Kr = h;
+    Kr += 1;                                                                  // sd.cpp:2803-2812
+    if ((rc = run_reconstruct(c, d_seg, d_nact, d_hard, d_count, nf, chunks, n, Kr, v))) return rc;
+    c->stage_ms[2] += now_ms() - t0;
+    return SD_OK;
+}
+
+extern "C" int sd_shard_infer_dev(sd_ctx* c, const int16_t* d_pcm, int64_t n, int64_t chunk_lo, int64_t chunk_hi, float* d_seg, float* d_emb)
+{
+    ENTER(c);
+    if (!d_pcm || !d_seg || !d_emb || n <= 1) SD_FAIL(c, SD_ERR_ARG, "sd_shard_infer_dev: bad argument");
+    float* d_wav = nullptr;
+    int rc = get_wav(c, d_pcm, n, &d_wav);
+    if (rc) return rc;
+    for (int i = 0; i < 4; ++i) c->stage_ms[i] = 0;
+    return shard_infer(c, d_wav, n, chunk_lo, chunk_hi, d_seg, d_emb);
+}
+
+extern "C" int sd_finalize_dev(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t chunks, int64_t n, sd_turn** turns, int64_t* n_turns)
+{
+    ENTER(c);
+    if (!d_seg || !d_emb || !turns || !n_turns || chunks <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_finalize_dev: bad argument");
+    std::vector<sd_turn> v;
+    int rc = finalize(c, d_seg, d_emb, chunks, n, v);
+    if (rc) return rc;
+    return turns_out(c, v, turns, n_turns);
+}
+
+extern "C" int sd_diarize_dev(sd_ctx* c, const int16_t* d_pcm, int64_t n, sd_turn** turns, int64_t* n_turns)
+{
+    ENTER(c);
+    if (!d_pcm || !turns || !n_turns) SD_FAIL(c, SD_ERR_ARG, "sd_diarize_dev: bad argument");
+    const double t0 = now_ms();
+    const int64_t chunks = sd_num_chunks(n, nullptr);
+    if (chunks <= 0) SD_FAIL(c, SD_ERR_SHORT, "audio of %lld samples yields no chunk", (long long)n);
+    for (int i = 0; i < 4; ++i) c->stage_ms[i] = 0;
+    float* d_wav = nullptr;
+    int rc = get_wav(c, d_pcm, n, &d_wav);
+    if (rc) return rc;
+    WS(c, float, d_seg, "dz_seg", chunks * SD_FRAMES * 3);
+    WS(c, float, d_emb, "dz_emb", chunks * 3 * SD_EMB_DIM);
+    if ((rc = shard_infer(c, d_wav, n, 0, chunks, d_seg, d_emb))) return rc;
+    std::vector<sd_turn> v;
+    if ((rc = finalize(c, d_seg, d_emb, chunks, n, v))) return rc;
+    c->stage_ms[3] = now_ms() - t0;
+    return turns_out(c, v, turns, n_turns);
+}
+
+extern "C" int sd_diarize(sd_ctx* c, const int16_t* h_pcm, int64_t n, sd_turn** turns, int64_t* n_turns)
+{
+    ENTER(c);
+    if (!h_pcm || n <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_diarize: bad argument");
+    DTMP(c, dp, n * sizeof(int16_t));
+    HIPCHK(c, hipMemcpy(dp.p, h_pcm, n * sizeof(int16_t), hipMemcpyHostToDevice));
+    return sd_diarize_dev(c, (const int16_t*)dp.p, n, turns, n_turns);
+}

@@ -1,0 +1,268 @@
+"""ctypes mirror of include/sdhip.h -- the host-side binding the tests, bench.py and
+__graft_entry__ use.  It only loads libsdhip.so (built in-tree next to this file) and
+fails loudly when the library or the GPU is missing: there is no CPU fallback.
+
+Names follow the reference's operator seams: segment ~ SegmentModel::slide,
+embed ~ getEmbedding + EmbeddingModel1::infer, cluster ~ Clustering::cluster,
+diarize ~ speakerDiarization()."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdhip.so")
+
+CHUNK, HOP, FRAMES, SPEAKERS, EMB_DIM, EMB_BATCH = 80000, 8000, 293, 3, 192, 32
+T_FRAMES, N_MELS = 501, 80
+
+
+class Turn(C.Structure):
+    _fields_ = [("start", C.c_double), ("end", C.c_double), ("label", C.c_int32), ("_pad", C.c_int32)]
+
+
+class SdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libsdhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+# every symbol include/sdhip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "sd_create", "sd_destroy", "sd_last_error", "sd_create_error", "sd_num_chunks", "sd_segment", "sd_segment_dev",
+    "sd_postseg", "sd_count_frames", "sd_embed", "sd_embed_dev", "sd_frontend", "sd_ecapa", "sd_linkage", "sd_cluster",
+    "sd_clustering", "sd_reconstruct", "sd_diarize", "sd_diarize_dev", "sd_free_turns", "sd_shard_infer_dev",
+    "sd_finalize_dev", "sd_read_wav", "sd_free_pcm", "sd_format_turn", "sd_stage_ms", "sd_kernel_stats",
+    "sd_reset_stats", "sd_set_option",
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libsdhip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or make -C '%s')" % _HERE)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+    L.sd_create.restype = vp
+    L.sd_create.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.sd_destroy.argtypes = [vp]
+    L.sd_last_error.restype = C.c_char_p
+    L.sd_last_error.argtypes = [vp]
+    L.sd_create_error.restype = C.c_char_p
+    L.sd_num_chunks.restype = i64
+    L.sd_num_chunks.argtypes = [i64, C.POINTER(i64)]
+    L.sd_count_frames.restype = i64
+    L.sd_count_frames.argtypes = [i64]
+    L.sd_segment.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
+    L.sd_segment_dev.argtypes = [vp, vp, i64, vp, i64]
+    L.sd_postseg.argtypes = [vp, vp, i64, vp, vp, vp, i64, C.POINTER(i64)]
+    L.sd_embed.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.sd_embed_dev.argtypes = [vp, vp, i64, vp, i64, i64, vp]
+    L.sd_frontend.argtypes = [vp, vp, i64, vp, i64, vp, vp]
+    L.sd_ecapa.argtypes = [vp, vp, vp, i64, vp]
+    L.sd_linkage.argtypes = [vp, vp, i64, C.c_int, vp]
+    L.sd_cluster.argtypes = [vp, vp, i64, C.c_int, dbl, vp]
+    L.sd_clustering.argtypes = [vp, vp, i64, C.c_int, vp, C.POINTER(i32)]
+    L.sd_reconstruct.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
+    L.sd_diarize.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
+    L.sd_diarize_dev.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
+    L.sd_free_turns.argtypes = [C.POINTER(Turn)]
+    L.sd_shard_infer_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+    L.sd_finalize_dev.argtypes = [vp, vp, vp, i64, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
+    L.sd_read_wav.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
+    L.sd_free_pcm.argtypes = [C.POINTER(C.c_int16)]
+    L.sd_format_turn.argtypes = [C.POINTER(Turn), C.c_char_p, C.c_int]
+    L.sd_stage_ms.argtypes = [vp, C.POINTER(dbl)]
+    L.sd_kernel_stats.argtypes = [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
+    L.sd_reset_stats.argtypes = [vp]
+    L.sd_set_option.argtypes = [vp, C.c_char_p, i64]
+    _lib = L
+    return L
+
+
+def num_chunks(n):
+    ll = C.c_int64(0)
+    c = lib().sd_num_chunks(n, C.byref(ll))
+    return int(c), int(ll.value)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def format_turn(t):
+    tt = Turn(t[0], t[1], t[2], 0)
+    buf = C.create_string_buffer(128)
+    lib().sd_format_turn(C.byref(tt), buf, 128)
+    return buf.value.decode()
+
+
+def read_wav(path):
+    p = C.POINTER(C.c_int16)()
+    n, sr, ch = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+    rc = lib().sd_read_wav(path.encode(), C.byref(p), C.byref(n), C.byref(sr), C.byref(ch))
+    if rc:
+        raise SdError(rc, "cannot read wav " + path)
+    total = n.value * max(ch.value, 1)
+    arr = np.ctypeslib.as_array(p, shape=(total,)).copy()
+    lib().sd_free_pcm(p)
+    return arr[:n.value], sr.value, ch.value
+
+
+class Diarizer:
+    """one libsdhip context on one GPU (not thread-safe, like the reference's OnnxModel statics)"""
+
+    def __init__(self, seg_model=None, emb_model=None, device=0):
+        L = lib()
+        self._h = L.sd_create(seg_model.encode() if seg_model else None, emb_model.encode() if emb_model else None, device)
+        if not self._h:
+            raise SdError(-1, L.sd_create_error().decode())
+
+    def close(self):
+        if self._h:
+            lib().sd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise SdError(rc, lib().sd_last_error(self._h).decode())
+
+    def set_option(self, key, value):
+        self._chk(lib().sd_set_option(self._h, key.encode(), int(value)))
+
+    # ---- a2+a3
+    def segment(self, wav):
+        wav = np.ascontiguousarray(wav, np.float32)
+        c, _ = num_chunks(len(wav))
+        out = np.zeros((c, FRAMES, SPEAKERS), np.float32)
+        cc = C.c_int64(0)
+        self._chk(lib().sd_segment(self._h, _ptr(wav), len(wav), _ptr(out), C.byref(cc)))
+        return out[:cc.value]
+
+    # ---- a4-a6
+    def postseg(self, seg):
+        seg = np.ascontiguousarray(seg, np.float32)
+        c = seg.shape[0]
+        nb = np.zeros((c, FRAMES, SPEAKERS), np.uint8)
+        masks = np.zeros((c * SPEAKERS, FRAMES), np.float32)
+        cap = int(lib().sd_count_frames(c))
+        count = np.zeros(max(cap, 1), np.int32)
+        nc = C.c_int64(0)
+        self._chk(lib().sd_postseg(self._h, _ptr(seg), c, _ptr(nb), _ptr(masks), _ptr(count), cap, C.byref(nc)))
+        return nb, masks, count[:nc.value]
+
+    # ---- a6-a9
+    def embed(self, wav, masks):
+        wav = np.ascontiguousarray(wav, np.float32)
+        masks = np.ascontiguousarray(masks, np.float32)
+        items = masks.shape[0]
+        out = np.zeros((items, EMB_DIM), np.float32)
+        self._chk(lib().sd_embed(self._h, _ptr(wav), len(wav), _ptr(masks), items, _ptr(out)))
+        return out
+
+    def frontend(self, wav, masks):
+        wav = np.ascontiguousarray(wav, np.float32)
+        masks = np.ascontiguousarray(masks, np.float32)
+        items = masks.shape[0]
+        feats = np.zeros((items, T_FRAMES, N_MELS), np.float32)
+        lens = np.zeros(items, np.float32)
+        self._chk(lib().sd_frontend(self._h, _ptr(wav), len(wav), _ptr(masks), items, _ptr(feats), _ptr(lens)))
+        return feats, lens
+
+    def ecapa(self, feats, lens):
+        feats = np.ascontiguousarray(feats, np.float32)
+        lens = np.ascontiguousarray(lens, np.float32)
+        items = feats.shape[0]
+        out = np.zeros((items, EMB_DIM), np.float32)
+        self._chk(lib().sd_ecapa(self._h, _ptr(feats), _ptr(lens), items, _ptr(out)))
+        return out
+
+    # ---- a12-a14
+    def linkage(self, X):
+        X = np.ascontiguousarray(X, np.float64)
+        N, d = X.shape
+        Z = np.zeros((max(N - 1, 0), 4), np.float64)
+        self._chk(lib().sd_linkage(self._h, _ptr(X), N, d, _ptr(Z)))
+        return Z
+
+    def cluster(self, X, cutoff):
+        X = np.ascontiguousarray(X, np.float64)
+        N, d = X.shape
+        T = np.zeros(N, np.int32)
+        self._chk(lib().sd_cluster(self._h, _ptr(X), N, d, float(cutoff), _ptr(T)))
+        return T
+
+    def clustering(self, emb):
+        emb = np.ascontiguousarray(emb, np.float64)
+        c, S, d = emb.shape
+        assert S == SPEAKERS
+        hard = np.zeros((c, S), np.int32)
+        K = C.c_int32(0)
+        self._chk(lib().sd_clustering(self._h, _ptr(emb), c, d, _ptr(hard), C.byref(K)))
+        return hard, int(K.value)
+
+    # ---- a15-a17
+    def reconstruct(self, seg, binarized, hard, count, n_samples):
+        seg = np.ascontiguousarray(seg, np.float32)
+        binarized = np.ascontiguousarray(binarized, np.uint8)
+        hard = np.ascontiguousarray(hard, np.int32)
+        count = np.ascontiguousarray(count, np.int32)
+        p = C.POINTER(Turn)()
+        n = C.c_int64(0)
+        self._chk(lib().sd_reconstruct(self._h, _ptr(seg), _ptr(binarized), _ptr(hard), _ptr(count), len(count),
+                                       seg.shape[0], n_samples, C.byref(p), C.byref(n)))
+        return self._turns(p, n)
+
+    def _turns(self, p, n):
+        out = [(p[i].start, p[i].end, int(p[i].label)) for i in range(n.value)]
+        lib().sd_free_turns(p)
+        return out
+
+    # ---- whole path
+    def diarize(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        p = C.POINTER(Turn)()
+        n = C.c_int64(0)
+        self._chk(lib().sd_diarize(self._h, _ptr(pcm), len(pcm), C.byref(p), C.byref(n)))
+        return self._turns(p, n)
+
+    def diarize_dev(self, d_pcm_ptr, n_samples):
+        p = C.POINTER(Turn)()
+        n = C.c_int64(0)
+        self._chk(lib().sd_diarize_dev(self._h, C.c_void_p(d_pcm_ptr), n_samples, C.byref(p), C.byref(n)))
+        return self._turns(p, n)
+
+    def shard_infer_dev(self, d_pcm_ptr, n_samples, chunk_lo, chunk_hi, d_seg_ptr, d_emb_ptr):
+        self._chk(lib().sd_shard_infer_dev(self._h, C.c_void_p(d_pcm_ptr), n_samples, chunk_lo, chunk_hi,
+                                           C.c_void_p(d_seg_ptr), C.c_void_p(d_emb_ptr)))
+
+    def finalize_dev(self, d_seg_ptr, d_emb_ptr, chunks, n_samples):
+        p = C.POINTER(Turn)()
+        n = C.c_int64(0)
+        self._chk(lib().sd_finalize_dev(self._h, C.c_void_p(d_seg_ptr), C.c_void_p(d_emb_ptr), chunks, n_samples,
+                                        C.byref(p), C.byref(n)))
+        return self._turns(p, n)
+
+    # ---- measurement
+    def stage_ms(self):
+        a = (C.c_double * 4)()
+        self._chk(lib().sd_stage_ms(self._h, a))
+        return list(a)
+
+    def kernel_stats(self, name):
+        ms, n, fl, by = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
+        self._chk(lib().sd_kernel_stats(self._h, name.encode(), C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+        return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+
+    def reset_stats(self):
+        lib().sd_reset_stats(self._h)
