@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- real-time factor of the MI355X diarization hot path (BASELINE.json metric).
+
+One step = one pass of the whole path (int16 PCM resident in HBM -> speaker turns on the host)
+over N hours of synthetic 16 kHz mono audio on N GPUs: every rank runs segmentation + embeddings
+for its contiguous chunk range (multiple of 32 chunks), segmentation scores and
+embeddings are all-gathered with RCCL, rank 0 runs counting / clustering / reconstruction.
+N = 1 is BASELINE.json configs[2] (1 h, single GPU, full pipeline).
+
+Prints ONE JSON line on rank 0 (contract in the task brief) including
+  roofline     : the dominant kernel (f32-MFMA conv_gemm) measured live with HIP events on the
+                 library's own stream over the timed region
+  cpu_baseline : the oracle ("port") timed on this box's host cores on a bounded sample (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "pyannote-audio_speaker-diarization_cpp_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HOUR = 3600
+SR = 16000
+F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def cpu_baseline(ws, we, seconds):
+    """oracle pipeline (torch CPU + C restatement) on `seconds` of the same synthetic audio"""
+    import synth
+    from oracle import pipeline_oracle
+    pcm = synth.make_pcm(seconds, seed=1234)
+    torch.set_num_threads(os.cpu_count() or 1)
+    t0 = time.time()
+    turns = pipeline_oracle.diarize_ref(pcm, ws, we)
+    dt = time.time() - t0
+    return {"value": round(seconds / dt, 4), "unit": "x real-time (audio-s / wall-s)", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": "first %d s of the synthetic hour (seed 1234): %d chunks, %d embedding items, oracle "
+            "pipeline (torch-CPU PyanNet/ECAPA fp32 + C restatement), %.1f s wall" % (seconds, (seconds * SR - 80000) // 8000 + 1,
+                                                                                      3 * ((seconds * SR - 80000) // 8000 + 1), dt),
+            "turns": len(turns)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--hours-per-gpu", type=float, default=1.0)
+    ap.add_argument("--cpu-seconds", type=int, default=20, help="audio seconds for the cpu_baseline sample (0 = skip)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0 and world > 1:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libsdhip has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import sdhip
+    import synth
+    from oracle import nn_oracle as nn          # weight *generation* only
+
+    tmp = tempfile.mkdtemp(prefix="sdw_r%d_" % rank)
+    ws, we = nn.synth_segmentation_weights(4321), nn.synth_embedding_weights(4322)
+    nn.save_pack(os.path.join(tmp, "segment.sdw"), ws)
+    nn.save_pack(os.path.join(tmp, "embedding.sdw"), we)
+    d = sdhip.Diarizer(os.path.join(tmp, "segment.sdw"), os.path.join(tmp, "embedding.sdw"), local)
+
+    # ---- the job: `world` x hours_per_gpu of audio; rank r owns a contiguous, 32-aligned chunk range
+    per_samples = int(round(a.hours_per_gpu * HOUR * SR))
+    n_total = per_samples * world
+    C, _ = sdhip.num_chunks(n_total)
+    per, ranges = sdhip.plan_shards(n_total, world)
+    lo, hi = ranges[rank]
+    first, need_hi = sdhip.shard_sample_range(lo, hi, n_total)
+    # synthesise only what this rank reads: its own hour(s) + the 72 000-sample halo of the next one
+    pieces, pos = [], first
+    while pos < need_hi:
+        h = pos // per_samples
+        off = pos - h * per_samples
+        take = min(per_samples - off, need_hi - pos)
+        seg_pcm = synth.make_pcm(a.hours_per_gpu * HOUR, seed=1234 + h, limit=off + take)
+        pieces.append(seg_pcm[off:off + take])
+        pos += take
+    pcm_host = np.concatenate(pieces) if pieces else np.zeros(1, np.int16)
+    d_pcm = torch.from_numpy(pcm_host).to(dev)
+    nloc = hi - lo
+    d_seg = torch.zeros((per, sdhip.FRAMES, 3), dtype=torch.float32, device=dev)
+    d_emb = torch.zeros((per * 3, sdhip.EMB_DIM), dtype=torch.float32, device=dev)
+    if world > 1:
+        g_seg = torch.empty((world * per, sdhip.FRAMES, 3), dtype=torch.float32, device=dev)
+        g_emb = torch.empty((world * per * 3, sdhip.EMB_DIM), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    turns_box = [None]
+
+    def step():
+        if nloc > 0:
+            d.shard_infer_dev(d_pcm.data_ptr(), first, int(d_pcm.numel()), n_total, lo, hi, d_seg.data_ptr(), d_emb.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(g_seg, d_seg)
+            dist.all_gather_into_tensor(g_emb, d_emb)
+            torch.cuda.synchronize()
+            if rank == 0:
+                turns_box[0] = d.finalize_dev(g_seg.data_ptr(), g_emb.data_ptr(), C, n_total)
+        else:
+            turns_box[0] = d.finalize_dev(d_seg.data_ptr(), d_emb.data_ptr(), C, n_total)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    d.set_option("profile", 1)
+    d.reset_stats()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / max(a.steps, 1) * 1e3
+    audio_s = n_total / SR
+
+    if rank == 0:
+        cg = d.kernel_stats("conv_gemm")
+        stages = d.stage_ms()
+        ach = cg["flops"] / max(cg["ms"], 1e-9) / 1e9      # TFLOP/s
+        extra = {}
+        for k in ("stft_mel", "lstm_rec", "pdist", "linkage", "row_nn", "se_apply", "asp_pool"):
+            s = d.kernel_stats(k)
+            extra[k] = {"ms_per_step": round(s["ms"] / max(a.steps, 1), 3), "launches_per_step": s["launches"] // max(a.steps, 1)}
+        out = {
+            "metric": "real-time factor (audio-sec/wall-sec), %g h 16 kHz mono per GPU" % a.hours_per_gpu,
+            "value": round(audio_s / (ms_per_step / 1e3), 2),
+            "unit": "x real-time",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%g h synthetic 16 kHz mono per GPU (%d h total), full pipeline: PyanNet segmentation + "
+                                   "post-seg + STFT/fbank + ECAPA-TDNN + centroid AHC + reconstruction" % (a.hours_per_gpu, round(audio_s / HOUR)),
+                       "audio_seconds": audio_s, "chunks": C, "embedding_items": 3 * C,
+                       "weights": "seeded synthetic (seg 4321, emb 4322): the reference's ONNX blobs are not in the checkout",
+                       "sharding": "contiguous chunk ranges of %d per rank, RCCL all-gather of scores+embeddings, clustering on rank 0" % per,
+                       "turns": len(turns_box[0] or []),
+                       "stage_ms_last_step": {"segmentation": round(stages[0], 1), "embedding": round(stages[1], 1), "clustering": round(stages[2], 1)}},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "k_conv_gemm (v_mfma_f32_32x32x2_f32)", "launches_per_step": cg["launches"] // max(a.steps, 1),
+                         "kernel_ms_per_step": round(cg["ms"] / max(a.steps, 1), 2),
+                         "algorithmic_gflop_per_step": round(cg["flops"] / max(a.steps, 1) / 1e9, 1)},
+            "other_kernels": extra,
+        }
+        if world == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(ws, we, a.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    d.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

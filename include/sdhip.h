@@ -111,7 +111,10 @@ void sd_free_turns(sd_turn*);
 /* ---- multi-GPU split of the same path: ranks run infer on their
  * contiguous chunk range (multiple of 32 chunks), all-gather d_seg / d_emb with
  * RCCL (torch.distributed), then any rank finalizes. */
-int sd_shard_infer_dev(sd_ctx*, const int16_t* d_pcm, int64_t n, int64_t chunk_lo, int64_t chunk_hi,
+/* d_pcm_shard holds samples [first_sample, first_sample + shard_samples) of the n_total-sample
+ * recording and must cover [chunk_lo*8000, min(n_total, (chunk_hi-1)*8000 + 80000)). */
+int sd_shard_infer_dev(sd_ctx*, const int16_t* d_pcm_shard, int64_t first_sample, int64_t shard_samples,
+                       int64_t n_total, int64_t chunk_lo, int64_t chunk_hi,
                        float* d_seg /*[hi-lo][293][3]*/, float* d_emb /*[(hi-lo)*3][192]*/);
 int sd_finalize_dev(sd_ctx*, const float* d_seg, const float* d_emb, int64_t chunks, int64_t n,
                     sd_turn** turns, int64_t* n_turns);

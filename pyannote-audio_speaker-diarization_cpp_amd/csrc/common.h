@@ -48,6 +48,7 @@ struct ConvArgs {
     int TpIn, TpOut;       // rows per item in input / output buffers
     int Tin, T;            // valid rows per item in input / output
     int Cin, Cout, KT, dil;
+    int cin_real;          // un-padded input channels (algorithmic FLOP accounting only; 0 = Cin)
     int pad_mode;          // 0 = "same" with reflect padding, 1 = "valid" (src row = t + kk*dil)
     int act1, act2;        // act1: 0 none 1 relu 2 leaky(0.01); act2 (after BN): 0 none 1 tanh 2 sigmoid
     int m_tiles, n_tiles;

@@ -179,8 +179,11 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     a.m_tiles = (a.M + BM - 1) / BM;
     a.n_tiles = (a.Cout + BN - 1) / BN;
     const int grid = ((a.m_tiles + 7) / 8) * 8 * a.n_tiles;
-    const double flops = 2.0 * (double)a.M * a.Cout * a.Cin * a.KT;
-    const double bytes = 4.0 * ((double)a.M * a.Cin * (a.X2 ? 2 : 1) + (double)a.M * a.Cout + (double)a.Cout * a.Cin * a.KT);
+    // algorithmic work: valid rows only (T of every TpOut), un-padded input channels
+    const double rows = (double)(a.M / a.TpOut) * a.T + (double)((a.M % a.TpOut) < a.T ? (a.M % a.TpOut) : a.T);
+    const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
+    const double flops = 2.0 * rows * a.Cout * cin * a.KT;
+    const double bytes = 4.0 * (rows * cin * (a.X2 ? 2 : 1) + rows * a.Cout + (double)a.Cout * cin * a.KT);
     ProfScope ps(c, "conv_gemm", flops, bytes);
     if (a.X2) hipLaunchKernelGGL(k_conv_gemm<true>, dim3(grid), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL(k_conv_gemm<false>, dim3(grid), dim3(256), 0, c->stream, a);

@@ -104,7 +104,7 @@ static ConvArgs conv_args(const ConvLayer& L, const float* X, int x_ld, float* Y
     a.M = (int)M;
     if (per_item) { a.TpIn = a.TpOut = SD_TP; a.Tin = a.T = SD_T; }
     else { a.TpIn = a.TpOut = (int)M; a.Tin = a.T = (int)M; }
-    a.Cin = L.CinPad; a.Cout = L.Cout; a.KT = L.KT; a.dil = L.dil;
+    a.Cin = L.CinPad; a.cin_real = L.Cin; a.Cout = L.Cout; a.KT = L.KT; a.dil = L.dil;
     a.pad_mode = 0;
     return a;
 }

@@ -227,15 +227,21 @@ static int finalize(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t c
     return SD_OK;
 }
 
-extern "C" int sd_shard_infer_dev(sd_ctx* c, const int16_t* d_pcm, int64_t n, int64_t chunk_lo, int64_t chunk_hi, float* d_seg, float* d_emb)
+extern "C" int sd_shard_infer_dev(sd_ctx* c, const int16_t* d_pcm_shard, int64_t first_sample, int64_t shard_samples, int64_t n,
+                                  int64_t chunk_lo, int64_t chunk_hi, float* d_seg, float* d_emb)
 {
     ENTER(c);
-    if (!d_pcm || !d_seg || !d_emb || n <= 1) SD_FAIL(c, SD_ERR_ARG, "sd_shard_infer_dev: bad argument");
-    float* d_wav = nullptr;
-    int rc = get_wav(c, d_pcm, n, &d_wav);
-    if (rc) return rc;
+    if (!d_pcm_shard || !d_seg || !d_emb || n <= 1 || shard_samples <= 0 || first_sample < 0) SD_FAIL(c, SD_ERR_ARG, "sd_shard_infer_dev: bad argument");
+    const int64_t need_lo = chunk_lo * SD_HOP;
+    int64_t need_hi = (chunk_hi - 1) * SD_HOP + SD_CHUNK; if (need_hi > n) need_hi = n;
+    if (chunk_hi > chunk_lo && (first_sample > need_lo || first_sample + shard_samples < need_hi))
+        SD_FAIL(c, SD_ERR_ARG, "shard samples [%lld,%lld) do not cover chunks [%lld,%lld)", (long long)first_sample, (long long)(first_sample + shard_samples), (long long)chunk_lo, (long long)chunk_hi);
+    WS(c, float, w, "wav_f32", shard_samples + 512);
+    hipLaunchKernelGGL(k_pcm_to_f32, GRID1(shard_samples), 0, c->stream, d_pcm_shard, w, shard_samples);
+    KCHECK(c);
     for (int i = 0; i < 4; ++i) c->stage_ms[i] = 0;
-    return shard_infer(c, d_wav, n, chunk_lo, chunk_hi, d_seg, d_emb);
+    // kernels index the recording with absolute sample positions; only the covered range is ever touched
+    return shard_infer(c, w - first_sample, n, chunk_lo, chunk_hi, d_seg, d_emb);
 }
 
 extern "C" int sd_finalize_dev(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t chunks, int64_t n, sd_turn** turns, int64_t* n_turns)

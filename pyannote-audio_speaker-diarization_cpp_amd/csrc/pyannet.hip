@@ -226,7 +226,7 @@ static ConvArgs gemm_args(const ConvLayer& L, const float* X, int x_ld, float* Y
     memset(&a, 0, sizeof(a));
     a.X = X; a.x_ld = x_ld; a.Y = Y; a.y_ld = y_ld; a.W = L.W; a.bias = L.bias;
     a.M = (int)M; a.TpIn = a.TpOut = (int)M; a.Tin = a.T = (int)M;
-    a.Cin = L.CinPad; a.Cout = L.Cout; a.KT = L.KT; a.dil = L.dil; a.pad_mode = 1;
+    a.Cin = L.CinPad; a.cin_real = L.Cin; a.Cout = L.Cout; a.KT = L.KT; a.dil = L.dil; a.pad_mode = 1;
     return a;
 }
 
@@ -264,7 +264,7 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
         ConvArgs a; memset(&a, 0, sizeof(a));
         a.X = xn; a.x_ld = 10; a.W = S.conv0.W; a.Y = c0; a.y_ld = 80;
         a.M = (int)(CB * L0); a.TpIn = SD_CHUNK / 10; a.TpOut = L0; a.Tin = SD_CHUNK / 10; a.T = L0;
-        a.Cin = 256; a.Cout = 80; a.KT = 1; a.dil = 1; a.pad_mode = 1;
+        a.Cin = 256; a.cin_real = 251; a.Cout = 80; a.KT = 1; a.dil = 1; a.pad_mode = 1;
         if ((rc = launch_conv_gemm(c, a, "sinc0"))) return rc;
     }
     hipLaunchKernelGGL((k_pool_norm<80, 96, true>), dim3((unsigned)CB), dim3(240), 0, st, c0, L0, P0, S.in_w[0], S.in_b[0], p0);
@@ -273,7 +273,7 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
         ConvArgs a; memset(&a, 0, sizeof(a));
         a.X = p0; a.x_ld = 96; a.W = S.conv1.W; a.bias = S.conv1.bias; a.Y = c1; a.y_ld = 60;
         a.M = (int)(CB * L1); a.TpIn = P0; a.TpOut = L1; a.Tin = P0; a.T = L1;
-        a.Cin = 96; a.Cout = 60; a.KT = 5; a.dil = 1; a.pad_mode = 1;
+        a.Cin = 96; a.cin_real = 80; a.Cout = 60; a.KT = 5; a.dil = 1; a.pad_mode = 1;
         if ((rc = launch_conv_gemm(c, a, "sinc1"))) return rc;
     }
     hipLaunchKernelGGL((k_pool_norm<60, 64, false>), dim3((unsigned)CB), dim3(240), 0, st, c1, L1, P1, S.in_w[1], S.in_b[1], p1);
@@ -282,7 +282,7 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
         ConvArgs a; memset(&a, 0, sizeof(a));
         a.X = p1; a.x_ld = 64; a.W = S.conv2.W; a.bias = S.conv2.bias; a.Y = c2; a.y_ld = 60;
         a.M = (int)(CB * L2); a.TpIn = P1; a.TpOut = L2; a.Tin = P1; a.T = L2;
-        a.Cin = 64; a.Cout = 60; a.KT = 5; a.dil = 1; a.pad_mode = 1;
+        a.Cin = 64; a.cin_real = 60; a.Cout = 60; a.KT = 5; a.dil = 1; a.pad_mode = 1;
         if ((rc = launch_conv_gemm(c, a, "sinc2"))) return rc;
     }
     hipLaunchKernelGGL((k_pool_norm<60, 64, false>), dim3((unsigned)CB), dim3(240), 0, st, c2, L2, P2, S.in_w[2], S.in_b[2], p2);

@@ -71,7 +71,7 @@ def lib():
     L.sd_diarize.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
     L.sd_diarize_dev.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
     L.sd_free_turns.argtypes = [C.POINTER(Turn)]
-    L.sd_shard_infer_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+    L.sd_shard_infer_dev.argtypes = [vp, vp, i64, i64, i64, i64, i64, vp, vp]
     L.sd_finalize_dev.argtypes = [vp, vp, vp, i64, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
     L.sd_read_wav.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
     L.sd_free_pcm.argtypes = [C.POINTER(C.c_int16)]
@@ -88,6 +88,22 @@ def num_chunks(n):
     ll = C.c_int64(0)
     c = lib().sd_num_chunks(n, C.byref(ll))
     return int(c), int(ll.value)
+
+
+def plan_shards(n_total, world):
+    """contiguous chunk ranges per rank, aligned to 32 chunks (= 96 items = 3 reference embedding
+    batches) so every rank forms exactly the reference's batches.  Returns (per, [(lo, hi)])"""
+    C, _ = num_chunks(n_total)
+    per = -(-C // world)
+    per = -(-per // 32) * 32
+    return per, [(min(C, r * per), min(C, (r + 1) * per)) for r in range(world)]
+
+
+def shard_sample_range(lo, hi, n_total):
+    """samples a rank must hold for chunks [lo, hi): [lo*8000, min(n, (hi-1)*8000 + 80000))"""
+    if hi <= lo:
+        return lo * HOP, lo * HOP
+    return lo * HOP, min(n_total, (hi - 1) * HOP + CHUNK)
 
 
 def _ptr(a):
@@ -242,9 +258,9 @@ class Diarizer:
         self._chk(lib().sd_diarize_dev(self._h, C.c_void_p(d_pcm_ptr), n_samples, C.byref(p), C.byref(n)))
         return self._turns(p, n)
 
-    def shard_infer_dev(self, d_pcm_ptr, n_samples, chunk_lo, chunk_hi, d_seg_ptr, d_emb_ptr):
-        self._chk(lib().sd_shard_infer_dev(self._h, C.c_void_p(d_pcm_ptr), n_samples, chunk_lo, chunk_hi,
-                                           C.c_void_p(d_seg_ptr), C.c_void_p(d_emb_ptr)))
+    def shard_infer_dev(self, d_pcm_shard_ptr, first_sample, shard_samples, n_total, chunk_lo, chunk_hi, d_seg_ptr, d_emb_ptr):
+        self._chk(lib().sd_shard_infer_dev(self._h, C.c_void_p(d_pcm_shard_ptr), first_sample, shard_samples, n_total,
+                                           chunk_lo, chunk_hi, C.c_void_p(d_seg_ptr), C.c_void_p(d_emb_ptr)))
 
     def finalize_dev(self, d_seg_ptr, d_emb_ptr, chunks, n_samples):
         p = C.POINTER(Turn)()

@@ -1,0 +1,76 @@
+"""CPU tests of the drop-in boundary: libsdhip.so loads without a GPU, exports every symbol that
+include/sdhip.h declares, and its pure-host entry points agree with the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sdhip
+from oracle import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = sdhip.lib()
+    hdr = open(os.path.join(ROOT, "include", "sdhip.h")).read()
+    declared = set(re.findall(r"\b(sd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(sdhip.EXPORTS), declared ^ set(sdhip.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_create_fails_loudly_without_gpu_or_model(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        with pytest.raises(sdhip.SdError) as e:
+            sdhip.Diarizer(str(tmp_path / "missing.sdw"), None)
+        assert "cannot open" in str(e.value)
+    else:
+        with pytest.raises(sdhip.SdError) as e:
+            sdhip.Diarizer(None, None)
+        assert "no HIP device" in str(e.value)        # no CPU fallback in the product path
+
+
+@pytest.mark.parametrize("n", [1, 2, 79999, 80000, 80001, 88000, 100000, 944000, 9600000, 57600000, 57601234])
+def test_chunk_rule_matches_oracle(n):
+    assert sdhip.num_chunks(n) == orc.num_chunks(n)
+
+
+@pytest.mark.parametrize("c", [1, 2, 7, 109, 1191, 7191])
+def test_count_frames_matches_oracle(c):
+    b = np.zeros((c, 293, 3))
+    cnt, _, _ = orc.speaker_count(b)
+    assert sdhip.lib().sd_count_frames(c) == len(cnt)
+
+
+def test_format_turn_matches_reference_stream_format():
+    for t in [(5.222812345, 17.74406789, 3), (0.4978125, 39.9516, 0), (1234.56789, 3599.991, 12), (1e-7, 100000.5, 1)]:
+        assert sdhip.format_turn(t) == orc.format_turn(t)
+    assert sdhip.format_turn((5.222812345, 17.74406789, 3)) == "[5.22281 -- 17.7441] --> Speaker_3"
+
+
+def test_wav_reader_matches_oracle(golden_dir):
+    pcm, sr, ch = sdhip.read_wav(os.path.join(golden_dir, "multi-speaker_1min.wav"))
+    w, sr2, ch2, bits = orc.read_wav(os.path.join(golden_dir, "multi-speaker_1min.wav"))
+    assert (sr, ch, len(pcm)) == (16000, 1, 944000) and sr2 == sr and bits == 16
+    assert np.array_equal(pcm.astype(np.float32) / np.float32(32768.0), w)
+    with pytest.raises(sdhip.SdError):
+        sdhip.read_wav("/nonexistent.wav")
+
+
+def test_cli_usage_line():
+    import subprocess
+    exe = os.path.join(ROOT, "pyannote-audio_speaker-diarization_cpp_amd", "speakerDiarizer")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0                                              # sd.cpp:3421-3425
+    assert out.stdout.strip() == "program [segment model file] [embeding model file] [wave file]"
+
+
+def test_synth_is_deterministic_and_prefix_consistent():
+    import synth
+    a = synth.make_pcm(30.0, seed=5)
+    assert np.array_equal(a, synth.make_pcm(30.0, seed=5))
+    assert np.array_equal(a[:100000], synth.make_pcm(30.0, seed=5, limit=100000))
+    assert a.dtype == np.int16 and len(a) == 480000 and np.abs(a).max() > 5000

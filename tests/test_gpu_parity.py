@@ -1,0 +1,302 @@
+"""GPU parity tests: every stage of the HIP path, called through the C ABI, against the oracle.
+Integer / index / fp64 stages must be bit-exact; the fp32 networks use the reference's own
+tolerance rtol=1e-3, atol=1e-4 (pipeline/script/verifyEveryStepResult.py:119-124) and the
+north-star bar "embedding cosine distance within 1e-3"."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn_oracle as nn
+from oracle import orc, pipeline_oracle
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-3, 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def tkey(t):
+    return (round(t[0], 9), t[2])
+
+
+def test_native_library_is_the_one_running(diarizer):
+    import sdhip
+    maps = open("/proc/self/maps").read()
+    assert os.path.realpath(sdhip.LIB_PATH) in maps
+
+
+# ------------------------------------------------------------------ a2 + a3
+@pytest.mark.parametrize("n", [80000 + 8000 * 3, 80000 + 8000 * 2 + 3000, 80000, 47011, 80001])
+def test_segmentation_parity(diarizer, weights, n):
+    rng = np.random.default_rng(n)
+    wav = (0.1 * rng.standard_normal(n)).astype(np.float32) * (1 + np.sin(np.arange(n) / 2000.0)).astype(np.float32)
+    seg = diarizer.segment(wav)
+    nc, last = orc.num_chunks(n)
+    assert seg.shape == (nc, 293, 3)
+    net = nn.PyanNetOracle(weights[2])
+    for i in range(nc):
+        y = net(wav[None, i * 8000:i * 8000 + 80000]).numpy()[0]
+        ref = np.zeros((293, 3), np.float32)
+        ref[:y.shape[0]] = y                        # short last chunk is zero padded (sd.cpp:1473-1479)
+        np.testing.assert_allclose(seg[i], ref, rtol=RTOL, atol=ATOL)
+
+
+def test_segmentation_too_short_tail_is_zero(diarizer):
+    # a trailing chunk too short for one frame: frames are zero padded like sd.cpp:1473-1479
+    n = 80000 + 8000 + 200
+    wav = np.random.default_rng(0).standard_normal(n).astype(np.float32) * 0.1
+    seg = diarizer.segment(wav)
+    assert seg.shape[0] == 3 and not seg[2].any() and seg[0].any()
+
+
+# ------------------------------------------------------------------ a4 - a6
+def test_postseg_bit_exact(diarizer):
+    rng = np.random.default_rng(1)
+    c = 150
+    sc = rng.random((c, 293, 3)).astype(np.float32)
+    sc[:, :, 2] *= 0.5
+    sc[5] = 0.1                                   # inactive chunk
+    sc[6, :, 0] = 0.9; sc[6, :, 1] = 0.9          # permanent overlap: clean masks empty
+    sc[7, :, :] = 0.9                             # 3 speakers always on
+    sc[8, :5, 1] = 0.9; sc[8, 5:, 1] = 0.1        # 5 frames only
+    sc[9] = np.float32(orc.ONSET)                 # nearest float to the threshold
+    b, m, cnt = diarizer.postseg(sc)
+    b_ref = orc.binarize(sc)
+    assert np.array_equal(b.astype(np.float64), b_ref)
+    assert np.array_equal(m, orc.select_masks(b_ref))
+    cnt_ref, _, _ = orc.speaker_count(b_ref)
+    assert np.array_equal(cnt, cnt_ref)
+
+
+# ------------------------------------------------------------------ a7 - a9
+def _wav_and_masks(rng, items):
+    n = 8000 * ((items + 2) // 3 - 1) + 80000
+    wav = (0.2 * rng.standard_normal(n)).astype(np.float32) * (1 + np.sin(np.arange(n) / 3000.0)).astype(np.float32)
+    masks = (rng.random((items, 293)) > 0.4).astype(np.float32)
+    return wav, masks
+
+
+def _oracle_signals(wav, masks):
+    items = masks.shape[0]
+    sigs = np.zeros((items, 80000), np.float32)
+    cnts = np.zeros(items, np.int64)
+    for i in range(items):
+        sigs[i], cnts[i] = orc.mask_compact(orc.crop(wav, (i // 3) * 8000), masks[i])
+    lens = np.zeros(items, np.float32)
+    bad = np.zeros(items, bool)
+    for b0 in range(0, items, 32):
+        l, ts, an = orc.wav_lens(cnts[b0:b0 + 32])
+        lens[b0:b0 + 32] = l
+        bad[b0:b0 + 32] = ts | an
+    return sigs, lens, bad
+
+
+def test_frontend_parity(diarizer, weights):
+    rng = np.random.default_rng(2)
+    wav, masks = _wav_and_masks(rng, 70)
+    masks[3] = 0; masks[3, :2] = 1                 # 546 samples < 640: too short
+    masks[7] = 1                                   # everything selected
+    masks[9] = 0                                   # nothing selected
+    masks[11, ::2] = 0; masks[11, 1::2] = 1        # alternating frames: many short runs
+    f_gpu, l_gpu = diarizer.frontend(wav, masks)
+    sigs, lens, bad = _oracle_signals(wav, masks)
+    assert np.array_equal(l_gpu, lens)             # wav_lens is "same file content" in the reference harness
+    st = nn.stft_ref(sigs, weights[3]["stft.window"])
+    f_ref = nn.fbank_norm_ref(st, lens, weights[3]["fbank.matrix"]).numpy()
+    np.testing.assert_allclose(f_gpu[~bad], f_ref[~bad], rtol=RTOL, atol=ATOL)
+
+
+def test_ecapa_parity(diarizer, weights):
+    rng = np.random.default_rng(3)
+    feats = (3.0 * rng.standard_normal((6, 501, 80))).astype(np.float32)
+    lens = np.array([1.0, 0.7311, 0.25, 0.5, 0.9991, 0.008], np.float32)
+    e_gpu = diarizer.ecapa(feats, lens)
+    e_ref = nn.EcapaOracle(weights[3])(feats, lens).numpy()
+    np.testing.assert_allclose(e_gpu, e_ref, rtol=RTOL, atol=ATOL)
+
+
+def test_embed_parity(diarizer, weights):
+    rng = np.random.default_rng(4)
+    wav, masks = _wav_and_masks(rng, 100)
+    masks[3] = 0; masks[3, :2] = 1
+    masks[64:96] = 0; masks[64:96, :1] = 1         # a whole reference batch below min_num_samples -> all NaN (sd.cpp:2479)
+    e_gpu = diarizer.embed(wav, masks)
+    sigs, lens, bad = _oracle_signals(wav, masks)
+    assert bad[64:96].all() and bad[3]
+    assert np.array_equal(np.isnan(e_gpu[:, 0]), bad)
+    st = nn.stft_ref(sigs, weights[3]["stft.window"])
+    ok = ~bad
+    f32 = nn.fbank_norm_ref(st, lens, weights[3]["fbank.matrix"])
+    e_ref = nn.EcapaOracle(weights[3])(f32, lens).numpy()[ok]
+    f64 = nn.fbank_norm_ref(st, lens, weights[3]["fbank.matrix"], torch.float64)
+    e_ref64 = nn.EcapaOracle(weights[3], torch.float64)(f64, lens).numpy()[ok]
+    g = e_gpu[ok].astype(np.float64)
+    # north-star bar: cosine distance to the reference embedding within 1e-3
+    cos = (g * e_ref).sum(1) / np.linalg.norm(g, axis=1) / np.linalg.norm(e_ref, axis=1)
+    assert (1 - cos).max() < 1e-3
+    # reference tolerance, atol scaled to the embedding magnitude (the synthetic net's outputs are O(100))
+    np.testing.assert_allclose(g, e_ref, rtol=RTOL, atol=ATOL * np.abs(e_ref).max())
+    # and no less accurate than the fp32 oracle itself is w.r.t. an fp64 evaluation
+    assert np.abs(g - e_ref64).max() <= 8 * np.abs(e_ref - e_ref64).max() + 1e-6
+
+
+# ------------------------------------------------------------------ a12 - a14
+def _blobs(rng, N, d=192, k=4, s=0.6):
+    cen = rng.standard_normal((k, d))
+    X = cen[rng.integers(0, k, N)] + s * rng.standard_normal((N, d))
+    return X / np.linalg.norm(X, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("N,d", [(2, 192), (3, 192), (12, 2), (65, 192), (300, 192), (2000, 192), (700, 7)])
+def test_linkage_bit_exact(diarizer, N, d):
+    rng = np.random.default_rng(N + d)
+    X = _blobs(rng, N, d) if d > 2 else np.array([[0, 0], [0, 1], [1, 0], [0, 4], [0, 3], [1, 4], [4, 0], [3, 0], [4, 1], [4, 4], [3, 4], [4, 3]], float)
+    cutoff = orc.THRESH_F32 if d > 2 else 1.1
+    T_ref, Z_ref = orc.ahc(X, cutoff)
+    assert np.array_equal(diarizer.linkage(X), Z_ref)          # bit-identical dendrogram
+    assert np.array_equal(diarizer.cluster(X, cutoff), T_ref)
+
+
+def test_linkage_with_exact_ties_gives_same_partition(diarizer):
+    # duplicate rows: the heap's order for exactly equal candidates is not reproduced;
+    # the flat clustering must still agree
+    rng = np.random.default_rng(9)
+    X = _blobs(rng, 200)
+    X[7] = X[3]; X[19] = X[3]; X[30] = X[11]; X[150] = X[149]
+    T_ref, _ = orc.ahc(X, orc.THRESH_F32)
+    T = diarizer.cluster(X, orc.THRESH_F32)
+    m = {}
+    for a, b in zip(T.tolist(), T_ref.tolist()):
+        assert m.setdefault(a, b) == b
+    assert len(set(m.values())) == len(m)
+
+
+def test_clustering_parity(diarizer):
+    rng = np.random.default_rng(10)
+    for trial, (c, k, s, pnan) in enumerate([(200, 5, 0.5, 0.2), (120, 3, 0.4, 0.15), (40, 2, 0.3, 0.0), (300, 8, 0.7, 0.3)]):
+        cen = rng.standard_normal((k, 192)) * 2
+        lab = rng.integers(0, k, (c, 3))
+        lab[rng.random((c, 3)) < 0.03] = k - 1                       # a rare (small) cluster
+        emb = (cen[lab] + s * rng.standard_normal((c, 3, 192))).astype(np.float32).astype(np.float64)
+        emb[rng.random((c, 3)) < pnan] = np.nan
+        h, K = diarizer.clustering(emb)
+        h_ref, K_ref, _ = orc.clustering(emb)
+        assert K == K_ref and np.array_equal(h, h_ref), trial
+    # fewer than two embeddings -> all zeros (sd.cpp:2081-2088)
+    e1 = np.full((4, 3, 192), np.nan); e1[2, 1] = 1.0
+    h1, _ = diarizer.clustering(e1)
+    assert not h1.any()
+    # no cluster reaches min_cluster_size -> all zeros (sd.cpp:2371-2375)
+    e2 = np.random.default_rng(1).standard_normal((10, 3, 192))
+    h2, _ = diarizer.clustering(e2)
+    h2_ref, _, _ = orc.clustering(e2)
+    assert np.array_equal(h2, h2_ref)
+
+
+# ------------------------------------------------------------------ a15 - a17
+@pytest.mark.parametrize("c,kmax", [(30, 3), (12, 1), (77, 6), (1, 2)])
+def test_reconstruct_parity(diarizer, c, kmax):
+    rng = np.random.default_rng(c)
+    n_s = 80000 + 8000 * (c - 1)
+    sc = rng.random((c, 293, 3)).astype(np.float32)
+    sc[min(3, c - 1), :, 1] = 0.01                      # an inactive local speaker -> -2
+    b, _, cnt = diarizer.postseg(sc)
+    hard = rng.integers(0, kmax, (c, 3)).astype(np.int32)
+    turns = diarizer.reconstruct(sc, b, hard, cnt, n_s)
+    b_ref = orc.binarize(sc)
+    cnt_ref, win, ft = orc.speaker_count(b_ref)
+    binr, st = orc.reconstruct(sc, orc.mark_inactive(b_ref, hard), cnt_ref, win, ft, n_s)
+    t_ref = orc.to_annotation(binr, st)
+    assert sorted(turns, key=tkey) == sorted(t_ref, key=tkey)
+    assert turns == sorted(turns, key=lambda t: t[0])
+
+
+# ------------------------------------------------------------------ whole path
+def test_whole_path_against_oracle(diarizer, weights):
+    import synth
+    pcm = synth.make_pcm(33.3, seed=11)
+    turns = diarizer.diarize(pcm)
+    wav = pcm.astype(np.float32) / np.float32(32768.0)
+    nc, _ = orc.num_chunks(len(pcm))
+    seg = diarizer.segment(wav)
+    masks = orc.select_masks(orc.binarize(seg))
+    emb = diarizer.embed(wav, masks)
+    # (1) with the GPU's network outputs injected, every non-neural stage must agree bit for bit
+    t1 = pipeline_oracle.diarize_ref(pcm, weights[2], weights[3], seg_override=seg, emb_override=emb)
+    assert sorted(turns, key=tkey) == sorted(t1, key=tkey)
+    # (2) against the full oracle (torch networks): same speakers, boundaries within +-1 frame (north star)
+    t2 = pipeline_oracle.diarize_ref(pcm, weights[2], weights[3])
+    assert len(t2) == len(turns)
+    for a, b in zip(sorted(turns, key=tkey), sorted(t2, key=tkey)):
+        assert a[2] == b[2] and abs(a[0] - b[0]) <= 0.016875 + 1e-9 and abs(a[1] - b[1]) <= 0.016875 + 1e-9
+
+
+def test_sharded_equals_unsharded_and_is_idempotent(diarizer):
+    """multi-GPU split exercised on one GPU: two 32-aligned shards == one shot"""
+    import sdhip
+    import synth
+    pcm = synth.make_pcm(60.0, seed=12)
+    n = len(pcm)
+    C, _ = sdhip.num_chunks(n)
+    dev = torch.device("cuda", 0)
+    d_pcm = torch.from_numpy(pcm).to(dev)
+    seg = torch.zeros((C, 293, 3), dtype=torch.float32, device=dev)
+    emb = torch.zeros((C * 3, 192), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    whole = diarizer.diarize_dev(d_pcm.data_ptr(), n)
+    assert whole == diarizer.diarize_dev(d_pcm.data_ptr(), n)
+    per, ranges = sdhip.plan_shards(n, 2)
+    assert per % 32 == 0 and ranges[0][1] == ranges[1][0]
+    for lo, hi in ranges:
+        s0, s1 = sdhip.shard_sample_range(lo, hi, n)
+        shard = d_pcm[s0:s1].contiguous()
+        torch.cuda.synchronize()
+        diarizer.shard_infer_dev(shard.data_ptr(), s0, s1 - s0, n, lo, hi, seg[lo:].data_ptr(), emb[lo * 3:].data_ptr())
+    assert diarizer.finalize_dev(seg.data_ptr(), emb.data_ptr(), C, n) == whole
+
+
+def test_cli_matches_api(diarizer, weights, golden_dir):
+    import sdhip
+    wav = os.path.join(golden_dir, "multi-speaker_1min.wav")          # BASELINE.json configs[0] input
+    exe = os.path.join(ROOT, "pyannote-audio_speaker-diarization_cpp_amd", "speakerDiarizer")
+    out = subprocess.run([exe, weights[0], weights[1], wav], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    rule = "-" * 52
+    i0 = lines.index(rule)
+    i1 = lines.index(rule, i0 + 1)                                   # block between the two rules (sd.cpp:3435-3441)
+    pcm, sr, ch = sdhip.read_wav(wav)
+    turns = diarizer.diarize(pcm)
+    assert lines[i0 + 1:i1] == [sdhip.format_turn(t) for t in turns]
+    for lab in ("Segmenations time", "Embedding time", "Clustering time", "Time cost"):
+        assert any(l.startswith(lab) for l in lines)
+
+
+# ------------------------------------------------------------------ full-size, size-independent properties
+def test_full_size_linkage_properties(diarizer):
+    """N = 21 573 (1 h of audio, BASELINE.json configs[2]): dendrogram validity + planted partition"""
+    N = 21573
+    rng = np.random.default_rng(0)
+    cen = rng.standard_normal((4, 192))
+    lab = rng.integers(0, 4, N)
+    X = cen[lab] + 0.6 * rng.standard_normal((N, 192))
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Z = diarizer.linkage(X)
+    ids = np.concatenate([Z[:, 0], Z[:, 1]]).astype(np.int64)
+    assert np.array_equal(np.sort(ids), np.arange(2 * N - 2))         # every node merged exactly once
+    assert (Z[:, 0] < Z[:, 1]).all() and Z[-1, 3] == N and (Z[:, 2] >= 0).all()
+    size = np.ones(2 * N - 1)
+    for k in range(N - 1):
+        size[N + k] = size[int(Z[k, 0])] + size[int(Z[k, 1])]
+    assert np.array_equal(size[N:], Z[:, 3])
+    T = orc.fcluster_distance(Z, orc.THRESH_F32)                       # oracle's fcluster on the GPU dendrogram
+    assert np.array_equal(T, diarizer.cluster(X, orc.THRESH_F32))
+    assert T.max() == 4
+    for k in range(4):
+        assert len(set(T[lab == k].tolist())) == 1
+    # first merge is the globally closest pair
+    sub = X[:3000]
+    from scipy.spatial.distance import pdist
+    assert Z[0, 2] <= pdist(sub).min() + 1e-15
