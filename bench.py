@@ -38,7 +38,13 @@ def cpu_baseline(ws, we, seconds):
     import synth
     from oracle import pipeline_oracle
     pcm = synth.make_pcm(seconds, seed=1234)
-    torch.set_num_threads(os.cpu_count() or 1)
+    # threads actually used: the cores this process may run on, capped at 32 (torch's intra-op pool
+    # collapses on small batches when handed hundreds of threads)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(32, avail)))
     t0 = time.time()
     turns = pipeline_oracle.diarize_ref(pcm, ws, we)
     dt = time.time() - t0

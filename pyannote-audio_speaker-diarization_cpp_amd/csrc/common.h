@@ -88,6 +88,7 @@ struct sd_ctx {
     std::map<std::string, DevBuf> ws;          // named workspaces
     std::map<std::string, KernelStat> stats;
     bool profile = false;
+    bool profile_detail = false;               // also bracket conv_gemm per layer tag (option profile=2)
     std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t, double, double>> pending;
     double stage_ms[4] = {0, 0, 0, 0};
     int64_t emb_batch_items = 768;             // multiple of 96
@@ -109,8 +110,8 @@ template <class T> inline T* ws_get(sd_ctx* c, const char* name, size_t count) {
 
 // profiling bracket: records events around one launch when ctx->profile is set
 struct ProfScope {
-    sd_ctx* c; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr; double flops, bytes;
-    ProfScope(sd_ctx* ctx, const char* n, double fl = 0, double by = 0) : c(ctx), name(n), flops(fl), bytes(by) {
+    sd_ctx* c; std::string name; hipEvent_t e0 = nullptr, e1 = nullptr; double flops, bytes;
+    ProfScope(sd_ctx* ctx, const std::string& n, double fl = 0, double by = 0) : c(ctx), name(n), flops(fl), bytes(by) {
         if (c->profile) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream); }
     }
     ~ProfScope() {

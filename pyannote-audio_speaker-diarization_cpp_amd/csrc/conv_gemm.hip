@@ -184,7 +184,7 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
     const double flops = 2.0 * rows * a.Cout * cin * a.KT;
     const double bytes = 4.0 * (rows * cin * (a.X2 ? 2 : 1) + rows * a.Cout + (double)a.Cout * cin * a.KT);
-    ProfScope ps(c, "conv_gemm", flops, bytes);
+    ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
     if (a.X2) hipLaunchKernelGGL(k_conv_gemm<true>, dim3(grid), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL(k_conv_gemm<false>, dim3(grid), dim3(256), 0, c->stream, a);
     KCHECK(c);
