@@ -52,6 +52,7 @@ struct ConvArgs {
     int pad_mode;          // 0 = "same" with reflect padding, 1 = "valid" (src row = t + kk*dil)
     int act1, act2;        // act1: 0 none 1 relu 2 leaky(0.01); act2 (after BN): 0 none 1 tanh 2 sigmoid
     int m_tiles, n_tiles;
+    int sched;             // persistent-schedule variant (set by the launcher)
 };
 
 struct EcapaWeights {

@@ -15,10 +15,18 @@
 // 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).  LDS rows are padded to 36 floats:
 // ds_read_b128 of 16 distinct rows then hits 16 distinct 4-bank slots (conflict
 // free), and every row start stays 16-byte aligned.  Global->LDS goes through
-// registers with the next step's loads issued before the current step's MFMAs
-// (2 LDS buffers, one barrier per K step).  blockIdx is remapped so that the
-// N tiles sharing one A row-panel run on one XCD (shared L2).
+// registers: the next step's loads are issued before the current step's MFMAs and
+// written to the other LDS buffer half-way through them (one barrier per K step).
+//
+// Persistent schedule: the grid is 2 workgroups per CU; workgroup w (XCD = w % 8 under
+// round-robin dispatch, a speed assumption only) walks a contiguous slice of its XCD's
+// tile list (row panels m = xcd + 8j, all column tiles of a panel consecutively, so the
+// A panel it just read is re-read from its own L2).  The K-step pipeline runs straight
+// across tile boundaries: the first loads of tile i+1 are in flight while tile i's
+// accumulators go through the epilogue, so short-K layers (Res2Net K=384, ASP K=128)
+// do not pay a load-latency bubble per tile.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned float4 (x_ld may be 10)
@@ -27,70 +35,95 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte a
 #define BN 128
 #define BK 32
 #define LDP 36
+#define SD_CONV_SCHED_DEFAULT 3
 
-template <bool HAS_X2>
+// DBG (micro-benchmark ablations only, never used by the pipeline): 1 = no epilogue stores,
+// 2 = no global loads inside the K loop, 3 = no LDS restaging / barrier inside the K loop
+template <bool HAS_X2, int DBG>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 {
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDP];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDP];
 
-    // XCD-aware tile mapping: blocks b and b+8 share an XCD; give each XCD whole row panels
-    const int id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    const int mt = (slot / a.n_tiles) * 8 + xcd;
-    const int nt = slot % a.n_tiles;
-    if (mt >= a.m_tiles) return;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int w = blockIdx.x, G = gridDim.x;                 // G is a multiple of 8
+    const int xcd = w & 7, wl = w >> 3, wpx = G >> 3;
+    const int mx = (a.m_tiles - xcd + 7) >> 3;               // row panels owned by this XCD
+    const int Lx = mx * a.n_tiles;
+    // interleaved assignment: workgroup wl takes tiles wl, wl+wpx, ... of its XCD's list, so the workgroups
+    // of an XCD work on adjacent tiles (same row panel) at the same time and share that panel in L2
+    const int q0 = wl, q_step = wpx, q_end = Lx;
+    if (q0 >= q_end) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int c4 = tid & 7, r0 = tid >> 3;
+    const int li = lane & 31, lh = lane >> 5;
 
-    // per-thread staging rows
-    int item_base[4], tt[4];
-    size_t wrow[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int g = m0 + r0 + 32 * p;
-        if (g > a.M - 1) g = a.M - 1;
-        int b = g / a.TpOut;
-        int t = g - b * a.TpOut;
-        if (t > a.T - 1) t = a.T - 1;
-        item_base[p] = b * a.TpIn;
-        tt[p] = t;
-        int co = n0 + r0 + 32 * p;
-        if (co > a.Cout - 1) co = a.Cout - 1;
-        wrow[p] = (size_t)co * a.Cin;
-    }
     const int kcs = a.Cin / BK;
     const int S = a.KT * kcs;
     const int half = a.KT / 2;
 
-    f4u ra[4], rb[4];
-    auto gload = [&](int s) {
-        const int kk = s / kcs, kc = s - kk * kcs;
-        const int coff = kc * BK + c4 * 4;
+    // ---- load stream state (runs one K-step ahead of the compute stream) ----
+    int item_base[4], tt[4];
+    size_t wrow[4];
+    const float* pa[4]; const float* pb[4]; const float* px[4];
+    int l_q = q0, l_kk = 0, l_kc = 0, m0l = 0, n0l = 0;
+    auto set_tile = [&](int qq) {
+        const int j = qq / a.n_tiles, nt = qq - j * a.n_tiles;
+        m0l = (xcd + 8 * j) * BM; n0l = nt * BN;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            int q;
-            if (a.pad_mode == 0) {
-                q = tt[p] + (kk - half) * a.dil;
-                if (q < 0) q = -q;
-                if (q >= a.Tin) q = 2 * (a.Tin - 1) - q;
-                if (q < 0) q = 0;
-            } else {
-                q = tt[p] + kk * a.dil;
-                if (q > a.Tin - 1) q = a.Tin - 1;
-            }
-            const size_t row = (size_t)(item_base[p] + q);
-            ra[p] = *(const f4u*)(a.X + row * a.x_ld + coff);
-            if (HAS_X2) {
-                f4u v2 = *(const f4u*)(a.X2 + row * a.x2_ld + coff);
-                ra[p] += v2;
-            }
-            rb[p] = *(const f4u*)(a.W + (size_t)kk * a.Cout * a.Cin + wrow[p] + coff);
+            int g = m0l + r0 + 32 * p;
+            if (g > a.M - 1) g = a.M - 1;
+            const int b = g / a.TpOut;
+            int t = g - b * a.TpOut;
+            if (t > a.T - 1) t = a.T - 1;
+            item_base[p] = b * a.TpIn;
+            tt[p] = t;
+            int co = n0l + r0 + 32 * p;
+            if (co > a.Cout - 1) co = a.Cout - 1;
+            wrow[p] = (size_t)co * a.Cin;
         }
+    };
+    auto set_tap = [&](int kk) {          // pointers of K-chunk 0 of tap kk (reflect / valid row map)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int qr;
+            if (a.pad_mode == 0) {
+                qr = tt[p] + (kk - half) * a.dil;
+                if (qr < 0) qr = -qr;
+                if (qr >= a.Tin) qr = 2 * (a.Tin - 1) - qr;
+                if (qr < 0) qr = 0;
+            } else {
+                qr = tt[p] + kk * a.dil;
+                if (qr > a.Tin - 1) qr = a.Tin - 1;
+            }
+            const size_t row = (size_t)(item_base[p] + qr);
+            pa[p] = a.X + row * a.x_ld + c4 * 4;
+            if (HAS_X2) px[p] = a.X2 + row * a.x2_ld + c4 * 4;
+            pb[p] = a.W + (size_t)kk * a.Cout * a.Cin + wrow[p] + c4 * 4;
+        }
+    };
+    auto advance = [&]() {                // move the load stream to the next K-step
+        if (++l_kc < kcs) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { pa[p] += BK; pb[p] += BK; if (HAS_X2) px[p] += BK; }
+            return;
+        }
+        l_kc = 0;
+        if (++l_kk == a.KT) {
+            l_kk = 0;
+            if (l_q + q_step < q_end) { l_q += q_step; set_tile(l_q); }   // else: stay on the last tile (dummy loads)
+        }
+        set_tap(l_kk);
+    };
+
+    f4u ra[4], rb[4];
+    auto gload_part = [&](int p) {
+        ra[p] = *(const f4u*)pa[p];
+        if (HAS_X2) { const f4u v2 = *(const f4u*)px[p]; ra[p] += v2; }
+        rb[p] = *(const f4u*)pb[p];
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -108,67 +141,154 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    const int li = lane & 31, lh = lane >> 5;
     const int aoff = (wr * 64 + li) * LDP + lh * 16;
     const int boff = (wc * 64 + li) * LDP + lh * 16;
-
-    for (int s = 0; s < S; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < S) gload(s + 1);
+    auto mma = [&](int buf, int qq) {
         const float* Ab = &As[buf][aoff];
         const float* Bb = &Bs[buf][boff];
+        const float4 a0 = *(const float4*)(Ab + qq * 4);
+        const float4 a1 = *(const float4*)(Ab + 32 * LDP + qq * 4);
+        const float4 b0 = *(const float4*)(Bb + qq * 4);
+        const float4 b1 = *(const float4*)(Bb + 32 * LDP + qq * 4);
+        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+        const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 a0 = *(const float4*)(Ab + q * 4);
-            const float4 a1 = *(const float4*)(Ab + 32 * LDP + q * 4);
-            const float4 b0 = *(const float4*)(Bb + q * 4);
-            const float4 b1 = *(const float4*)(Bb + 32 * LDP + q * 4);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
-            }
+        for (int e = 0; e < 4; ++e) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
         }
-        if (s + 1 < S) lstore(buf ^ 1);
-        __syncthreads();
-    }
+    };
 
-    // epilogue: C layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // prologue: stage step 0 of the first tile
+    set_tile(l_q);
+    set_tap(0);
+    int m0c = m0l, n0c = n0l;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int g = m0 + row;
-            if (g >= a.M) continue;
-            const int b = g / a.TpOut;
-            const int t = g - b * a.TpOut;
-            const bool live = t < a.T;
+    for (int p = 0; p < 4; ++p) gload_part(p);
+    lstore(0);
+    __syncthreads();
+    advance();
+
+    int q = q0, s = 0, buf = 0;
+    while (true) {
+        const int cb = (DBG == 3) ? 0 : buf;
+        // one basic block: the next step's global loads are spread between the four MFMA groups
+        mma(cb, 0); if (DBG < 2) gload_part(0);
+        mma(cb, 1); if (DBG < 2) gload_part(1);
+        mma(cb, 2); if (DBG < 2) gload_part(2);
+        mma(cb, 3); if (DBG < 2) gload_part(3);
+        if (DBG < 3) { lstore(buf ^ 1); __syncthreads(); }
+        const int m0n = m0l, n0n = n0l;           // origin of the tile the load stream is on
+        advance();
+
+        if (s == S - 1) {
+            // ---- epilogue.  C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+            // Per-column work (bias, activation, folded BN) happens while a lane still owns one column;
+            // then each group of 4 registers (4 consecutive rows) is transposed inside its lane quad so
+            // that a lane owns 4 consecutive columns of one row and stores one dwordx4 (16 wide stores
+            // per lane and tile instead of 64 scalar ones).
+            float cb_[2] = {0.0f, 0.0f}, cs_[2] = {1.0f, 1.0f}, ch_[2] = {0.0f, 0.0f};
+            int cco[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int co = n0 + wc * 64 + j * 32 + li;
-                if (co >= a.Cout) continue;
-                float v = acc[i][j][r];
-                if (a.bias) v += a.bias[co];
-                if (a.item_bias) v += a.item_bias[(size_t)b * a.ib_ld + co];
-                if (a.act1 == 1) v = v > 0.0f ? v : 0.0f;
-                else if (a.act1 == 2) v = v > 0.0f ? v : 0.01f * v;
-                if (a.scale) v = v * a.scale[co] + a.shift[co];
-                if (a.act2 == 1) v = tanhf(v);
-                else if (a.act2 == 2) v = 1.0f / (1.0f + expf(-v));
-                if (a.R) v += a.R[(size_t)g * a.r_ld + co];
-                a.Y[(size_t)g * a.y_ld + co] = live ? v : 0.0f;
+                cco[j] = n0c + wc * 64 + j * 32 + li;
+                const int cc = cco[j] < a.Cout ? cco[j] : a.Cout - 1;
+                if (a.bias) cb_[j] = a.bias[cc];
+                if (a.scale) { cs_[j] = a.scale[cc]; ch_[j] = a.shift[cc]; }
             }
+            const float slope = (a.act1 == 1) ? 0.0f : ((a.act1 == 2) ? 0.01f : 1.0f);
+            const int b0 = m0c / a.TpOut, t0 = m0c - b0 * a.TpOut;      // wave-uniform
+            const bool fast_rows = a.TpOut >= BM;
+            const bool wide = ((a.Cout | a.y_ld) & 3) == 0 && a.R == nullptr;
+            const int lq = lane & 3;
+            auto tile_out = [&](auto IBt, auto A2t) {
+                constexpr bool IB = decltype(IBt)::value;
+                constexpr int A2 = decltype(A2t)::value;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        float x[2][4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = wr * 64 + i * 32 + e + 8 * gq + 4 * lh;
+                            int b, t;
+                            if (fast_rows) { t = t0 + row; b = b0; if (t >= a.TpOut) { t -= a.TpOut; b += 1; } }
+                            else { const int g = m0c + row; b = g / a.TpOut; t = g - b * a.TpOut; }
+                            const bool live = t < a.T;
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                float v = acc[i][j][4 * gq + e] + cb_[j];
+                                acc[i][j][4 * gq + e] = 0.0f;
+                                if (IB) v += a.item_bias[(size_t)b * a.ib_ld + (cco[j] < a.Cout ? cco[j] : a.Cout - 1)];
+                                v = v > 0.0f ? v : v * slope;
+                                v = v * cs_[j] + ch_[j];
+                                if (A2 == 1) v = tanhf(v);
+                                else if (A2 == 2) v = 1.0f / (1.0f + expf(-v));
+                                x[j][e] = live ? v : 0.0f;
+                            }
+                        }
+                        if (wide) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                // 4x4 transpose across the lane quad (two butterfly stages on DPP quad_perm)
+                                float s0 = (lq & 1) ? x[j][0] : x[j][1];
+                                float s1 = (lq & 1) ? x[j][2] : x[j][3];
+                                float r0_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xF, 0xF, true));
+                                float r1_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xF, 0xF, true));
+                                if (lq & 1) { x[j][0] = r0_; x[j][2] = r1_; } else { x[j][1] = r0_; x[j][3] = r1_; }
+                                s0 = (lq & 2) ? x[j][0] : x[j][2];
+                                s1 = (lq & 2) ? x[j][1] : x[j][3];
+                                r0_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0x4E, 0xF, 0xF, true));
+                                r1_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0x4E, 0xF, 0xF, true));
+                                if (lq & 2) { x[j][0] = r0_; x[j][1] = r1_; } else { x[j][2] = r0_; x[j][3] = r1_; }
+                                const int g = m0c + wr * 64 + i * 32 + 8 * gq + 4 * lh + lq;
+                                const int co = n0c + wc * 64 + j * 32 + (li & ~3);
+                                if (g < a.M && co < a.Cout) {
+                                    if (DBG == 1) { if (x[j][0] == 12345.678f) a.Y[0] = x[j][1]; }
+                                    else *(float4*)(a.Y + (size_t)g * a.y_ld + co) = make_float4(x[j][0], x[j][1], x[j][2], x[j][3]);
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int g = m0c + wr * 64 + i * 32 + e + 8 * gq + 4 * lh;
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    if (g >= a.M || cco[j] >= a.Cout) continue;
+                                    float v = x[j][e];
+                                    if (a.R) v += a.R[(size_t)g * a.r_ld + cco[j]];
+                                    a.Y[(size_t)g * a.y_ld + cco[j]] = v;
+                                }
+                            }
+                        }
+                    }
+                }
+            };
+            using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+            if (a.item_bias) { if (a.act2 == 1) tile_out(std::true_type{}, T1{}); else if (a.act2 == 2) tile_out(std::true_type{}, T2{}); else tile_out(std::true_type{}, T0{}); }
+            else { if (a.act2 == 1) tile_out(std::false_type{}, T1{}); else if (a.act2 == 2) tile_out(std::false_type{}, T2{}); else tile_out(std::false_type{}, T0{}); }
+            q += q_step;
+            if (q >= q_end) break;
+            m0c = m0n; n0c = n0n; s = 0;
+        } else {
+            ++s;
         }
+        buf ^= 1;
     }
+}
+
+static int conv_grid(sd_ctx* c, const ConvArgs& a)
+{
+    int g = 2 * c->num_cu;
+    g = (g / 8) * 8;
+    if (g < 8) g = 8;
+    // no point launching more workgroups per XCD than the busiest XCD has tiles
+    const int lx_max = ((a.m_tiles + 7) / 8) * a.n_tiles;
+    if (g / 8 > lx_max) g = lx_max * 8;
+    return g;
 }
 
 int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
@@ -178,15 +298,65 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     if (a.M <= 0) return SD_OK;
     a.m_tiles = (a.M + BM - 1) / BM;
     a.n_tiles = (a.Cout + BN - 1) / BN;
-    const int grid = ((a.m_tiles + 7) / 8) * 8 * a.n_tiles;
+    a.sched = SD_CONV_SCHED_DEFAULT;
+    const int grid = conv_grid(c, a);
     // algorithmic work: valid rows only (T of every TpOut), un-padded input channels
     const double rows = (double)(a.M / a.TpOut) * a.T + (double)((a.M % a.TpOut) < a.T ? (a.M % a.TpOut) : a.T);
     const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
     const double flops = 2.0 * rows * a.Cout * cin * a.KT;
     const double bytes = 4.0 * (rows * cin * (a.X2 ? 2 : 1) + rows * a.Cout + (double)a.Cout * cin * a.KT);
     ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
-    if (a.X2) hipLaunchKernelGGL(k_conv_gemm<true>, dim3(grid), dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL(k_conv_gemm<false>, dim3(grid), dim3(256), 0, c->stream, a);
+    if (a.X2) hipLaunchKernelGGL((k_conv_gemm<true, 0>), dim3(grid), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_conv_gemm<false, 0>), dim3(grid), dim3(256), 0, c->stream, a);
     KCHECK(c);
+    return SD_OK;
+}
+
+// ---- measurement hook: time one conv_gemm shape on random-filled scratch buffers (tools/tune_conv.py)
+__global__ void k_fill_rand(float* p, int64_t n, unsigned seed)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)i * 2654435761u + seed;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    p[i] = ((float)(x & 0xffffff) / 8388608.0f - 1.0f) * 0.5f;
+}
+
+extern "C" int sd_bench_conv(sd_ctx* c, int64_t items, int Tp, int T, int Cin, int Cout, int KT, int dil, int has_x2, int dbg, int reps, double* ms_per_launch)
+{
+    if (!c || !ms_per_launch || items <= 0 || Cin % BK) return SD_ERR_ARG;
+    c->err.clear();
+    if (hipSetDevice(c->device) != hipSuccess) return SD_ERR_HIP;
+    const int64_t M = items * Tp;
+    WS(c, float, X, "bc_X", M * Cin);
+    WS(c, float, X2, "bc_X2", has_x2 ? M * Cin : 16);
+    WS(c, float, W, "bc_W", (int64_t)KT * Cout * Cin);
+    WS(c, float, Y, "bc_Y", M * Cout);
+    WS(c, float, B, "bc_B", 3 * Cout);
+    hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)((M * Cin + 255) / 256)), dim3(256), 0, c->stream, X, M * Cin, 1u);
+    if (has_x2) hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)((M * Cin + 255) / 256)), dim3(256), 0, c->stream, X2, M * Cin, 2u);
+    hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)(((int64_t)KT * Cout * Cin + 255) / 256)), dim3(256), 0, c->stream, W, (int64_t)KT * Cout * Cin, 3u);
+    hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)((3 * Cout + 255) / 256)), dim3(256), 0, c->stream, B, (int64_t)3 * Cout, 4u);
+    ConvArgs a; memset(&a, 0, sizeof(a));
+    a.X = X; a.x_ld = Cin; a.X2 = has_x2 ? X2 : nullptr; a.x2_ld = Cin; a.W = W; a.Y = Y; a.y_ld = Cout;
+    a.bias = B; a.scale = B + Cout; a.shift = B + 2 * Cout; a.act1 = 1;
+    a.M = (int)M; a.TpIn = a.TpOut = Tp; a.Tin = a.T = T; a.Cin = Cin; a.Cout = Cout; a.KT = KT; a.dil = dil; a.pad_mode = 0;
+    a.m_tiles = (a.M + BM - 1) / BM; a.n_tiles = (a.Cout + BN - 1) / BN;
+    a.sched = (dbg >= 10) ? (dbg / 10 - 1) : SD_CONV_SCHED_DEFAULT;   // dbg = 10*(sched+1) + ablation
+    dbg %= 10;
+    const int grid = conv_grid(c, a);
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+#define LAUNCH_V(X2, D) hipLaunchKernelGGL((k_conv_gemm<X2, D>), dim3(grid), dim3(256), 0, c->stream, a)
+#define LAUNCH_S(X2) do { if (dbg == 0) LAUNCH_V(X2, 0); else if (dbg == 1) LAUNCH_V(X2, 1); else if (dbg == 2) LAUNCH_V(X2, 2); else LAUNCH_V(X2, 3); } while (0)
+    for (int r = -2; r < reps; ++r) {
+        if (r == 0) HIPCHK(c, hipEventRecord(e0, c->stream));
+        if (has_x2) LAUNCH_S(true); else LAUNCH_S(false);
+    }
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return SD_OK;
 }
