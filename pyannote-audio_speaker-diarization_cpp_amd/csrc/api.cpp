@@ -83,6 +83,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     std::string k(key);
     if (k == "emb_batch_items") c->emb_batch_items = v;
     else if (k == "seg_batch_chunks") c->seg_batch_chunks = v;
+    else if (k == "linkage_wgs") c->linkage_wgs = v;
     else if (k == "profile") { c->profile = v != 0; c->profile_detail = v >= 2; }
     else SD_FAIL(c, SD_ERR_ARG, "unknown option %s", key);
     return SD_OK;

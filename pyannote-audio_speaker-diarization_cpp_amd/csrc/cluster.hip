@@ -125,6 +125,32 @@ __global__ __launch_bounds__(256) void k_row_nn(const double* __restrict__ D, in
     if (lane == 0) { nb[x] = m.i; md[x] = (m.i < 0) ? INFINITY : m.v; }
 }
 
+
+// nearest active neighbour above row x, scanned by `nthreads` threads with U loads in flight per thread
+// (a plain strided loop keeps one load outstanding and is latency bound: ~1 us per element per thread)
+template <int U>
+__device__ __forceinline__ MinIdx scan_row_nn(const double* __restrict__ D, const int* __restrict__ size, int64_t N, int n, int x,
+                                              int first, int stride)
+{
+    MinIdx q; q.v = INFINITY; q.i = -1;
+    const double* row = D + cidx(N, x, (int64_t)x + 1) - (x + 1);       // row[j] = D[x, j]
+    for (int j0 = x + 1 + first; j0 < n; j0 += stride * U) {
+        double v[U]; int sz[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * stride;
+            const int jc = j < n ? j : n - 1;
+            v[u] = row[jc]; sz[u] = size[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * stride;
+            if (j < n && sz[u] != 0 && v[u] < q.v) { q.v = v[u]; q.i = j; }
+        }
+    }
+    return q;
+}
+
 // Lance-Williams centroid update with the reference's operation order, cl.cpp:250-256
 __device__ __forceinline__ double lw_centroid(double d_xi, double d_yi, double d_xy, int sx, int sy)
 {
@@ -158,18 +184,20 @@ __global__ __launch_bounds__(LT) void k_linkage(double* D, int n, int* size, int
         int x, y; double dist;
         for (int guard = 0; guard <= n - k; ++guard) {
             MinIdx m; m.v = INFINITY; m.i = -1;
-            for (int r = tid; r < n - 1; r += LT)
-                if (size[r] > 0) { const double v = md[r]; if (m.i < 0 || v < m.v) { m.v = v; m.i = r; } }
+            for (int r0 = tid; r0 < n - 1; r0 += LT * 4) {           // 4 rows per thread in flight
+                double v[4]; int sz[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int r = r0 + u * LT; const int rc = r < n - 1 ? r : n - 2; v[u] = md[rc]; sz[u] = size[rc]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int r = r0 + u * LT; if (r < n - 1 && sz[u] > 0 && (m.i < 0 || v[u] < m.v)) { m.v = v[u]; m.i = r; } }
+            }
             m = block_min(m, sh);
             x = m.i; dist = m.v; y = nb[x];
             if (tid == 0) s_ok = (y >= 0) && (dist == D[cidx(N, x, y)]);          // cl.cpp:329
             __syncthreads();
             if (s_ok) break;
             // stale candidate: recompute row x's true nearest neighbour (cl.cpp:333-338)
-            MinIdx q; q.v = INFINITY; q.i = -1;
-            const double* row = D + cidx(N, x, (int64_t)x + 1);
-            for (int j = x + 1 + tid; j < n; j += LT)
-                if (size[j] != 0) { const double v = row[j - x - 1]; if (v < q.v) { q.v = v; q.i = j; } }
+            MinIdx q = scan_row_nn<4>(D, size, N, n, x, tid, LT);
             q = block_min(q, sh);
             if (tid == 0) { nb[x] = q.i; md[x] = (q.i < 0) ? INFINITY : q.v; }
             __syncthreads();
@@ -184,25 +212,295 @@ __global__ __launch_bounds__(LT) void k_linkage(double* D, int n, int* size, int
             size[x] = 0; size[y] = nx + ny; cid[y] = n + k;
         }
         __syncthreads();
-        for (int z = tid; z < n; z += LT) {
-            if (z == y || size[z] == 0) continue;
-            const int64_t izy = cidx(N, z, y);
-            const double nd = lw_centroid(D[cidx(N, z, x)], D[izy], dist, nx, ny);   // cl.cpp:367
-            D[izy] = nd;
-            if (z < x && nb[z] == x) nb[z] = y;                                       // cl.cpp:374-378
-            if (z < y && nd < md[z]) { nb[z] = y; md[z] = nd; }                       // cl.cpp:381-392
+        for (int z0 = tid; z0 < n; z0 += LT * 4) {                   // 4 rows per thread: all their loads issued together
+            double dzx[4], dzy[4], mdz[4]; int sz[4], nbz[4]; int64_t izy[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int z = z0 + u * LT;
+                const int zc = (z < n && z != y) ? z : ((y > 0) ? 0 : 1);        // any valid row other than y
+                izy[u] = cidx(N, zc, y);
+                sz[u] = size[zc];
+                dzx[u] = (zc == x) ? 0.0 : D[cidx(N, zc, x)];
+                dzy[u] = D[izy[u]];
+                const int zr = zc < n - 1 ? zc : n - 2;
+                nbz[u] = nb[zr]; mdz[u] = md[zr];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int z = z0 + u * LT;
+                if (z >= n || z == y || sz[u] == 0) continue;
+                const double nd = lw_centroid(dzx[u], dzy[u], dist, nx, ny);           // cl.cpp:367
+                D[izy[u]] = nd;
+                if (z < x && nbz[u] == x) nb[z] = y;                                    // cl.cpp:374-378
+                if (z < y && nd < mdz[u]) { nb[z] = y; md[z] = nd; }                    // cl.cpp:381-392
+            }
         }
         __syncthreads();
         if (y < n - 1) {                                                              // cl.cpp:395-404
-            MinIdx q; q.v = INFINITY; q.i = -1;
-            const double* row = D + cidx(N, y, (int64_t)y + 1);
-            for (int j = y + 1 + tid; j < n; j += LT)
-                if (size[j] != 0) { const double v = row[j - y - 1]; if (v < q.v) { q.v = v; q.i = j; } }
+            MinIdx q = scan_row_nn<4>(D, size, N, n, y, tid, LT);
             q = block_min(q, sh);
             if (tid == 0 && q.i >= 0) { nb[y] = q.i; md[y] = q.v; }
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------- k_linkage_mw : the same algorithm on G co-resident workgroups
+// Rows are owned round-robin (row z belongs to workgroup z % G).  Per merge every workgroup
+//   1. applies the size bookkeeping of the merge to its own view (identical stores from all workgroups),
+//   2. runs the Lance-Williams update for its rows, folding the nearest-neighbour search of row y into the
+//      same pass (the new D[z,y], z > y, are in registers: row y is never re-read),
+//   3. computes its local arg-min of the lower bounds and publishes {NN(y) partial, arg-min} in a slot,
+//   4. meets the others at ONE device-scope barrier (agent-scope release before arriving, one relaxed poll,
+//      agent-scope acquire after; placement independent) and reduces the G slots, so all workgroups take the
+//      same decision without a broadcast.
+// A stale candidate (cl.cpp:329-338) costs one extra round in which every workgroup refreshes its own
+// submitted row if that one is stale.  Used for large N, where one CU's memory pipeline is the bottleneck.
+#define MWT 256
+struct MwSlot { double nnv; double amv; int nni; int ami; int amy; int fresh; };
+// arg-min candidate that carries its neighbour and freshness along through the reductions
+struct Cand { double v; int i; int y; int fresh; };
+
+__device__ __forceinline__ bool mw_barrier(unsigned* counter, unsigned target, unsigned* timeout_flag)
+{
+    __syncthreads();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 26)) { *timeout_flag = 1; ok = false; break; }      // ~seconds: never in a healthy run
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    return ok;
+}
+
+__device__ __forceinline__ MinIdx block_min_t(MinIdx m, MinIdx* sh, int nwaves)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    m = wave_min(m);
+    __syncthreads();
+    if (lane == 0) sh[w] = m;
+    __syncthreads();
+    MinIdx r = sh[0];
+    for (int k = 1; k < nwaves; ++k) r = better(r, sh[k]);
+    return r;
+}
+__device__ __forceinline__ Cand cbetter(Cand a, Cand b)
+{
+    if (b.i < 0) return a;
+    if (a.i < 0) return b;
+    if (b.v < a.v) return b;
+    if (b.v == a.v && b.i < a.i) return b;
+    return a;
+}
+__device__ __forceinline__ Cand block_min_c(Cand m, Cand* sh, int nwaves)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+        Cand t; t.v = __shfl_xor(m.v, o); t.i = __shfl_xor(m.i, o); t.y = __shfl_xor(m.y, o); t.fresh = __shfl_xor(m.fresh, o);
+        m = cbetter(m, t);
+    }
+    __syncthreads();
+    if (lane == 0) sh[w] = m;
+    __syncthreads();
+    Cand r = sh[0];
+    for (int k = 1; k < nwaves; ++k) r = cbetter(r, sh[k]);
+    return r;
+}
+
+__global__ __launch_bounds__(MWT) void k_linkage_mw(double* D, int n, int* size_all /*[G][n] private copies*/, int* cid, int* nb, double* md,
+                                                    unsigned char* fresh_flag /*[n]: md[r] == D[r, nb[r]] known to hold*/, double* Z,
+                                                    MwSlot* slots /*[2][G]*/, unsigned* sync /*[0]=counter [1]=timeout [2]=retry rounds*/)
+{
+    __shared__ MinIdx sh[MWT / 64];
+    __shared__ Cand shc[MWT / 64];
+    const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
+    const int64_t N = n;
+    // every workgroup applies every merge to its OWN copy of the cluster sizes: a shared array would be
+    // written by fast workgroups while slow ones still read the pre-merge sizes
+    int* size = size_all + (size_t)g * n;
+    unsigned bar = 0;              // barriers passed so far
+    int par = 0;
+    auto barrier = [&]() -> bool { ++bar; return mw_barrier(&sync[0], bar * (unsigned)G, &sync[1]); };
+    // local arg-min over the owned active rows
+    auto local_argmin = [&]() -> Cand {
+        Cand m; m.v = INFINITY; m.i = -1; m.y = -1; m.fresh = 0;
+        for (int r = g + G * tid; r < n - 1; r += G * MWT)
+            if (size[r] > 0) { const double v = md[r]; if (m.i < 0 || v < m.v) { m.v = v; m.i = r; m.y = nb[r]; m.fresh = fresh_flag[r]; } }
+        return block_min_c(m, shc, MWT / 64);
+    };
+    // whole-row nearest-neighbour scan by this workgroup alone (rows it owns)
+    auto own_row_nn = [&](int x) -> MinIdx {
+        MinIdx q = scan_row_nn<8>(D, size, N, n, x, tid, MWT);
+        return block_min_t(q, sh, MWT / 64);
+    };
+    auto reduce_slots = [&](int p, MinIdx& nn, Cand& am) {
+        MinIdx a; a.v = INFINITY; a.i = -1;
+        Cand b; b.v = INFINITY; b.i = -1; b.y = -1; b.fresh = 0;
+        for (int k = tid; k < G; k += MWT) {
+            const MwSlot sl = slots[p * G + k];
+            MinIdx t; t.v = sl.nnv; t.i = sl.nni; a = better(a, t);
+            Cand u; u.v = sl.amv; u.i = sl.ami; u.y = sl.amy; u.fresh = sl.fresh; b = cbetter(b, u);
+        }
+        nn = block_min_t(a, sh, MWT / 64);
+        am = block_min_c(b, shc, MWT / 64);
+    };
+    auto publish = [&](MinIdx q, Cand m) {
+        if (tid == 0) {
+            MwSlot sl; sl.nnv = q.v; sl.nni = q.i; sl.amv = m.v; sl.ami = m.i; sl.amy = m.y; sl.fresh = m.fresh;
+            slots[par * G + g] = sl;
+        }
+    };
+
+    // initial state: k_row_nn produced exact bounds for every row
+    for (int r = g + G * tid; r < n - 1; r += G * MWT) fresh_flag[r] = 1;
+    __syncthreads();
+    MinIdx none; none.v = INFINITY; none.i = -1;
+    Cand m0 = local_argmin();
+    int my_best = m0.i;
+    publish(none, m0);
+    if (!barrier()) return;
+    MinIdx nn; Cand am;
+    reduce_slots(par, nn, am);
+    par ^= 1;
+    int x = am.i, y = am.y; double dist = am.v; bool fresh = am.fresh != 0;
+#ifdef SD_LINKAGE_STAMPS
+    unsigned long long tS = __builtin_amdgcn_s_memrealtime(), acc[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); acc[i] += t_ - tS; tS = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+    for (int k = 0; k < n - 1; ++k) {
+        // ---- lazy validation (cl.cpp:323-339), batched: while the global candidate is stale, EVERY workgroup
+        // refreshes its own submitted row if that one is stale (one whole-row scan, in parallel across
+        // workgroups), then the arg-min is exchanged again.  The stale global candidate is one of those rows,
+        // so each round makes progress; rows refreshed early are rows the reference would have had to refresh
+        // before they could be merged anyway.  "fresh" = the owner knows md[x] == D[x, nb[x]] (cl.cpp:329).
+        for (int guard = 0; guard <= n - k; ++guard) {
+            if (fresh && y >= 0) break;
+            if (g == 0 && tid == 0) sync[2] += 1;            // diagnostic: retry rounds
+            if (my_best >= 0 && !fresh_flag[my_best] && md[my_best] != INFINITY) {
+                MinIdx q2 = own_row_nn(my_best);
+                if (tid == 0) { nb[my_best] = q2.i; md[my_best] = (q2.i < 0) ? INFINITY : q2.v; fresh_flag[my_best] = 1; }
+                __syncthreads();
+            }
+            Cand m = local_argmin();
+            my_best = m.i;
+            publish(none, m);
+            if (!barrier()) return;
+            reduce_slots(par, nn, am);
+            par ^= 1;
+            x = am.i; dist = am.v; y = am.y; fresh = am.fresh != 0;
+        }
+        STAMP(0);   // validation / retry rounds
+        // ---- merge (x, y) at height dist
+        const int nx = size[x], ny = size[y];
+        __syncthreads();
+        if (tid == 0) {
+            size[x] = 0; size[y] = nx + ny;                   // every workgroup keeps its own view current
+            if (g == 0) {
+                int ix = cid[x], iy = cid[y];
+                if (ix > iy) { const int t = ix; ix = iy; iy = t; }
+                Z[(size_t)k * 4 + 0] = (double)ix; Z[(size_t)k * 4 + 1] = (double)iy;
+                Z[(size_t)k * 4 + 2] = dist;       Z[(size_t)k * 4 + 3] = (double)(nx + ny);
+                cid[y] = n + k;
+            }
+        }
+        __syncthreads();
+        if (k == n - 2) break;
+        STAMP(1);   // bookkeeping
+        // One pass over the owned rows: Lance-Williams update + neighbour patches (cl.cpp:361-392), the
+        // nearest neighbour of row y from the freshly computed distances (cl.cpp:395-404), and the next
+        // local arg-min of the lower bounds.  All loads of a row are issued together (one latency).
+        MinIdx q = none;
+        Cand m; m.v = INFINITY; m.i = -1; m.y = -1; m.fresh = 0;
+        for (int z = g + G * tid; z < n; z += G * MWT) {
+            if (z == y) continue;
+            const int sz = size[z];
+            const int64_t izy = cidx(N, z, y);
+            const double dzx = (z == x) ? 0.0 : D[cidx(N, z, x)];
+            const double dzy = D[izy];
+            int nbz = -1; double mdz = INFINITY; int frz = 0;
+            if (z < n - 1) { nbz = nb[z]; mdz = md[z]; frz = fresh_flag[z]; }
+            if (sz == 0) continue;
+            const double nd = lw_centroid(dzx, dzy, dist, nx, ny);
+            D[izy] = nd;
+            if (z < y) {
+                bool touch = false;
+                if (z < x && nbz == x) { nbz = y; touch = true; }          // cl.cpp:374-378 (bound keeps its old value)
+                else if (nbz == y) touch = true;                            // the distance its bound refers to just changed
+                if (nd < mdz) { nbz = y; mdz = nd; frz = 1; md[z] = nd; nb[z] = y; fresh_flag[z] = 1; }   // cl.cpp:381-392
+                else if (touch) { frz = (mdz == nd); nb[z] = nbz; fresh_flag[z] = (unsigned char)frz; }
+            } else if (nd < q.v) { q.v = nd; q.i = z; }                     // z > y: candidate neighbour of row y
+            if (z < n - 1 && (m.i < 0 || mdz < m.v)) { m.v = mdz; m.i = z; m.y = nbz; m.fresh = frz; }
+        }
+        STAMP(2);   // LW pass
+        q = block_min_t(q, sh, MWT / 64);
+        m = block_min_c(m, shc, MWT / 64);                   // row y itself is handled through q
+        my_best = m.i;
+        publish(q, m);
+        STAMP(3);   // block reductions + publish
+        if (!barrier()) return;
+        STAMP(4);   // barrier
+        reduce_slots(par, nn, am);
+        par ^= 1;
+        STAMP(5);   // slot reduction
+        double mdy; int nby; bool fy;
+        if (y < n - 1 && nn.i >= 0) {
+            mdy = nn.v; nby = nn.i; fy = true;                // exact by construction
+            if (tid == 0 && (y % G) == g) { nb[y] = nby; md[y] = mdy; fresh_flag[y] = 1; }
+        } else {
+            mdy = (y < n - 1) ? md[y] : INFINITY; nby = (y < n - 1) ? nb[y] : -1; fy = false;
+            if (tid == 0 && y < n - 1 && (y % G) == g) fresh_flag[y] = 0;
+        }
+        Cand best = am;
+        if (y < n - 1) {
+            if (best.i < 0 || mdy < best.v || (mdy == best.v && y < best.i)) { best.v = mdy; best.i = y; best.y = nby; best.fresh = fy; }
+        }
+        if ((y % G) == g && best.i != y) { /* row y competes in this workgroup's later local arg-mins through md[y] */ }
+        x = best.i; dist = best.v; y = best.y; fresh = best.fresh != 0;
+        __syncthreads();
+    }
+#ifdef SD_LINKAGE_STAMPS
+    if (g == 0 && tid == 0) for (int i = 0; i < 6; ++i) sync[8 + i] = (unsigned)(acc[i] / 100);   // microseconds
+#endif
+}
+
+// tuning hook: cost of the device-scope barrier alone (mode 0), or with each workgroup dirtying `dirty` doubles first
+__global__ __launch_bounds__(MWT) void k_barrier_bench(unsigned* sync, int iters, double* scratch, int dirty)
+{
+    unsigned bar = 0;
+    const int G = gridDim.x;
+    for (int it = 0; it < iters; ++it) {
+        for (int i = threadIdx.x; i < dirty; i += MWT) scratch[((size_t)blockIdx.x * 7919 + (size_t)i * 104729 + it) % (1 << 22)] = (double)it;
+        ++bar;
+        if (!mw_barrier(&sync[0], bar * (unsigned)G, &sync[1])) return;
+    }
+}
+extern "C" int sd_bench_barrier(sd_ctx* c, int G, int iters, int dirty, double* us_per_barrier)
+{
+    if (!c || !us_per_barrier || G < 1 || G > c->num_cu) return SD_ERR_ARG;
+    WS(c, unsigned, sync, "cl_sync", 4);
+    WS(c, double, scratch, "bb_scratch", 1 << 22);
+    HIPCHK(c, hipMemsetAsync(sync, 0, 4 * sizeof(unsigned), c->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(k_barrier_bench, dim3(G), dim3(MWT), 0, c->stream, sync, iters, scratch, dirty);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    *us_per_barrier = ms * 1e3 / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return SD_OK;
 }
 
 __global__ void k_fill_i32(int* p, int v, int64_t n, int iota)
@@ -236,10 +534,34 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         hipLaunchKernelGGL(k_row_nn, dim3((unsigned)((N - 1 + 3) / 4)), dim3(256), 0, c->stream, D, N, nb, md);
         KCHECK(c);
     }
-    {
+    int G = (int)c->linkage_wgs;
+    if (G < 0) G = (N >= 6000) ? 64 : 0;                  // auto: one workgroup below ~6k rows (measured crossover on clustered data)
+    if (G > c->num_cu) G = c->num_cu;
+    if (G <= 1) {
         ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
         hipLaunchKernelGGL(k_linkage, dim3(1), dim3(LT), 0, c->stream, D, (int)N, size, cid, nb, md, d_Z);
         KCHECK(c);
+    } else {
+        WS(c, MwSlot, slots, "cl_slots", 2 * G);
+        WS(c, int, size_all, "cl_size_all", (int64_t)G * N);
+        WS(c, unsigned char, fresh_flag, "cl_fresh", N + 16);
+        hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)(((int64_t)G * N + 255) / 256)), dim3(256), 0, c->stream, size_all, 1, (int64_t)G * N, 0);
+        KCHECK(c);
+        WS(c, unsigned, sync, "cl_sync", 16);
+        HIPCHK(c, hipMemsetAsync(sync, 0, 16 * sizeof(unsigned), c->stream));
+        {
+            ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
+            hipLaunchKernelGGL(k_linkage_mw, dim3(G), dim3(MWT), 0, c->stream, D, (int)N, size_all, cid, nb, md, fresh_flag, d_Z, slots, sync);
+            KCHECK(c);
+        }
+        unsigned h[16] = {0};
+        HIPCHK(c, hipMemcpyAsync(h, sync, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (h[1]) SD_FAIL(c, SD_ERR_HIP, "linkage: device-scope barrier timed out (workgroups not co-resident?)");
+        c->stats["linkage_retry_rounds"].flops += (double)h[2];
+#ifdef SD_LINKAGE_STAMPS
+        fprintf(stderr, "linkage stamps (us): retry %u bookkeeping %u lw %u reductions %u barrier %u slots %u\n", h[8], h[9], h[10], h[11], h[12], h[13]);
+#endif
     }
     return SD_OK;
 }

@@ -34,7 +34,7 @@ EXPORTS = [
     "sd_postseg", "sd_count_frames", "sd_embed", "sd_embed_dev", "sd_frontend", "sd_ecapa", "sd_linkage", "sd_cluster",
     "sd_clustering", "sd_reconstruct", "sd_diarize", "sd_diarize_dev", "sd_free_turns", "sd_shard_infer_dev",
     "sd_finalize_dev", "sd_read_wav", "sd_free_pcm", "sd_format_turn", "sd_stage_ms", "sd_kernel_stats",
-    "sd_reset_stats", "sd_set_option", "sd_bench_conv",
+    "sd_reset_stats", "sd_set_option", "sd_bench_conv", "sd_bench_barrier",
 ]
 
 
@@ -80,6 +80,7 @@ def lib():
     L.sd_kernel_stats.argtypes = [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
     L.sd_reset_stats.argtypes = [vp]
     L.sd_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.sd_bench_barrier.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(dbl)]
     L.sd_bench_conv.argtypes = [vp, i64] + [C.c_int] * 9 + [C.POINTER(dbl)]
     _lib = L
     return L
@@ -280,6 +281,11 @@ class Diarizer:
         ms, n, fl, by = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
         self._chk(lib().sd_kernel_stats(self._h, name.encode(), C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
         return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+
+    def bench_barrier(self, G, iters=2000, dirty=0):
+        us = C.c_double(0)
+        self._chk(lib().sd_bench_barrier(self._h, G, iters, dirty, C.byref(us)))
+        return us.value
 
     def bench_conv(self, items, Tp, T, Cin, Cout, KT=1, dil=1, has_x2=0, dbg=0, reps=5):
         ms = C.c_double(0)
