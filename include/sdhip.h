@@ -43,12 +43,16 @@ enum {
 
 /* ---- context ------------------------------------------------------------
  * replaces OnnxModel::OnnxModel(path) x2 (onnx_model.cc:41-105) + SegmentModel /
- * EmbeddingModel1 construction (sd.cpp:2958, 3043).  Model files are ".sdw"
- * weight packs (tools/make_weights.py; an ONNX initializer reader is the next
- * row of SURVEY section 8f).  Either path may be NULL when only the other
- * network (or only clustering) is used. */
+ * EmbeddingModel1 construction (sd.cpp:2958, 3043).  Model files are either the
+ * reference's ONNX files (segment2.onnx / emd4.onnx as written by segment/export2.py
+ * and embeddings/export3.py; weights are pulled out of the graph, no ONNX runtime)
+ * or ".sdw" weight packs (tools/make_weights.py).  Either path may be NULL when only
+ * the other network (or only clustering) is used. */
 sd_ctx* sd_create(const char* seg_model_path, const char* emb_model_path, int device_id);
 void sd_destroy(sd_ctx*);
+/* host-only: parse an ONNX model (kind 0 = segmentation, 1 = embedding) and write the .sdw pack */
+int sd_convert_onnx(const char* onnx_path, int kind, const char* out_sdw_path);
+const char* sd_convert_error(void);
 const char* sd_last_error(const sd_ctx*);     /* "" when no error */
 const char* sd_create_error(void);            /* reason for the last NULL from sd_create */
 

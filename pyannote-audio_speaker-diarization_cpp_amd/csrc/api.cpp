@@ -27,12 +27,12 @@ extern "C" sd_ctx* sd_create(const char* seg_path, const char* emb_path, int dev
     auto fail = [&](const std::string& m) { g_create_err = m; sd_destroy(c); return (sd_ctx*)nullptr; };
     if (seg_path && seg_path[0]) {
         Pack p; std::string e;
-        if (load_pack(seg_path, p, e)) return fail(e);
+        if (load_model_any(seg_path, 0, p, e)) return fail(e);
         if (build_seg_weights(c, p)) return fail(c->err);
     }
     if (emb_path && emb_path[0]) {
         Pack p; std::string e;
-        if (load_pack(emb_path, p, e)) return fail(e);
+        if (load_model_any(emb_path, 1, p, e)) return fail(e);
         if (build_ecapa_weights(c, p)) return fail(c->err);
     }
     c->err.clear();

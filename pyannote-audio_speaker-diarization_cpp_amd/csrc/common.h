@@ -129,6 +129,7 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& a, const char* tag);
 struct PackTensor { std::vector<int64_t> dims; std::vector<float> data; };
 typedef std::map<std::string, PackTensor> Pack;
 int load_pack(const char* path, Pack& out, std::string& err);
+int load_model_any(const char* path, int kind, Pack& out, std::string& err);   // onnx_reader.cpp: .sdw pack or .onnx (kind 0 seg, 1 emb)
 int build_ecapa_weights(sd_ctx* c, const Pack& p);
 int build_seg_weights(sd_ctx* c, const Pack& p);
 // ---- frontend.hip

@@ -1,0 +1,330 @@
+// onnx_reader.cpp -- minimal ONNX (protobuf) reader for the two model files of the reference
+// CLI: `speakerDiarizer segment.onnx embedding.onnx file.wav` (README.md:39, sd.cpp:3428-3430).
+// Replaces Ort::Session's model parsing (onnx_model.cc:73-104) for exactly the two graphs the
+// reference's exporters produce with torch.onnx.export, opset 17:
+//   segment/export2.py:42-52     input "signal"[B,1,T]           -> "segments"[B,293,3]
+//   embeddings/export3.py:177-189 inputs "feats"[B,T,201,2], "wav_lens"[B] -> "embedding"[B,1,192]
+// No ONNX runtime is involved: the graph is only walked to pull the weights out, in execution
+// order, into the library's weight pack (the kernels implement the architectures directly):
+//   PyanNet : InstanceNormalization x4, Conv x3, LSTM x4 (W/R/B, gate order iofc), MatMul+Add x3
+//   ECAPA   : MatMul with the constant [201,80] mel matrix, Conv x38, BatchNormalization x31
+// Anything else (unexpected op counts, non-constant weights, external data) is reported as
+// SD_ERR_MODEL with the reason; nothing is guessed.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+struct PB {                      // protobuf wire reader over a byte range
+    const uint8_t* p; const uint8_t* e; bool ok = true;
+    PB(const uint8_t* b, size_t n) : p(b), e(b + n) {}
+    bool done() const { return p >= e || !ok; }
+    uint64_t varint() {
+        uint64_t v = 0; int sh = 0;
+        while (p < e) { const uint8_t c = *p++; v |= (uint64_t)(c & 0x7f) << sh; if (!(c & 0x80)) return v; sh += 7; if (sh > 63) break; }
+        ok = false; return 0;
+    }
+    bool tag(int& field, int& wt) { if (done()) return false; const uint64_t t = varint(); field = (int)(t >> 3); wt = (int)(t & 7); return ok; }
+    PB sub() { const uint64_t n = varint(); if (!ok || (uint64_t)(e - p) < n) { ok = false; return PB(p, 0); } PB s(p, (size_t)n); p += n; return s; }
+    void skip(int wt) {
+        if (wt == 0) (void)varint();
+        else if (wt == 1) { if (e - p < 8) ok = false; else p += 8; }
+        else if (wt == 2) (void)sub();
+        else if (wt == 5) { if (e - p < 4) ok = false; else p += 4; }
+        else ok = false;
+    }
+    std::string str() { PB s = sub(); return std::string((const char*)s.p, (size_t)(s.e - s.p)); }
+};
+
+struct OTensor { std::vector<int64_t> dims; int dtype = 0; std::vector<float> f; std::vector<int64_t> i64; bool external = false; std::string name; };
+struct OAttr { std::string name; int64_t i = 0; float f = 0; std::string s; std::vector<int64_t> ints; OTensor t; bool has_t = false; };
+struct ONode { std::string op, name; std::vector<std::string> in, out; std::vector<OAttr> attrs;
+               const OAttr* attr(const char* n) const { for (auto& a : attrs) if (a.name == n) return &a; return nullptr; } };
+struct OGraph { std::vector<ONode> nodes; std::map<std::string, OTensor> init; };
+
+bool parse_tensor(PB pb, OTensor& t)
+{
+    std::string raw;
+    int f, wt;
+    while (pb.tag(f, wt)) {
+        if (f == 1) { if (wt == 2) { PB s = pb.sub(); while (!s.done()) t.dims.push_back((int64_t)s.varint()); } else t.dims.push_back((int64_t)pb.varint()); }
+        else if (f == 2 && wt == 0) t.dtype = (int)pb.varint();
+        else if (f == 4) { if (wt == 2) { PB s = pb.sub(); while (s.e - s.p >= 4) { float v; memcpy(&v, s.p, 4); s.p += 4; t.f.push_back(v); } } else if (wt == 5) { float v; memcpy(&v, pb.p, 4); pb.p += 4; t.f.push_back(v); } else pb.skip(wt); }
+        else if (f == 7) { if (wt == 2) { PB s = pb.sub(); while (!s.done()) t.i64.push_back((int64_t)s.varint()); } else t.i64.push_back((int64_t)pb.varint()); }
+        else if (f == 8 && wt == 2) t.name = pb.str();
+        else if (f == 9 && wt == 2) raw = pb.str();
+        else if (f == 10 && wt == 2) { PB s = pb.sub(); while (s.e - s.p >= 8) { double v; memcpy(&v, s.p, 8); s.p += 8; t.f.push_back((float)v); } }
+        else if (f == 13 || f == 14) { t.external = true; pb.skip(wt); }
+        else pb.skip(wt);
+    }
+    if (!pb.ok) return false;
+    if (!raw.empty()) {
+        if (t.dtype == 1) { t.f.resize(raw.size() / 4); memcpy(t.f.data(), raw.data(), t.f.size() * 4); }
+        else if (t.dtype == 11) { const size_t n = raw.size() / 8; t.f.resize(n); for (size_t k = 0; k < n; ++k) { double v; memcpy(&v, raw.data() + 8 * k, 8); t.f[k] = (float)v; } }
+        else if (t.dtype == 7) { t.i64.resize(raw.size() / 8); memcpy(t.i64.data(), raw.data(), t.i64.size() * 8); }
+        else if (t.dtype == 6) { const size_t n = raw.size() / 4; t.i64.resize(n); for (size_t k = 0; k < n; ++k) { int32_t v; memcpy(&v, raw.data() + 4 * k, 4); t.i64[k] = v; } }
+    }
+    return true;
+}
+
+bool parse_attr(PB pb, OAttr& a)
+{
+    int f, wt;
+    while (pb.tag(f, wt)) {
+        if (f == 1 && wt == 2) a.name = pb.str();
+        else if (f == 2 && wt == 5) { memcpy(&a.f, pb.p, 4); pb.p += 4; }
+        else if (f == 3 && wt == 0) a.i = (int64_t)pb.varint();
+        else if (f == 4 && wt == 2) a.s = pb.str();
+        else if (f == 5 && wt == 2) { a.has_t = true; if (!parse_tensor(pb.sub(), a.t)) return false; }
+        else if (f == 8) { if (wt == 2) { PB s = pb.sub(); while (!s.done()) a.ints.push_back((int64_t)s.varint()); } else a.ints.push_back((int64_t)pb.varint()); }
+        else pb.skip(wt);
+    }
+    return pb.ok;
+}
+
+bool parse_node(PB pb, ONode& n)
+{
+    int f, wt;
+    while (pb.tag(f, wt)) {
+        if (f == 1 && wt == 2) n.in.push_back(pb.str());
+        else if (f == 2 && wt == 2) n.out.push_back(pb.str());
+        else if (f == 3 && wt == 2) n.name = pb.str();
+        else if (f == 4 && wt == 2) n.op = pb.str();
+        else if (f == 5 && wt == 2) { OAttr a; if (!parse_attr(pb.sub(), a)) return false; n.attrs.push_back(std::move(a)); }
+        else pb.skip(wt);
+    }
+    return pb.ok;
+}
+
+bool parse_graph(PB pb, OGraph& g)
+{
+    int f, wt;
+    while (pb.tag(f, wt)) {
+        if (f == 1 && wt == 2) { ONode n; if (!parse_node(pb.sub(), n)) return false; g.nodes.push_back(std::move(n)); }
+        else if (f == 5 && wt == 2) { OTensor t; if (!parse_tensor(pb.sub(), t)) return false; g.init[t.name] = std::move(t); }
+        else pb.skip(wt);
+    }
+    // Constant nodes act as initializers under their output name
+    for (auto& n : g.nodes)
+        if (n.op == "Constant" && !n.out.empty()) { const OAttr* a = n.attr("value"); if (a && a->has_t) { OTensor t = a->t; t.name = n.out[0]; g.init[n.out[0]] = std::move(t); } }
+    return pb.ok;
+}
+
+int load_onnx(const char* path, OGraph& g, std::string& err)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) { err = std::string("cannot open model file: ") + path; return SD_ERR_MODEL; }
+    fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> buf((size_t)(sz > 0 ? sz : 0));
+    if (sz <= 0 || fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); err = std::string("cannot read model file: ") + path; return SD_ERR_MODEL; }
+    fclose(f);
+    PB pb(buf.data(), buf.size());
+    int fld, wt; bool got = false;
+    while (pb.tag(fld, wt)) {
+        if (fld == 7 && wt == 2) { if (!parse_graph(pb.sub(), g)) { err = std::string("malformed ONNX graph in ") + path; return SD_ERR_MODEL; } got = true; }
+        else pb.skip(wt);
+    }
+    if (!pb.ok || !got) { err = std::string("not an ONNX ModelProto: ") + path; return SD_ERR_MODEL; }
+    return SD_OK;
+}
+
+const OTensor* weight_of(const OGraph& g, const std::string& name, std::string& err, const char* what)
+{
+    auto it = g.init.find(name);
+    if (it == g.init.end()) { err = std::string(what) + ": input '" + name + "' is not a constant (weights must be initializers / folded constants)"; return nullptr; }
+    if (it->second.external) { err = std::string(what) + ": external tensor data is not supported"; return nullptr; }
+    if (it->second.f.empty()) { err = std::string(what) + ": tensor '" + name + "' holds no float data"; return nullptr; }
+    return &it->second;
+}
+
+void put(Pack& p, const std::string& name, const std::vector<int64_t>& dims, const std::vector<float>& data)
+{
+    PackTensor t; t.dims = dims; t.data = data; p[name] = std::move(t);
+}
+
+// ---- PyanNet (segment2.onnx)
+int seg_from_onnx(const OGraph& g, Pack& p, std::string& err)
+{
+    std::vector<const ONode*> inorm, conv, lstm, mm;
+    for (auto& n : g.nodes) {
+        if (n.op == "InstanceNormalization") inorm.push_back(&n);
+        else if (n.op == "Conv") conv.push_back(&n);
+        else if (n.op == "LSTM") lstm.push_back(&n);
+        else if (n.op == "MatMul" || n.op == "Gemm") mm.push_back(&n);
+    }
+    if (inorm.size() != 4 || conv.size() != 3 || lstm.size() != 4 || mm.size() != 3) {
+        char b[256]; snprintf(b, sizeof(b), "segmentation graph: expected 4 InstanceNormalization / 3 Conv / 4 LSTM / 3 MatMul, found %zu / %zu / %zu / %zu",
+                              inorm.size(), conv.size(), lstm.size(), mm.size());
+        err = b; return SD_ERR_MODEL;
+    }
+    const char* inn[4] = {"sincnet.wav_norm", "sincnet.norm0", "sincnet.norm1", "sincnet.norm2"};
+    for (int i = 0; i < 4; ++i) {
+        const OTensor *s = weight_of(g, inorm[i]->in[1], err, "InstanceNormalization scale"), *b = weight_of(g, inorm[i]->in[2], err, "InstanceNormalization bias");
+        if (!s || !b) return SD_ERR_MODEL;
+        put(p, std::string(inn[i]) + ".weight", {(int64_t)s->f.size()}, s->f);
+        put(p, std::string(inn[i]) + ".bias", {(int64_t)b->f.size()}, b->f);
+    }
+    for (int i = 0; i < 3; ++i) {
+        const OTensor* w = weight_of(g, conv[i]->in[1], err, "Conv weight");
+        if (!w || w->dims.size() != 3) { if (w) err = "Conv weight is not 3-D"; return SD_ERR_MODEL; }
+        put(p, "sincnet.conv" + std::to_string(i) + ".weight", w->dims, w->f);
+        if (conv[i]->in.size() > 2 && !conv[i]->in[2].empty()) {
+            const OTensor* b = weight_of(g, conv[i]->in[2], err, "Conv bias");
+            if (!b) return SD_ERR_MODEL;
+            put(p, "sincnet.conv" + std::to_string(i) + ".bias", {(int64_t)b->f.size()}, b->f);
+        } else if (i > 0) put(p, "sincnet.conv" + std::to_string(i) + ".bias", {w->dims[0]}, std::vector<float>((size_t)w->dims[0], 0.0f));
+    }
+    // LSTM: W [2][4H][in], R [2][4H][H], B [2][8H]; ONNX gate order i,o,f,c -> PyTorch i,f,g,o
+    for (int l = 0; l < 4; ++l) {
+        const ONode& n = *lstm[l];
+        if (n.in.size() < 4) { err = "LSTM node without W/R/B"; return SD_ERR_MODEL; }
+        const OTensor *W = weight_of(g, n.in[1], err, "LSTM W"), *R = weight_of(g, n.in[2], err, "LSTM R"), *B = weight_of(g, n.in[3], err, "LSTM B");
+        if (!W || !R || !B) return SD_ERR_MODEL;
+        if (W->dims.size() != 3 || W->dims[0] != 2 || R->dims.size() != 3 || R->dims[0] != 2) { err = "LSTM is not bidirectional [2,4H,*]"; return SD_ERR_MODEL; }
+        const int64_t H4 = W->dims[1], H = H4 / 4, nin = W->dims[2];
+        if (R->dims[1] != H4 || R->dims[2] != H || (int64_t)B->f.size() != 2 * 2 * H4) { err = "LSTM W/R/B shapes disagree"; return SD_ERR_MODEL; }
+        const int src_of_dst[4] = {0, 2, 3, 1};        // pytorch gate k (i,f,g,o) <- onnx gate (i,o,f,c) index
+        for (int d = 0; d < 2; ++d) {
+            std::vector<float> wih((size_t)H4 * nin), whh((size_t)H4 * H), bih((size_t)H4), bhh((size_t)H4);
+            for (int k = 0; k < 4; ++k)
+                for (int64_t r = 0; r < H; ++r) {
+                    const int64_t dst = k * H + r, src = src_of_dst[k] * H + r;
+                    memcpy(&wih[(size_t)dst * nin], &W->f[((size_t)d * H4 + src) * nin], (size_t)nin * 4);
+                    memcpy(&whh[(size_t)dst * H], &R->f[((size_t)d * H4 + src) * H], (size_t)H * 4);
+                    bih[(size_t)dst] = B->f[(size_t)d * 2 * H4 + src];
+                    bhh[(size_t)dst] = B->f[(size_t)d * 2 * H4 + H4 + src];
+                }
+            const std::string sfx = "_l" + std::to_string(l) + (d ? "_reverse" : "");
+            put(p, "lstm.weight_ih" + sfx, {H4, nin}, wih);
+            put(p, "lstm.weight_hh" + sfx, {H4, H}, whh);
+            put(p, "lstm.bias_ih" + sfx, {H4}, bih);
+            put(p, "lstm.bias_hh" + sfx, {H4}, bhh);
+        }
+    }
+    // Linear layers: MatMul(x, W^T [in,out]) followed by Add(bias); Gemm carries both
+    const char* ln[3] = {"linear.0", "linear.1", "classifier"};
+    for (int i = 0; i < 3; ++i) {
+        const ONode& n = *mm[i];
+        const OTensor* w = nullptr; bool transposed = true;        // MatMul constant is [in,out]
+        for (size_t k = 0; k < n.in.size() && k < 2; ++k) { auto it = g.init.find(n.in[k]); if (it != g.init.end() && it->second.dims.size() == 2) w = &it->second; }
+        if (!w || w->f.empty()) { err = "linear layer weight is not a constant 2-D tensor"; return SD_ERR_MODEL; }
+        if (n.op == "Gemm") { const OAttr* tb = n.attr("transB"); transposed = !(tb && tb->i == 1); }
+        const int64_t d0 = w->dims[0], d1 = w->dims[1];
+        const int64_t out = transposed ? d1 : d0, in = transposed ? d0 : d1;
+        std::vector<float> wt((size_t)out * in);
+        for (int64_t o = 0; o < out; ++o) for (int64_t q = 0; q < in; ++q) wt[(size_t)o * in + q] = transposed ? w->f[(size_t)q * d1 + o] : w->f[(size_t)o * d1 + q];
+        put(p, std::string(ln[i]) + ".weight", {out, in}, wt);
+        const OTensor* b = nullptr;
+        if (n.op == "Gemm" && n.in.size() > 2) b = weight_of(g, n.in[2], err, "Gemm bias");
+        else {
+            for (auto& a : g.nodes) {          // the Add consuming this MatMul's output
+                if (a.op != "Add" || a.in.size() != 2) continue;
+                for (int k = 0; k < 2; ++k) if (a.in[k] == n.out[0]) { auto it = g.init.find(a.in[1 - k]); if (it != g.init.end()) b = &it->second; }
+            }
+        }
+        if (!b || (int64_t)b->f.size() != out) { err = "linear layer bias not found"; return SD_ERR_MODEL; }
+        put(p, std::string(ln[i]) + ".bias", {out}, b->f);
+    }
+    return SD_OK;
+}
+
+// ---- ECAPA-TDNN front end + body (emd4.onnx)
+int emb_from_onnx(const OGraph& g, Pack& p, std::string& err)
+{
+    std::vector<const ONode*> conv, bn;
+    const OTensor* mel = nullptr;
+    for (auto& n : g.nodes) {
+        if (n.op == "Conv") conv.push_back(&n);
+        else if (n.op == "BatchNormalization") bn.push_back(&n);
+        else if (n.op == "MatMul" && !mel)
+            for (auto& nm : n.in) { auto it = g.init.find(nm); if (it != g.init.end() && it->second.dims.size() == 2 && it->second.dims[0] == SD_NBINS && it->second.dims[1] == SD_NMELS) mel = &it->second; }
+    }
+    if (!mel) { err = "embedding graph: no MatMul with a constant [201,80] mel filterbank"; return SD_ERR_MODEL; }
+    if (conv.size() != 38 || bn.size() != 31) {
+        char b[200]; snprintf(b, sizeof(b), "embedding graph: expected 38 Conv / 31 BatchNormalization (ECAPA-TDNN C=1024), found %zu / %zu", conv.size(), bn.size());
+        err = b; return SD_ERR_MODEL;
+    }
+    put(p, "fbank.matrix", mel->dims, mel->f);
+    std::vector<std::string> cn, bnn;
+    cn.push_back("blocks.0.conv"); bnn.push_back("blocks.0.norm");
+    for (int b = 1; b <= 3; ++b) {
+        const std::string pre = "blocks." + std::to_string(b);
+        cn.push_back(pre + ".tdnn1.conv"); bnn.push_back(pre + ".tdnn1.norm");
+        for (int i = 0; i < 7; ++i) { cn.push_back(pre + ".res2net." + std::to_string(i) + ".conv"); bnn.push_back(pre + ".res2net." + std::to_string(i) + ".norm"); }
+        cn.push_back(pre + ".tdnn2.conv"); bnn.push_back(pre + ".tdnn2.norm");
+        cn.push_back(pre + ".se.conv1"); cn.push_back(pre + ".se.conv2");
+    }
+    cn.push_back("mfa.conv"); bnn.push_back("mfa.norm");
+    cn.push_back("asp.tdnn.conv"); bnn.push_back("asp.tdnn.norm");
+    cn.push_back("asp.conv"); bnn.push_back("asp_bn");
+    cn.push_back("fc");
+    for (size_t i = 0; i < conv.size(); ++i) {
+        const OTensor* w = weight_of(g, conv[i]->in[1], err, "Conv weight");
+        if (!w || w->dims.size() != 3) { if (w) err = "Conv weight is not 3-D"; return SD_ERR_MODEL; }
+        put(p, cn[i] + ".weight", w->dims, w->f);
+        std::vector<float> bias((size_t)w->dims[0], 0.0f);
+        if (conv[i]->in.size() > 2 && !conv[i]->in[2].empty()) { const OTensor* b = weight_of(g, conv[i]->in[2], err, "Conv bias"); if (!b) return SD_ERR_MODEL; bias = b->f; }
+        put(p, cn[i] + ".bias", {w->dims[0]}, bias);
+    }
+    for (size_t i = 0; i < bn.size(); ++i) {
+        if (bn[i]->in.size() < 5) { err = "BatchNormalization without 5 inputs"; return SD_ERR_MODEL; }
+        const char* part[4] = {".weight", ".bias", ".running_mean", ".running_var"};
+        for (int k = 0; k < 4; ++k) {
+            const OTensor* t = weight_of(g, bn[i]->in[1 + k], err, "BatchNormalization parameter");
+            if (!t) return SD_ERR_MODEL;
+            put(p, bnn[i] + part[k], {(int64_t)t->f.size()}, t->f);
+        }
+        const OAttr* eps = bn[i]->attr("epsilon");
+        if (eps && fabsf(eps->f - 1e-5f) > 1e-9f) { err = "BatchNormalization epsilon != 1e-5"; return SD_ERR_MODEL; }
+    }
+    // shape sanity for the architecture the kernels implement
+    if (p["blocks.0.conv.weight"].dims[1] != SD_NMELS || p["fc.weight"].dims[0] != SD_EMB_DIM) { err = "embedding graph: unexpected block0 / fc shapes"; return SD_ERR_MODEL; }
+    return SD_OK;
+}
+
+int save_pack(const char* path, const Pack& p, std::string& err)
+{
+    FILE* f = fopen(path, "wb");
+    if (!f) { err = std::string("cannot write ") + path; return SD_ERR_ARG; }
+    const uint32_t cnt = (uint32_t)p.size();
+    fwrite("SDW1", 1, 4, f); fwrite(&cnt, 4, 1, f);
+    for (auto& kv : p) {
+        const uint16_t nl = (uint16_t)kv.first.size(); const uint8_t nd = (uint8_t)kv.second.dims.size();
+        fwrite(&nl, 2, 1, f); fwrite(kv.first.data(), 1, nl, f); fwrite(&nd, 1, 1, f);
+        if (nd) fwrite(kv.second.dims.data(), 8, nd, f);
+        if (!kv.second.data.empty()) fwrite(kv.second.data.data(), 4, kv.second.data.size(), f);
+    }
+    fclose(f);
+    return SD_OK;
+}
+
+}  // namespace
+
+// kind: 0 = segmentation (PyanNet), 1 = embedding (ECAPA-TDNN)
+int load_model_any(const char* path, int kind, Pack& out, std::string& err)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) { err = std::string("cannot open model file: ") + path; return SD_ERR_MODEL; }
+    char magic[4] = {0, 0, 0, 0};
+    const size_t got = fread(magic, 1, 4, f);
+    fclose(f);
+    if (got == 4 && memcmp(magic, "SDW1", 4) == 0) return load_pack(path, out, err);
+    OGraph g;
+    int rc = load_onnx(path, g, err);
+    if (rc) return rc;
+    rc = kind == 0 ? seg_from_onnx(g, out, err) : emb_from_onnx(g, out, err);
+    if (rc) err = std::string(path) + ": " + err;
+    return rc;
+}
+
+static std::string g_convert_err;
+extern "C" const char* sd_convert_error(void) { return g_convert_err.c_str(); }
+extern "C" int sd_convert_onnx(const char* onnx_path, int kind, const char* out_sdw_path)
+{
+    g_convert_err.clear();
+    if (!onnx_path || !out_sdw_path || (kind != 0 && kind != 1)) { g_convert_err = "bad argument"; return SD_ERR_ARG; }
+    Pack p;
+    int rc = load_model_any(onnx_path, kind, p, g_convert_err);
+    if (rc) return rc;
+    return save_pack(out_sdw_path, p, g_convert_err);
+}

@@ -134,8 +134,9 @@ int build_ecapa_weights(sd_ctx* c, const Pack& p)
     std::vector<float> win(400);
     auto itw = p.find("stft.window");
     for (int n = 0; n < 400; ++n)
+        // torch::hamming_window (periodic) evaluates arange * float(2 pi / N) -> cos -> * -0.46 -> + 0.54 in float32
         win[n] = (itw != p.end() && itw->second.data.size() == 400) ? itw->second.data[n]
-                                                                      : (float)(0.54 - 0.46 * cos(2.0 * M_PI * n / 400.0));
+                                                                      : cosf((float)n * (float)(2.0 * M_PI / 400.0)) * (-0.46f) + 0.54f;
     E.window = upload(c, win);
     std::vector<double> tc(400), ts(400);
     for (int k = 0; k < 400; ++k) { tc[k] = cos(2.0 * M_PI * k / 400.0); ts[k] = -sin(2.0 * M_PI * k / 400.0); }

@@ -34,7 +34,7 @@ EXPORTS = [
     "sd_postseg", "sd_count_frames", "sd_embed", "sd_embed_dev", "sd_frontend", "sd_ecapa", "sd_linkage", "sd_cluster",
     "sd_clustering", "sd_reconstruct", "sd_diarize", "sd_diarize_dev", "sd_free_turns", "sd_shard_infer_dev",
     "sd_finalize_dev", "sd_read_wav", "sd_free_pcm", "sd_format_turn", "sd_stage_ms", "sd_kernel_stats",
-    "sd_reset_stats", "sd_set_option", "sd_bench_conv", "sd_bench_barrier",
+    "sd_reset_stats", "sd_set_option", "sd_bench_conv", "sd_bench_barrier", "sd_convert_onnx", "sd_convert_error",
 ]
 
 
@@ -80,6 +80,8 @@ def lib():
     L.sd_kernel_stats.argtypes = [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
     L.sd_reset_stats.argtypes = [vp]
     L.sd_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.sd_convert_onnx.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+    L.sd_convert_error.restype = C.c_char_p
     L.sd_bench_barrier.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(dbl)]
     L.sd_bench_conv.argtypes = [vp, i64] + [C.c_int] * 9 + [C.POINTER(dbl)]
     _lib = L
@@ -110,6 +112,13 @@ def shard_sample_range(lo, hi, n_total):
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def convert_onnx(onnx_path, kind, out_path):
+    """kind: 'segmentation' | 'embedding'.  Host-only (no GPU needed)."""
+    rc = lib().sd_convert_onnx(onnx_path.encode(), 0 if kind.startswith('seg') else 1, out_path.encode())
+    if rc:
+        raise SdError(rc, lib().sd_convert_error().decode())
 
 
 def format_turn(t):
