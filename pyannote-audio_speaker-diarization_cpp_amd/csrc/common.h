@@ -93,7 +93,7 @@ struct sd_ctx {
     std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t, double, double>> pending;
     double stage_ms[4] = {0, 0, 0, 0};
     int64_t emb_batch_items = 768;             // multiple of 96
-    int64_t seg_batch_chunks = 512;
+    int64_t seg_batch_chunks = 4096;           // 128 LSTM workgroups per direction: one full wave of CUs
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
     int num_cu = 256;
 };

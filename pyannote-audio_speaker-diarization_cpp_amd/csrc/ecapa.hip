@@ -52,22 +52,30 @@ __global__ void k_copy_slice(const float* __restrict__ src, int src_ld, float* _
 }
 
 // ASP global-context statistics: mean / std over valid frames -> ms[item][2C]
+// one pass (Welford) with 4 rows in flight per thread: the tensor is read once
 __global__ void k_asp_stats(const float* __restrict__ x, int ld, const int* __restrict__ nvalid, float* __restrict__ ms, int C)
 {
     const int item = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= C) return;
     const int nv = nvalid[item];
     const float* p = x + (size_t)item * SD_TP * ld + ch;
-    const float inv = 1.0f / (float)nv;
-    float s = 0;
-    for (int t = 0; t < nv; ++t) s += p[(size_t)t * ld] * inv;
-    float v = 0;
-    for (int t = 0; t < nv; ++t) { const float d = p[(size_t)t * ld] - s; v += inv * d * d; }
-    ms[(size_t)item * 2 * C + ch] = s;
-    ms[(size_t)item * 2 * C + C + ch] = sqrtf(fmaxf(v, 1e-12f));
+    float mean = 0.0f, m2 = 0.0f;
+    int t = 0;
+    for (; t + 3 < nv; t += 4) {
+        const float v0 = p[(size_t)t * ld], v1 = p[(size_t)(t + 1) * ld], v2 = p[(size_t)(t + 2) * ld], v3 = p[(size_t)(t + 3) * ld];
+        float d;
+        d = v0 - mean; mean += d / (float)(t + 1); m2 += d * (v0 - mean);
+        d = v1 - mean; mean += d / (float)(t + 2); m2 += d * (v1 - mean);
+        d = v2 - mean; mean += d / (float)(t + 3); m2 += d * (v2 - mean);
+        d = v3 - mean; mean += d / (float)(t + 4); m2 += d * (v3 - mean);
+    }
+    for (; t < nv; ++t) { const float v = p[(size_t)t * ld]; const float d = v - mean; mean += d / (float)(t + 1); m2 += d * (v - mean); }
+    ms[(size_t)item * 2 * C + ch] = mean;
+    ms[(size_t)item * 2 * C + C + ch] = sqrtf(fmaxf(m2 / (float)nv, 1e-12f));
 }
 
-// attentive statistics pooling: masked softmax over time of the logits, weighted mean/std of x
+// attentive statistics pooling: masked softmax over time of the logits, weighted mean/std of x.
+// One pass over both tensors: online softmax (running max, rescaled weights) + weighted Welford update.
 __global__ void k_asp_pool(const float* __restrict__ x, const float* __restrict__ logit, int ld, const int* __restrict__ nvalid,
                            float* __restrict__ pooled, int C)
 {
@@ -76,15 +84,24 @@ __global__ void k_asp_pool(const float* __restrict__ x, const float* __restrict_
     const int nv = nvalid[item];
     const float* px = x + (size_t)item * SD_TP * ld + ch;
     const float* pl = logit + (size_t)item * SD_TP * ld + ch;
-    float mx = -INFINITY;
-    for (int t = 0; t < nv; ++t) mx = fmaxf(mx, pl[(size_t)t * ld]);
-    float z = 0, s1 = 0;
-    for (int t = 0; t < nv; ++t) { const float e = expf(pl[(size_t)t * ld] - mx); z += e; s1 += e * px[(size_t)t * ld]; }
-    const float mean = s1 / z;
-    float s2 = 0;
-    for (int t = 0; t < nv; ++t) { const float e = expf(pl[(size_t)t * ld] - mx); const float d = px[(size_t)t * ld] - mean; s2 += e * d * d; }
+    float mx = -INFINITY, W = 0.0f, mean = 0.0f, m2 = 0.0f;
+    auto step = [&](float l, float v) {
+        if (l > mx) { const float s = expf(mx - l); W *= s; m2 *= s; mx = l; }      // expf(-inf) = 0 on the first frame
+        const float w = expf(l - mx);
+        W += w;
+        const float d = v - mean;
+        mean += (w / W) * d;
+        m2 += w * d * (v - mean);
+    };
+    int t = 0;
+    for (; t + 3 < nv; t += 4) {
+        const float l0 = pl[(size_t)t * ld], l1 = pl[(size_t)(t + 1) * ld], l2 = pl[(size_t)(t + 2) * ld], l3 = pl[(size_t)(t + 3) * ld];
+        const float v0 = px[(size_t)t * ld], v1 = px[(size_t)(t + 1) * ld], v2 = px[(size_t)(t + 2) * ld], v3 = px[(size_t)(t + 3) * ld];
+        step(l0, v0); step(l1, v1); step(l2, v2); step(l3, v3);
+    }
+    for (; t < nv; ++t) step(pl[(size_t)t * ld], px[(size_t)t * ld]);
     pooled[(size_t)item * 2 * C + ch] = mean;
-    pooled[(size_t)item * 2 * C + C + ch] = sqrtf(fmaxf(s2 / z, 1e-12f));
+    pooled[(size_t)item * 2 * C + C + ch] = sqrtf(fmaxf(m2 / W, 1e-12f));
 }
 
 // rows flagged too-short become NaN (sd.cpp:2541-2549)
@@ -170,7 +187,7 @@ int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d
     { ConvArgs a = conv_args(E.mfa, cat, C3, mfa, C3, M, true); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
     // ASP with global context: cat[x, mean, std] @ W == x @ Wx + (mean,std) @ Wms  (per-item bias)
     {
-        ProfScope ps(c, "asp_stats", 0, (double)items * SD_T * C3 * 8.0);
+        ProfScope ps(c, "asp_stats", 0, (double)items * SD_T * C3 * 4.0);
         hipLaunchKernelGGL(k_asp_stats, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, C3, d_nvalid, ms, C3);
         KCHECK(c);
     }
@@ -179,7 +196,7 @@ int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d
     float* logits = cat;   // cat is dead after mfa
     { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, M, true); if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
     {
-        ProfScope ps(c, "asp_pool", 0, (double)items * SD_T * C3 * 8.0 * 2.0);
+        ProfScope ps(c, "asp_pool", 0, (double)items * SD_T * C3 * 8.0);
         hipLaunchKernelGGL(k_asp_pool, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, C3, d_nvalid, pooled, C3);
         KCHECK(c);
     }

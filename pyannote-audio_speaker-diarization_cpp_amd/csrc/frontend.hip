@@ -10,8 +10,9 @@
 //   k_wav_lens    : per reference batch of 32 items: max_len, wav_len, too-short flags
 //   k_stft_mel    : per (item, 64-frame tile): gather the compacted samples into LDS
 //                   (inverse of the compaction via the prefix table), 400-point real
-//                   DFT as fp64 MFMA (v_mfma_f64_16x16x4_f64, twiddles from a 400-entry
-//                   LDS table), power in fp32, sparse mel, dB, per-item max (atomic)
+//                   DFT as fp64 MFMA (v_mfma_f64_16x16x4_f64, even/odd folded to K = 204,
+//                   twiddles from a 400-entry LDS table), power in fp32, sparse mel, dB,
+//                   per-item max (atomic)
 //   k_fbank_norm  : top-dB clamp, mean over the first round(len*501) frames, subtract,
 //                   write channels-last [512][96] zero-padded rows for the MFMA convs
 #include "common.h"
@@ -103,14 +104,25 @@ __device__ __forceinline__ void dft_tiles(const float* sig, const float* win, co
         idx[b] = (kq * j) % 400;
         inc[b] = (4 * j) % 400;
     }
-    for (int s = 0; s < 100; ++s) {
+    // Real-input symmetry halves the contraction: with xw[n] = x[n] w[n],
+    //   Re X[k] =  sum_{n=0..200} e[n] cos(2 pi k n / 400),  e[n] = xw[n] + xw[400-n]  (e[0] = xw[0], e[200] = xw[200])
+    //   Im X[k] = -sum_{n=1..199} o[n] sin(2 pi k n / 400),  o[n] = xw[n] - xw[400-n]
+    // 51 K-steps of 4 instead of 100 (indices 201..203 contribute zeros).
+    for (int s = 0; s < 51; ++s) {
         const int nn = 4 * s + kq;
-        const double a = (double)sig[sbase + nn + 2 * (nn / 160)] * (double)win[nn];
+        const int nc = nn <= 200 ? nn : 200;
+        const int nm = 400 - nc;                               // mirror index (400 for nc == 0: not used)
+        const double a0 = (double)sig[sbase + nc + 2 * (nc / 160)] * (double)win[nc];
+        const int nmc = nm < 400 ? nm : 399;
+        const double a1 = (double)sig[sbase + nmc + 2 * (nmc / 160)] * (double)win[nmc];
+        const bool mid = (nn >= 1) && (nn <= 199);
+        const double e = (nn > 200) ? 0.0 : (mid ? a0 + a1 : a0);
+        const double o = mid ? a0 - a1 : 0.0;
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
             const double cv = tc[idx[b]], sv = ts[idx[b]];
-            re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, cv, re[b], 0, 0, 0);
-            im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sv, im[b], 0, 0, 0);
+            re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(e, cv, re[b], 0, 0, 0);
+            im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(o, sv, im[b], 0, 0, 0);
             idx[b] += inc[b];
             if (idx[b] >= 400) idx[b] -= 400;
         }
@@ -250,7 +262,7 @@ int run_frontend(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks,
     KCHECK(c);
     {
         // algorithmic bytes per item: 80000*4 + 293*4 read, 501*80*4 written
-        ProfScope ps(c, "stft_mel", (double)items * (SD_TP * 208.0 * 400 * 2 * 2 + SD_T * 201.0 * 80 * 2), (double)items * (321172.0 + 160320.0));
+        ProfScope ps(c, "stft_mel", (double)items * (SD_TP * 208.0 * 204 * 2 * 2 + SD_T * 201.0 * 80 * 2), (double)items * (321172.0 + 160320.0));
         hipLaunchKernelGGL(k_stft_mel, dim3((SD_T + FT - 1) / FT, (unsigned)items), dim3(256), 0, c->stream, d_wav, n, d_prefix, d_counts,
                            first_item, E.window, E.tw_cos, E.tw_nsin, E.mel_w, E.mel_lo, E.mel_cnt, E.mel_off, E.mel_nnz, d_db, d_max);
         KCHECK(c);

@@ -31,4 +31,5 @@ for G in (0, 32, 64):
     st = d.kernel_stats("linkage")
     if Z0 is None: Z0 = Z
     rr = d.kernel_stats("linkage_retry_rounds")["flops"]
+    print("   flag-conservative exits:", d.kernel_stats("linkage_flag_conservative")["flops"])
     print("N=%d G=%3d linkage kernel %.1f ms (%.2f us/merge) wall %.2f s  same-as-G0 %s retry_rounds %d" % (N, G, st["ms"], st["ms"] * 1e3 / (N - 1), t1, np.array_equal(Z, Z0), rr), flush=True)
