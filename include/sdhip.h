@@ -97,6 +97,10 @@ int sd_cluster(sd_ctx*, const double* h_X, int64_t N, int d, double cutoff, int3
 /* ---- a10+a11+a14: Cluster::clustering (sd.cpp:2063-2116): emb [chunks][3][d]
  * f64 with NaN rows -> hard clusters i32 [chunks][3]; *n_clusters = K */
 int sd_clustering(sd_ctx*, const double* h_emb, int64_t chunks, int d, int32_t* h_hard, int32_t* n_clusters);
+/* same with the num_clusters / min_clusters / max_clusters constraints (-1 = unset) that the reference leaves
+ * unimplemented (assert(false), sd.cpp:2368-2369); semantics of clustering/Clustering.py:21-43, 352-399 */
+int sd_clustering_ex(sd_ctx*, const double* h_emb, int64_t chunks, int d, int num_clusters, int min_clusters,
+                     int max_clusters, int32_t* h_hard, int32_t* n_clusters);
 
 /* ---- a15-a17: inactive mask, reconstruct, to_diarization, to_annotation
  * (sd.cpp:3172-3191, 2789-2848, 2638-2764, 2852-2935).  Returns malloc'd turns
@@ -128,6 +132,13 @@ int sd_finalize_dev(sd_ctx*, const float* d_seg, const float* d_emb, int64_t chu
  * interleaved-as-mono exactly like the reference (wav.h:95-97). */
 int sd_read_wav(const char* path, int16_t** pcm, int64_t* n, int32_t* sample_rate, int32_t* channels);
 void sd_free_pcm(int16_t*);
+/* every bit depth WavReader reads (8 / 16 / 32, wav.h:99-122), as float samples already divided by 32768
+ * (sd.cpp:2948-2951); free with sd_free_wav.  sd_diarize_f32 is sd_diarize for such samples. */
+int sd_read_wav_f32(const char* path, float** wav, int64_t* n, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample);
+void sd_free_wav(float*);
+int sd_diarize_f32(sd_ctx*, const float* h_wav, int64_t n, sd_turn** turns, int64_t* n_turns);
+/* RTTM file of the turns ("SPEAKER <uri> 1 <start> <dur> <NA> <NA> SPEAKER_kk <NA> <NA>"), SURVEY 8f-4 */
+int sd_write_rttm(const char* path, const char* uri, const sd_turn* turns, int64_t n_turns);
 
 /* ---- a18: the reference's output line (sd.cpp:3439) */
 int sd_format_turn(const sd_turn* t, char* buf, int cap);
@@ -142,7 +153,7 @@ void sd_reset_stats(sd_ctx*);
 int sd_set_option(sd_ctx*, const char* key, int64_t value);
 /* tuning hook (tools/tune_conv.py): time one conv_gemm shape on scratch data; dbg selects an ablation */
 int sd_bench_barrier(sd_ctx*, int workgroups, int iters, int dirty_doubles, double* us_per_barrier);
-int sd_bench_conv(sd_ctx*, int64_t items, int Tp, int T, int Cin, int Cout, int KT, int dil, int has_x2, int dbg, int reps, double* ms_per_launch);   /* "emb_batch_items", "seg_batch_chunks", "profile" */
+int sd_bench_conv(sd_ctx*, int64_t items, int Tp, int T, int Cin, int Cout, int KT, int dil, int has_x2, int dbg, int reps, double* ms_per_launch);   /* "emb_batch_items", "seg_batch_chunks", "profile", "linkage_wgs", "num_clusters", "min_clusters", "max_clusters" */
 
 #ifdef __cplusplus
 }

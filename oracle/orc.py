@@ -58,6 +58,10 @@ def lib():
     L.orc_cluster_embeddings.argtypes = [c_dp, C.c_long, C.c_int, C.c_float, C.c_long, c_ip]
     L.orc_clustering.restype = C.c_int
     L.orc_clustering.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, C.c_float, C.c_long, c_ip, C.c_void_p, C.POINTER(C.c_long)]
+    L.orc_clustering_ex.restype = C.c_int
+    L.orc_clustering_ex.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, C.c_float, C.c_long, C.c_int, C.c_int, C.c_int, c_ip, C.c_void_p, C.POINTER(C.c_long)]
+    L.orc_cluster_embeddings_ex.restype = C.c_int
+    L.orc_cluster_embeddings_ex.argtypes = [c_dp, C.c_long, C.c_int, C.c_float, C.c_long, C.c_int, C.c_int, C.c_int, c_ip]
     L.orc_mark_inactive.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, c_ip]
     L.orc_reconstruct.restype = C.c_long
     L.orc_reconstruct.argtypes = [c_fp, C.c_long, C.c_int, C.c_int, c_ip, c_ip, C.c_long, c_dp, C.c_long,
@@ -224,15 +228,24 @@ def cluster_embeddings(X, threshold=THRESH_F32, min_cluster_size=MIN_CLUSTER_SIZ
     return lab, K
 
 
-def clustering(emb, threshold=THRESH_F32, min_cluster_size=MIN_CLUSTER_SIZE):
+def clustering(emb, threshold=THRESH_F32, min_cluster_size=MIN_CLUSTER_SIZE, num_clusters=-1, min_clusters=-1, max_clusters=-1):
     """emb [c][S][d] float64 with NaN rows -> hard [c][S], K, train_labels"""
     emb = np.ascontiguousarray(emb, np.float64)
     c, S, d = emb.shape
     hard = np.zeros((c, S), np.int32)
     tl = np.zeros(c * S, np.int32)
     nt = C.c_long(0)
-    K = lib().orc_clustering(emb, c, S, d, threshold, min_cluster_size, hard, tl.ctypes.data, C.byref(nt))
+    K = lib().orc_clustering_ex(emb, c, S, d, threshold, min_cluster_size, num_clusters, min_clusters, max_clusters,
+                                hard, tl.ctypes.data, C.byref(nt))
     return hard, K, tl[:nt.value].copy()
+
+
+def cluster_embeddings_ex(X, num_clusters=-1, min_clusters=-1, max_clusters=-1, threshold=THRESH_F32, min_cluster_size=MIN_CLUSTER_SIZE):
+    X = np.ascontiguousarray(X, np.float64)
+    N, d = X.shape
+    lab = np.zeros(N, np.int32)
+    K = lib().orc_cluster_embeddings_ex(X, N, d, threshold, min_cluster_size, num_clusters, min_clusters, max_clusters, lab)
+    return lab, K
 
 
 def mark_inactive(binarized, hard):

@@ -441,8 +441,62 @@ static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(c
 /* (or -1 on zero-norm centroid = reference throws).  threshold is the   */
 /* reference's float-typed member (sd.cpp:2049) promoted to double.      */
 /* ------------------------------------------------------------------ */
+/* number of fcluster labels (1-based) with at least mcs members */
+static int count_large_1based(const int *T, long N, long mcs)
+{
+    int mx = 0;
+    for (long i = 0; i < N; ++i) if (T[i] > mx) mx = T[i];
+    long *cnt = (long *)calloc((size_t)mx + 1, sizeof(long));
+    for (long i = 0; i < N; ++i) cnt[T[i]]++;
+    int nl = 0;
+    for (int k = 1; k <= mx; ++k) if (cnt[k] >= mcs) nl++;
+    free(cnt);
+    return nl;
+}
+
+typedef struct { double key; long idx; } orc_key;
+static int cmp_key(const void *a, const void *b)
+{
+    const orc_key *x = (const orc_key *)a, *y = (const orc_key *)b;
+    if (x->key < y->key) return -1;
+    if (x->key > y->key) return 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);          /* stable */
+}
+
+/* Constrained number of clusters: unimplemented in the C++ reference (assert(false), sd.cpp:2368-2369);
+ * restated from the Python it was ported from, clustering/Clustering.py:352-399.  labels: 0-based out. */
+static void orc_constrained_recut(const double *Z, long N, double threshold, long mcs, int num_clusters, int *labels)
+{
+    double *Zi = (double *)malloc(sizeof(double) * (size_t)(N - 1) * 4);
+    memcpy(Zi, Z, sizeof(double) * (size_t)(N - 1) * 4);
+    orc_key *ord = (orc_key *)malloc(sizeof(orc_key) * (size_t)(N - 1));
+    for (long k = 0; k < N - 1; ++k) { Zi[k * 4 + 2] = (double)k; ord[k].key = fabs(Z[k * 4 + 2] - threshold); ord[k].idx = k; }
+    qsort(ord, (size_t)(N - 1), sizeof(orc_key), cmp_key);
+    int *T = (int *)malloc(sizeof(int) * (size_t)N);
+    long best_iteration = N - 1; int best_large = 1, exact = 0;
+    for (long q = 0; q < N - 1; ++q) {
+        const long it = ord[q].idx;
+        if (Zi[it * 4 + 3] < (double)mcs) continue;
+        orc_fcluster_distance(Zi, N, (double)it, T);
+        const int nl = count_large_1based(T, N, mcs);
+        if (abs(nl - num_clusters) < abs(best_large - num_clusters)) { best_iteration = it; best_large = nl; }
+        if (nl == num_clusters) { exact = 1; break; }
+    }
+    if (!exact) orc_fcluster_distance(Zi, N, (double)best_iteration, T);
+    for (long i = 0; i < N; ++i) labels[i] = T[i] - 1;
+    free(Zi); free(ord); free(T);
+}
+
+int orc_cluster_embeddings_ex(const double *X, long N, int d, float threshold,
+                              long min_cluster_size_cfg, int num_clusters, int min_clusters, int max_clusters, int *labels);
 int orc_cluster_embeddings(const double *X, long N, int d, float threshold,
                            long min_cluster_size_cfg, int *labels)
+{
+    return orc_cluster_embeddings_ex(X, N, d, threshold, min_cluster_size_cfg, -1, -1, -1, labels);
+}
+
+int orc_cluster_embeddings_ex(const double *X, long N, int d, float threshold,
+                              long min_cluster_size_cfg, int num_clusters, int min_clusters, int max_clusters, int *labels)
 {
     /* sd.cpp:2308 */
     long r = (long)round(0.1 * (double)N);
@@ -457,10 +511,30 @@ int orc_cluster_embeddings(const double *X, long N, int d, float threshold,
         double nrm = (double)(float)sqrt(s);
         for (int q = 0; q < d; ++q) Xn[i * d + q] = (nrm != 0.0) ? X[i * d + q] / nrm : X[i * d + q];
     }
-    orc_ahc_labels(Xn, N, d, (double)threshold, labels, NULL);
+    double *Zc = (double *)malloc(sizeof(double) * (size_t)(N > 1 ? N - 1 : 1) * 4);
+    orc_ahc_labels(Xn, N, d, (double)threshold, labels, Zc);
     free(Xn);
+    for (long i = 0; i < N; ++i) labels[i] -= 1;
+    if (num_clusters != -1 || min_clusters != -1 || max_clusters != -1) {
+        /* set_num_clusters with the Python semantics (Clustering.py:21-43) */
+        if (num_clusters != -1) { min_clusters = num_clusters; max_clusters = num_clusters; }
+        if (min_clusters == -1) min_clusters = 1;
+        if (max_clusters == -1) max_clusters = (int)N;
+        if (min_clusters > N) min_clusters = (int)N; if (min_clusters < 1) min_clusters = 1;
+        if (max_clusters > N) max_clusters = (int)N; if (max_clusters < 1) max_clusters = 1;
+        if (min_clusters > max_clusters) min_clusters = max_clusters;
+        int target = (min_clusters == max_clusters) ? min_clusters : -1;
+        int *T1 = (int *)malloc(sizeof(int) * (size_t)N);
+        for (long i = 0; i < N; ++i) T1[i] = labels[i] + 1;
+        const int nlarge0 = count_large_1based(T1, N, mcs);
+        free(T1);
+        if (nlarge0 < min_clusters) target = min_clusters;
+        if (nlarge0 > max_clusters) target = max_clusters;
+        if (target != -1) orc_constrained_recut(Zc, N, (double)threshold, mcs, target, labels);
+    }
+    free(Zc);
     int maxl = 0;
-    for (long i = 0; i < N; ++i) { labels[i] -= 1; if (labels[i] > maxl) maxl = labels[i]; }
+    for (long i = 0; i < N; ++i) if (labels[i] > maxl) maxl = labels[i];
     int nl = maxl + 1;
     long *cnt = (long *)calloc((size_t)nl, sizeof(long));
     for (long i = 0; i < N; ++i) cnt[labels[i]]++;
@@ -528,21 +602,32 @@ done:
 /* emb [c][S][d] (NaN rows = no embedding) -> hard [c][S]; returns K or  */
 /* 0 when max_clusters<2 path (all zeros) was taken, -1 on error.        */
 /* ------------------------------------------------------------------ */
+int orc_clustering_ex(const double *emb, long c, int S, int d, float threshold, long min_cluster_size_cfg,
+                      int num_clusters, int min_clusters, int max_clusters, int *hard, int *train_labels_out, long *ntrain_out);
 int orc_clustering(const double *emb, long c, int S, int d, float threshold,
                    long min_cluster_size_cfg, int *hard, int *train_labels_out, long *ntrain_out)
+{
+    return orc_clustering_ex(emb, c, S, d, threshold, min_cluster_size_cfg, -1, -1, -1, hard, train_labels_out, ntrain_out);
+}
+int orc_clustering_ex(const double *emb, long c, int S, int d, float threshold, long min_cluster_size_cfg,
+                      int num_clusters, int min_clusters, int max_clusters, int *hard, int *train_labels_out, long *ntrain_out)
 {
     long M = c * S, N = 0;
     long *tidx = (long *)malloc(sizeof(long) * (size_t)M);
     for (long i = 0; i < M; ++i) if (!isnan(emb[i * d])) tidx[N++] = i;     /* sd.cpp:2224 */
     if (ntrain_out) *ntrain_out = N;
-    if (N < 2) {                                                            /* sd.cpp:2081 */
-        for (long i = 0; i < M; ++i) hard[i] = 0;
-        free(tidx); return 0;
+    {
+        int mxc = (num_clusters != -1) ? num_clusters : ((max_clusters != -1) ? max_clusters : (int)N);
+        if (mxc > N) mxc = (int)N;
+        if (N < 2 || mxc < 2) {                                             /* sd.cpp:2081 */
+            for (long i = 0; i < M; ++i) hard[i] = 0;
+            free(tidx); return 0;
+        }
     }
     double *X = (double *)malloc(sizeof(double) * (size_t)N * d);
     for (long i = 0; i < N; ++i) memcpy(&X[i * d], &emb[tidx[i] * d], sizeof(double) * d);
     int *lab = (int *)malloc(sizeof(int) * (size_t)N);
-    int K = orc_cluster_embeddings(X, N, d, threshold, min_cluster_size_cfg, lab);
+    int K = orc_cluster_embeddings_ex(X, N, d, threshold, min_cluster_size_cfg, num_clusters, min_clusters, max_clusters, lab);
     if (K < 0) { free(tidx); free(X); free(lab); return -1; }
     if (train_labels_out) memcpy(train_labels_out, lab, sizeof(int) * (size_t)N);
     /* assign_embeddings, sd.cpp:2119-2212 */

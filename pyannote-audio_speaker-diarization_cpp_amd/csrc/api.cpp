@@ -84,6 +84,9 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     if (k == "emb_batch_items") c->emb_batch_items = v;
     else if (k == "seg_batch_chunks") c->seg_batch_chunks = v;
     else if (k == "linkage_wgs") c->linkage_wgs = v;
+    else if (k == "num_clusters") c->num_clusters = (int)v;
+    else if (k == "min_clusters") c->min_clusters = (int)v;
+    else if (k == "max_clusters") c->max_clusters = (int)v;
     else if (k == "profile") { c->profile = v != 0; c->profile_detail = v >= 2; }
     else SD_FAIL(c, SD_ERR_ARG, "unknown option %s", key);
     return SD_OK;
@@ -222,5 +225,69 @@ extern "C" int sd_format_turn(const sd_turn* t, char* buf, int cap)
 {
     if (!t || !buf) return SD_ERR_ARG;
     snprintf(buf, (size_t)cap, "[%g -- %g] --> Speaker_%d", t->start, t->end, t->label);   // sd.cpp:3439, iostream default precision
+    return SD_OK;
+}
+
+// ------------------------------------------------------------------ wav reader, all bit depths the reference reads (wav.h:99-122)
+// 8-bit samples are read as signed char, 32-bit as int, every depth is then divided by 32768 (sd.cpp:2950) -- the
+// reference's scaling, kept as is.  Returns malloc'd float samples (sd_free_wav).
+extern "C" int sd_read_wav_f32(const char* path, float** wav, int64_t* n, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample)
+{
+    if (!path || !wav || !n) return SD_ERR_ARG;
+    *wav = nullptr; *n = 0;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return SD_ERR_ARG;
+    unsigned char h[44];
+    if (fread(h, 1, 44, fp) != 44) { fclose(fp); return SD_ERR_ARG; }
+    uint32_t fmt_size, sr, dsz; uint16_t ch, bits; char tag[4];
+    memcpy(&fmt_size, h + 16, 4); memcpy(&ch, h + 22, 2); memcpy(&sr, h + 24, 4); memcpy(&bits, h + 34, 2);
+    memcpy(tag, h + 36, 4); memcpy(&dsz, h + 40, 4);
+    if (fmt_size < 16) { fclose(fp); return SD_ERR_ARG; }
+    unsigned char t8[8];
+    if (fmt_size > 16) {
+        fseek(fp, 44 - 8 + (long)fmt_size - 16, SEEK_SET);
+        if (fread(t8, 1, 8, fp) != 8) { fclose(fp); return SD_ERR_ARG; }
+        memcpy(tag, t8, 4); memcpy(&dsz, t8 + 4, 4);
+    }
+    while (strncmp(tag, "data", 4) != 0) {
+        fseek(fp, (long)dsz, SEEK_CUR);
+        if (fread(t8, 1, 8, fp) != 8) { fclose(fp); return SD_ERR_ARG; }
+        memcpy(tag, t8, 4); memcpy(&dsz, t8 + 4, 4);
+    }
+    if (bits != 8 && bits != 16 && bits != 32) { fclose(fp); return SD_ERR_ARG; }     // reference: exit(1), wav.h:119-121
+    const int bps = bits / 8;
+    const int64_t num = dsz / bps;
+    std::vector<unsigned char> raw((size_t)(num > 0 ? num * bps : 1));
+    const size_t got = fread(raw.data(), 1, (size_t)num * bps, fp);
+    fclose(fp);
+    if (got < (size_t)num * bps) memset(raw.data() + got, 0, (size_t)num * bps - got);
+    float* out = (float*)malloc(sizeof(float) * (size_t)(num > 0 ? num : 1));
+    for (int64_t i = 0; i < num; ++i) {
+        float v;
+        if (bits == 8) v = (float)(signed char)raw[(size_t)i];
+        else if (bits == 16) { int16_t s; memcpy(&s, &raw[(size_t)i * 2], 2); v = (float)s; }
+        else { int32_t s; memcpy(&s, &raw[(size_t)i * 4], 4); v = (float)s; }
+        out[i] = (float)((double)(v * 1.0f) / 32768.0);
+    }
+    *wav = out;
+    *n = num / (ch ? ch : 1);
+    if (sample_rate) *sample_rate = (int32_t)sr;
+    if (channels) *channels = ch;
+    if (bits_per_sample) *bits_per_sample = bits;
+    return SD_OK;
+}
+extern "C" void sd_free_wav(float* p) { free(p); }
+
+// ------------------------------------------------------------------ RTTM output
+// one "SPEAKER <uri> 1 <start> <duration> <NA> <NA> SPEAKER_<kk> <NA> <NA>" line per turn (pyannote's RTTM writer layout)
+extern "C" int sd_write_rttm(const char* path, const char* uri, const sd_turn* turns, int64_t n_turns)
+{
+    if (!path || !turns || n_turns < 0) return SD_ERR_ARG;
+    FILE* f = fopen(path, "w");
+    if (!f) return SD_ERR_ARG;
+    for (int64_t i = 0; i < n_turns; ++i)
+        fprintf(f, "SPEAKER %s 1 %.3f %.3f <NA> <NA> SPEAKER_%02d <NA> <NA>\n", (uri && uri[0]) ? uri : "audio",
+                turns[i].start, turns[i].end - turns[i].start, turns[i].label);
+    fclose(f);
     return SD_OK;
 }

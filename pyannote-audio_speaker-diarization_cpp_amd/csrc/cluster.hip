@@ -628,7 +628,7 @@ void fcluster_host(const std::vector<double>& Z, int64_t n, double cutoff, std::
     }
 }
 
-int run_cluster_labels(sd_ctx* c, const double* d_Xn, int64_t N, int d, double cutoff, std::vector<int>& labels1)
+int run_cluster_labels(sd_ctx* c, const double* d_Xn, int64_t N, int d, double cutoff, std::vector<int>& labels1, std::vector<double>* Zout)
 {
     labels1.assign((size_t)N, 0);
     if (N == 1) { labels1[0] = 1; return SD_OK; }
@@ -640,6 +640,7 @@ int run_cluster_labels(sd_ctx* c, const double* d_Xn, int64_t N, int d, double c
     HIPCHK(c, hipMemcpyAsync(Z.data(), dZ, Z.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fcluster_host(Z, N, cutoff, labels1);
+    if (Zout) Zout->swap(Z);
     return SD_OK;
 }
 
@@ -698,8 +699,42 @@ static void group_by_label(const std::vector<int>& lab, int nl, std::vector<int>
     for (size_t i = 0; i < lab.size(); ++i) order[(size_t)pos[(size_t)lab[i]]++] = (int)i;
 }
 
+// Constrained number of clusters -- the branch the reference leaves unimplemented (assert(false), sd.cpp:2368-2369);
+// specification = the Python it was ported from, clustering/Clustering.py:352-399: re-cut the dendrogram by merge
+// index, walking away from the tuned threshold, until the number of large clusters is (closest to) num_clusters.
+static void constrained_recut(const std::vector<double>& Z, int64_t N, double threshold, size_t mcs, int num_clusters, std::vector<int>& lab)
+{
+    std::vector<double> Zi(Z);
+    for (int64_t k = 0; k < N - 1; ++k) Zi[(size_t)k * 4 + 2] = (double)k;          // Clustering.py:353-354
+    std::vector<int64_t> order((size_t)N - 1);
+    for (int64_t k = 0; k < N - 1; ++k) order[(size_t)k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        return fabs(Z[(size_t)a * 4 + 2] - threshold) < fabs(Z[(size_t)b * 4 + 2] - threshold); });   // :362
+    auto count_large = [&](const std::vector<int>& t1) {
+        int mx = 0; for (int v : t1) if (v > mx) mx = v;
+        std::vector<size_t> cnt((size_t)mx + 1, 0);
+        for (int v : t1) cnt[(size_t)v]++;
+        int nlarge = 0; for (size_t v = 1; v < cnt.size(); ++v) if (cnt[v] >= mcs) nlarge++;
+        return nlarge;
+    };
+    int64_t best_iteration = N - 1; int best_large = 1;                               // :356-357
+    std::vector<int> t1;
+    bool exact = false;
+    for (int64_t it : order) {
+        if (Zi[(size_t)it * 4 + 3] < (double)mcs) continue;                           // :366-368
+        fcluster_host(Zi, N, (double)it, t1);                                         // :371
+        const int nlarge = count_large(t1);
+        if (std::abs(nlarge - num_clusters) < std::abs(best_large - num_clusters)) { best_iteration = it; best_large = nlarge; }   // :377-381
+        if (nlarge == num_clusters) { exact = true; break; }                          // :384-385
+    }
+    if (!exact) fcluster_host(Zi, N, (double)best_iteration, t1);                     // :388-391
+    lab.resize((size_t)N);
+    for (int64_t i = 0; i < N; ++i) lab[(size_t)i] = t1[(size_t)i] - 1;
+}
+
 // d_emb: [M][d] f64 (NaN rows = no embedding), M = chunks*3.  hard: [M]
-int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector<int>& hard, int* Kout)
+int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector<int>& hard, int* Kout,
+                   int num_clusters, int min_clusters, int max_clusters)
 {
     hard.assign((size_t)M, 0);
     if (Kout) *Kout = 1;
@@ -711,7 +746,17 @@ int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector
     std::vector<int> tidx;
     for (int64_t i = 0; i < M; ++i) if (!std::isnan(first[(size_t)i])) tidx.push_back((int)i);
     const int64_t N = (int64_t)tidx.size();
-    if (N < 2) return SD_OK;                                        // max_clusters < 2 -> all zeros (sd.cpp:2081-2088)
+    // set_num_clusters (sd.cpp:2261-2296; with num_clusters given, max = num_clusters as in Clustering.py:27-41 --
+    // the port's `max_clusters == num_clusters;` is a no-op typo, sd.cpp:2278)
+    const bool constrained = (num_clusters != -1) || (min_clusters != -1) || (max_clusters != -1);
+    if (num_clusters != -1) { min_clusters = num_clusters; max_clusters = num_clusters; }
+    if (min_clusters == -1) min_clusters = 1;
+    if (max_clusters == -1) max_clusters = (int)N;
+    min_clusters = std::max(1, std::min((int)N, min_clusters));
+    max_clusters = std::max(1, std::min((int)N, max_clusters));
+    if (min_clusters > max_clusters) min_clusters = max_clusters;
+    if (min_clusters == max_clusters) num_clusters = min_clusters;
+    if (N < 2 || max_clusters < 2) return SD_OK;                    // all zeros (sd.cpp:2081-2088)
     WS(c, int, d_tidx, "cl_tidx", N);
     WS(c, double, X, "cl_X", N * d);
     WS(c, double, Xn, "cl_Xn", N * d);
@@ -721,7 +766,8 @@ int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector
     // a12+a13 with the reference's float-typed threshold (sd.cpp:2049) promoted to double
     const float thr = 0.7153814381597874;
     std::vector<int> lab;
-    int rc = run_cluster_labels(c, Xn, N, d, (double)thr, lab);
+    std::vector<double> Zh;
+    int rc = run_cluster_labels(c, Xn, N, d, (double)thr, lab, &Zh);
     if (rc) return rc;
     int nl = 0;
     for (auto& v : lab) { v -= 1; if (v + 1 > nl) nl = v + 1; }
@@ -729,6 +775,19 @@ int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector
     size_t mcs = std::min<size_t>(15, std::max<size_t>(1, (size_t)std::round(0.1 * (double)N)));     // sd.cpp:2308
     std::vector<int> order, off;
     group_by_label(lab, nl, order, off);
+    if (constrained) {
+        int nlarge0 = 0;
+        for (int k = 0; k < nl; ++k) if ((size_t)(off[(size_t)k + 1] - off[(size_t)k]) >= mcs) nlarge0++;
+        int target = (min_clusters == max_clusters) ? min_clusters : -1;
+        if (nlarge0 < min_clusters) target = min_clusters;                                            // sd.cpp:2361-2366
+        if (nlarge0 > max_clusters) target = max_clusters;
+        if (target != -1) {
+            constrained_recut(Zh, N, (double)thr, mcs, target, lab);
+            nl = 0;
+            for (int v : lab) if (v + 1 > nl) nl = v + 1;
+            group_by_label(lab, nl, order, off);
+        }
+    }
     std::vector<int> large, small;
     for (int k = 0; k < nl; ++k) {
         const size_t cnt = (size_t)(off[(size_t)k + 1] - off[(size_t)k]);

@@ -94,6 +94,7 @@ struct sd_ctx {
     double stage_ms[4] = {0, 0, 0, 0};
     int64_t emb_batch_items = 768;             // multiple of 96
     int64_t seg_batch_chunks = 4096;           // 128 LSTM workgroups per direction: one full wave of CUs
+    int num_clusters = -1, min_clusters = -1, max_clusters = -1;   // optional constraints for the whole-path entry points
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
     int num_cu = 256;
 };
@@ -134,7 +135,8 @@ int build_ecapa_weights(sd_ctx* c, const Pack& p);
 int build_seg_weights(sd_ctx* c, const Pack& p);
 // ---- frontend.hip
 int run_frontend(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item,
-                 float* d_feats /*[items][512][96]*/, float* d_wav_lens, int* d_nnorm, int* d_nvalid, int* d_flags);
+                 float* d_feats /*[items][512][96]*/, float* d_wav_lens, int* d_nnorm, int* d_nvalid, int* d_flags,
+                 bool compact = false, int* h_n_active = nullptr, int* d_cidx = nullptr);
 // ---- ecapa.hip
 int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_flags, int64_t items, float* d_emb);
 int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item, float* d_emb);
@@ -148,8 +150,9 @@ int sd_np_rint_host(double v);
 int64_t closest_frame_host(double w_start, double w_step, double w_dur, double t);
 // ---- cluster.hip
 int run_linkage(sd_ctx* c, const double* d_Xn, int64_t N, int d, double* d_Z);
-int run_cluster_labels(sd_ctx* c, const double* d_Xn, int64_t N, int d, double cutoff, std::vector<int>& labels1);
-int run_clustering(sd_ctx* c, const double* d_emb /*[M][d] f64*/, int64_t M, int d, std::vector<int>& hard, int* K);
+int run_cluster_labels(sd_ctx* c, const double* d_Xn, int64_t N, int d, double cutoff, std::vector<int>& labels1, std::vector<double>* Zout = nullptr);
+int run_clustering(sd_ctx* c, const double* d_emb /*[M][d] f64*/, int64_t M, int d, std::vector<int>& hard, int* K,
+                   int num_clusters = -1, int min_clusters = -1, int max_clusters = -1);
 void fcluster_host(const std::vector<double>& Z, int64_t n, double cutoff, std::vector<int>& T);
 // ---- reconstruct.hip
 int run_reconstruct(sd_ctx* c, const float* d_seg, const int* d_nact, const int* d_hard, const int32_t* d_count,

@@ -47,12 +47,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 
     const int w = blockIdx.x, G = gridDim.x;                 // G is a multiple of 8
     const int xcd = w & 7, wl = w >> 3, wpx = G >> 3;
-    const int mx = (a.m_tiles - xcd + 7) >> 3;               // row panels owned by this XCD
-    const int Lx = mx * a.n_tiles;
-    // interleaved assignment: workgroup wl takes tiles wl, wl+wpx, ... of its XCD's list, so the workgroups
-    // of an XCD work on adjacent tiles (same row panel) at the same time and share that panel in L2
-    const int q0 = wl, q_step = wpx, q_end = Lx;
-    if (q0 >= q_end) return;
+    const int mx = (a.m_tiles - xcd + 7) >> 3;               // row panels owned by this XCD (m = xcd + 8 j)
+    // Super-block schedule: the wpx workgroups of an XCD work at the same time on a PM x PN block of tiles
+    // (workgroup wl owns position (wl / PN, wl % PN) of every block).  They advance through K roughly in step,
+    // so each A and W K-slice is pulled into the XCD's L2 once per block and shared by PN resp. PM workgroups
+    // (measured before this order: 125 GB of fabric reads for the 3072x3072 layer against 4.9 GB algorithmic).
+    const int PN = a.n_tiles < 8 ? a.n_tiles : 8;
+    const int PM = wpx / PN > 0 ? wpx / PN : 1;
+    const int pm = wl / PN, pn = wl - pm * PN;
+    if (pm >= PM) return;
+    const int n_groups = (a.n_tiles + PN - 1) / PN, m_groups = (mx + PM - 1) / PM;
+    const int sb_end = n_groups * m_groups;
+    auto sb_valid = [&](int sb, int& j, int& nt) -> bool {
+        const int mg = sb / n_groups, ng = sb - mg * n_groups;
+        j = mg * PM + pm; nt = ng * PN + pn;
+        return j < mx && nt < a.n_tiles;
+    };
+    auto next_sb = [&](int sb) -> int {         // next super-block in which this workgroup has a tile, or sb_end
+        int j, nt;
+        for (++sb; sb < sb_end; ++sb) if (sb_valid(sb, j, nt)) return sb;
+        return sb_end;
+    };
+    const int q0 = next_sb(-1);
+    if (q0 >= sb_end) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -69,8 +86,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     size_t wrow[4];
     const float* pa[4]; const float* pb[4]; const float* px[4];
     int l_q = q0, l_kk = 0, l_kc = 0, m0l = 0, n0l = 0;
-    auto set_tile = [&](int qq) {
-        const int j = qq / a.n_tiles, nt = qq - j * a.n_tiles;
+    auto set_tile = [&](int sb) {
+        int j, nt;
+        (void)sb_valid(sb, j, nt);
         m0l = (xcd + 8 * j) * BM; n0l = nt * BN;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -114,7 +132,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         l_kc = 0;
         if (++l_kk == a.KT) {
             l_kk = 0;
-            if (l_q + q_step < q_end) { l_q += q_step; set_tile(l_q); }   // else: stay on the last tile (dummy loads)
+            const int nq = next_sb(l_q);
+            if (nq < sb_end) { l_q = nq; set_tile(l_q); }               // else: stay on the last tile (dummy loads)
         }
         set_tap(l_kk);
     };
@@ -270,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
             using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
             if (a.item_bias) { if (a.act2 == 1) tile_out(std::true_type{}, T1{}); else if (a.act2 == 2) tile_out(std::true_type{}, T2{}); else tile_out(std::true_type{}, T0{}); }
             else { if (a.act2 == 1) tile_out(std::false_type{}, T1{}); else if (a.act2 == 2) tile_out(std::false_type{}, T2{}); else tile_out(std::false_type{}, T0{}); }
-            q += q_step;
-            if (q >= q_end) break;
+            q = next_sb(q);
+            if (q >= sb_end) break;
             m0c = m0n; n0c = n0n; s = 0;
         } else {
             ++s;

@@ -111,6 +111,15 @@ __global__ void k_nan_rows(float* __restrict__ emb, const int* __restrict__ flag
     if (idx >= items * SD_EMB_DIM) return;
     if (flags[idx / SD_EMB_DIM]) emb[idx] = __int_as_float(0x7fc00000);
 }
+// emb[item] = embedding of its compact slot, or NaN for items dropped before the network
+__global__ void k_scatter_emb(const float* __restrict__ emb_c, const int* __restrict__ cidx, float* __restrict__ emb, int64_t items)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= items * SD_EMB_DIM) return;
+    const int64_t item = idx / SD_EMB_DIM;
+    const int a = cidx[item];
+    emb[idx] = (a >= 0) ? emb_c[(size_t)a * SD_EMB_DIM + (idx - item * SD_EMB_DIM)] : __int_as_float(0x7fc00000);
+}
 
 static ConvArgs conv_args(const ConvLayer& L, const float* X, int x_ld, float* Y, int y_ld, int64_t M, bool per_item)
 {
@@ -202,25 +211,35 @@ int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d
     }
     // asp_bn folded into fc
     { ConvArgs a = conv_args(E.fc, pooled, 2 * C3, d_emb, SD_EMB_DIM, items, false); if ((rc = launch_conv_gemm(c, a, "fc"))) return rc; }
-    hipLaunchKernelGGL(k_nan_rows, GRID1(items * SD_EMB_DIM), 0, st, d_emb, d_flags, items);
-    KCHECK(c);
+    if (d_flags) {
+        hipLaunchKernelGGL(k_nan_rows, GRID1(items * SD_EMB_DIM), 0, st, d_emb, d_flags, items);
+        KCHECK(c);
+    }
     return SD_OK;
 }
 
 int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item, float* d_emb)
 {
+    if (items <= 0) return SD_OK;
     int64_t nb = c->emb_batch_items;
     nb = (nb / 96) * 96; if (nb < 96) nb = 96;
     int rc;
-    for (int64_t i0 = 0; i0 < items; i0 += nb) {
-        const int64_t cnt = (items - i0 < nb) ? items - i0 : nb;
-        WS(c, float, feats, "emb_feats", nb * SD_TP * SD_FEAT_LD);
-        WS(c, float, lens, "emb_lens", nb);
-        WS(c, int, nnorm, "emb_nnorm", nb);
-        WS(c, int, nvalid, "emb_nvalid", nb);
-        WS(c, int, flags, "emb_flags", nb);
-        if ((rc = run_frontend(c, d_wav, n, d_masks + (size_t)i0 * SD_FRAMES, cnt, first_item + i0, feats, lens, nnorm, nvalid, flags))) return rc;
-        if ((rc = run_ecapa(c, feats, nvalid, flags, cnt, d_emb + (size_t)i0 * SD_EMB_DIM))) return rc;
+    // front end for the whole range first: items that are NaN by rule (sd.cpp:2479-2549) are dropped here, so the
+    // network always runs on full batches of live items (the reference computes the dead ones and overwrites them)
+    WS(c, float, feats, "emb_feats", items * SD_TP * SD_FEAT_LD);
+    WS(c, float, lens, "emb_lens", items);
+    WS(c, int, nnorm, "emb_nnorm", items);
+    WS(c, int, nvalid, "emb_nvalid", items);
+    WS(c, int, flags, "emb_flags", items);
+    WS(c, int, cidx, "emb_cidx", items);
+    WS(c, float, emb_c, "emb_compact", items * SD_EMB_DIM);
+    int n_active = 0;
+    if ((rc = run_frontend(c, d_wav, n, d_masks, items, first_item, feats, lens, nnorm, nvalid, flags, true, &n_active, cidx))) return rc;
+    for (int64_t a0 = 0; a0 < n_active; a0 += nb) {
+        const int64_t cnt = (n_active - a0 < nb) ? n_active - a0 : nb;
+        if ((rc = run_ecapa(c, feats + (size_t)a0 * SD_TP * SD_FEAT_LD, nvalid + a0, nullptr, cnt, emb_c + (size_t)a0 * SD_EMB_DIM))) return rc;
     }
+    hipLaunchKernelGGL(k_scatter_emb, GRID1(items * SD_EMB_DIM), 0, c->stream, emb_c, cidx, d_emb, items);
+    KCHECK(c);
     return SD_OK;
 }

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void k_stft_mel(
     const float* __restrict__ wav, int64_t n, const int* __restrict__ prefix, const int* __restrict__ counts,
     int64_t first_item, const float* __restrict__ window, const double* __restrict__ twc, const double* __restrict__ twns,
     const float* __restrict__ mel_w, const int* __restrict__ mel_lo, const int* __restrict__ mel_cnt,
-    const int* __restrict__ mel_off, int mel_nnz, float* __restrict__ db, float* __restrict__ item_max)
+    const int* __restrict__ mel_off, int mel_nnz, float* __restrict__ db, float* __restrict__ item_max,
+    const int* __restrict__ alist /* active-item list or null: outputs are indexed by the compact position */)
 {
     __shared__ double tc[400], ts[400];
     __shared__ float sig[SIG_LDS];
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(256) void k_stft_mel(
     __shared__ int pre[296];
     __shared__ int mlo[SD_NMELS], mcnt[SD_NMELS], moff[SD_NMELS];
 
-    const int item = blockIdx.y, t0 = blockIdx.x * FT;
+    const int slot = blockIdx.y, t0 = blockIdx.x * FT;
+    const int item = alist ? alist[slot] : slot;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t gitem = first_item + item;
     const int64_t chunk_start = (gitem / SD_SPEAKERS) * (int64_t)SD_HOP;     // crop(), sd.cpp:1643
@@ -200,12 +202,12 @@ __global__ __launch_bounds__(256) void k_stft_mel(
         const float v = 10.0f * log10f(fmaxf(acc, 1e-10f));
         const int t = t0 + 16 * w + fr;
         if (t < SD_T) {
-            db[((size_t)item * SD_T + t) * SD_NMELS + m] = v;
+            db[((size_t)slot * SD_T + t) * SD_NMELS + m] = v;
             vmax = fmaxf(vmax, v);
         }
     }
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if (lane == 0 && vmax > -INFINITY) atomic_max_float(&item_max[item], vmax);
+    if (lane == 0 && vmax > -INFINITY) atomic_max_float(&item_max[slot], vmax);
 }
 
 // ---------------------------------------------------------------- k_fbank_norm
@@ -236,16 +238,52 @@ __global__ __launch_bounds__(256) void k_fbank_norm(const float* __restrict__ db
     }
 }
 
+// items whose output row is NaN anyway (too short / whole batch too short, sd.cpp:2479-2549) are dropped
+// before the STFT and the network: alist[a] = item, cidx[item] = a or -1, compacted nnorm / nvalid
+__global__ __launch_bounds__(1024) void k_compact_active(const int* __restrict__ flags, int items, int* __restrict__ alist, int* __restrict__ cidx,
+                                                         const int* __restrict__ nnorm, const int* __restrict__ nvalid,
+                                                         int* __restrict__ nnorm_c, int* __restrict__ nvalid_c, int* __restrict__ n_active)
+{
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < items; i0 += 1024) {
+        const int i = i0 + tid;
+        const int act = (i < items && flags[i] == 0) ? 1 : 0;
+        int incl = act;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < w; ++k) off += wsum[k];
+        const int pos = off + incl - act;
+        if (i < items) {
+            cidx[i] = act ? pos : -1;
+            if (act) { alist[pos] = i; nnorm_c[pos] = nnorm[i]; nvalid_c[pos] = nvalid[i]; }
+        }
+        __syncthreads();
+        if (tid == 1023) base = off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) *n_active = base;
+}
+
 __global__ void k_fill_f32(float* p, float v, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
 
+// compact = true: only items whose embedding is not NaN by rule are processed; feats / nvalid_c are indexed by the
+// compact position, *h_n_active receives their number, d_cidx[item] = compact position or -1.
 int run_frontend(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item,
-                 float* d_feats, float* d_wav_lens, int* d_nnorm, int* d_nvalid, int* d_flags)
+                 float* d_feats, float* d_wav_lens, int* d_nnorm, int* d_nvalid, int* d_flags,
+                 bool compact, int* h_n_active, int* d_cidx)
 {
     if (!c->ew.loaded) SD_FAIL(c, SD_ERR_MODEL, "embedding model not loaded");
+    if (h_n_active) *h_n_active = (int)items;
     if (items <= 0) return SD_OK;
     if (first_item % SD_EMB_BATCH != 0) SD_FAIL(c, SD_ERR_ARG, "first_item must be a multiple of 32 (reference batches)");
     if (c->ew.mel_nnz > MEL_MAX_NNZ) SD_FAIL(c, SD_ERR_MODEL, "mel filterbank too dense (%d non-zeros)", c->ew.mel_nnz);
@@ -256,20 +294,41 @@ int run_frontend(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks,
     const EcapaWeights& E = c->ew;
     hipLaunchKernelGGL(k_mask_prefix, dim3((unsigned)items), dim3(512), 0, c->stream, d_masks, d_prefix, d_counts, (int)items);
     KCHECK(c);
-    hipLaunchKernelGGL(k_wav_lens, dim3((unsigned)((items + 31) / 32)), dim3(64), 0, c->stream, d_counts, (int)items, d_wav_lens, d_nnorm, d_nvalid, d_flags);
-    KCHECK(c);
-    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, c->stream, d_max, -INFINITY, items);
+    int* nnorm_all = d_nnorm; int* nvalid_all = d_nvalid;
+    int* alist = nullptr;
+    int64_t run_items = items;
+    if (compact) {
+        WS(c, int, t_nnorm, "fe_nnorm_all", items);
+        WS(c, int, t_nvalid, "fe_nvalid_all", items);
+        WS(c, int, t_alist, "fe_alist", items);
+        WS(c, int, t_nact, "fe_nact", 4);
+        nnorm_all = t_nnorm; nvalid_all = t_nvalid; alist = t_alist;
+        hipLaunchKernelGGL(k_wav_lens, dim3((unsigned)((items + 31) / 32)), dim3(64), 0, c->stream, d_counts, (int)items, d_wav_lens, nnorm_all, nvalid_all, d_flags);
+        KCHECK(c);
+        hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, c->stream, d_flags, (int)items, alist, d_cidx, nnorm_all, nvalid_all, d_nnorm, d_nvalid, t_nact);
+        KCHECK(c);
+        int na = 0;
+        HIPCHK(c, hipMemcpyAsync(&na, t_nact, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        run_items = na;
+        if (h_n_active) *h_n_active = na;
+        if (na == 0) return SD_OK;
+    } else {
+        hipLaunchKernelGGL(k_wav_lens, dim3((unsigned)((items + 31) / 32)), dim3(64), 0, c->stream, d_counts, (int)items, d_wav_lens, d_nnorm, d_nvalid, d_flags);
+        KCHECK(c);
+    }
+    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((run_items + 255) / 256)), dim3(256), 0, c->stream, d_max, -INFINITY, run_items);
     KCHECK(c);
     {
         // algorithmic bytes per item: 80000*4 + 293*4 read, 501*80*4 written
-        ProfScope ps(c, "stft_mel", (double)items * (SD_TP * 208.0 * 204 * 2 * 2 + SD_T * 201.0 * 80 * 2), (double)items * (321172.0 + 160320.0));
-        hipLaunchKernelGGL(k_stft_mel, dim3((SD_T + FT - 1) / FT, (unsigned)items), dim3(256), 0, c->stream, d_wav, n, d_prefix, d_counts,
-                           first_item, E.window, E.tw_cos, E.tw_nsin, E.mel_w, E.mel_lo, E.mel_cnt, E.mel_off, E.mel_nnz, d_db, d_max);
+        ProfScope ps(c, "stft_mel", (double)run_items * (SD_TP * 208.0 * 204 * 2 * 2 + SD_T * 201.0 * 80 * 2), (double)run_items * (321172.0 + 160320.0));
+        hipLaunchKernelGGL(k_stft_mel, dim3((SD_T + FT - 1) / FT, (unsigned)run_items), dim3(256), 0, c->stream, d_wav, n, d_prefix, d_counts,
+                           first_item, E.window, E.tw_cos, E.tw_nsin, E.mel_w, E.mel_lo, E.mel_cnt, E.mel_off, E.mel_nnz, d_db, d_max, alist);
         KCHECK(c);
     }
     {
-        ProfScope ps(c, "fbank_norm", 0, (double)items * (160320.0 + SD_TP * SD_FEAT_LD * 4.0));
-        hipLaunchKernelGGL(k_fbank_norm, dim3((unsigned)items), dim3(256), 0, c->stream, d_db, d_max, d_nnorm, d_feats);
+        ProfScope ps(c, "fbank_norm", 0, (double)run_items * (160320.0 + SD_TP * SD_FEAT_LD * 4.0));
+        hipLaunchKernelGGL(k_fbank_norm, dim3((unsigned)run_items), dim3(256), 0, c->stream, d_db, d_max, d_nnorm, d_feats);
         KCHECK(c);
     }
     return SD_OK;

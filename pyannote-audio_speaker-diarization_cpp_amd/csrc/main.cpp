@@ -6,6 +6,7 @@
 // through the C ABI of libsdhip.so.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include "sdhip.h"
 
 int main(int argc, char* argv[])
@@ -14,9 +15,9 @@ int main(int argc, char* argv[])
         printf("program [segment model file] [embeding model file] [wave file]\n");   // sd.cpp:3423
         return 0;
     }
-    int16_t* pcm = nullptr; int64_t n = 0; int32_t sr = 0, ch = 0;
-    if (sd_read_wav(argv[3], &pcm, &n, &sr, &ch) != SD_OK) {
-        fprintf(stderr, "cannot read 16-bit PCM wav: %s\n", argv[3]);
+    float* wav = nullptr; int64_t n = 0; int32_t sr = 0, ch = 0, bits = 0;
+    if (sd_read_wav_f32(argv[3], &wav, &n, &sr, &ch, &bits) != SD_OK) {       // 8 / 16 / 32-bit PCM like wav.h:99-122
+        fprintf(stderr, "cannot read PCM wav: %s\n", argv[3]);
         return 1;
     }
     sd_ctx* ctx = sd_create(argv[1], argv[2], 0);
@@ -25,7 +26,7 @@ int main(int argc, char* argv[])
         return 1;
     }
     sd_turn* turns = nullptr; int64_t nt = 0;
-    int rc = sd_diarize(ctx, pcm, n, &turns, &nt);
+    int rc = sd_diarize_f32(ctx, wav, n, &turns, &nt);
     if (rc != SD_OK) {
         fprintf(stderr, "diarization failed (%d): %s\n", rc, sd_last_error(ctx));
         return 1;
@@ -40,8 +41,9 @@ int main(int argc, char* argv[])
     char line[160];
     for (int64_t i = 0; i < nt; ++i) { sd_format_turn(&turns[i], line, sizeof(line)); printf("%s\n", line); }
     printf("----------------------------------------------------\n");
+    if (argc >= 6 && std::string(argv[4]) == "--rttm") sd_write_rttm(argv[5], argv[3], turns, nt);   // optional extra: RTTM file
     sd_free_turns(turns);
-    sd_free_pcm(pcm);
+    sd_free_wav(wav);
     sd_destroy(ctx);
     return 0;
 }

@@ -115,7 +115,14 @@ extern "C" int sd_cluster(sd_ctx* c, const double* h_X, int64_t N, int d, double
     return SD_OK;
 }
 
+extern "C" int sd_clustering_ex(sd_ctx* c, const double* h_emb, int64_t chunks, int d, int num_clusters, int min_clusters, int max_clusters,
+                                int32_t* h_hard, int32_t* n_clusters);
 extern "C" int sd_clustering(sd_ctx* c, const double* h_emb, int64_t chunks, int d, int32_t* h_hard, int32_t* n_clusters)
+{
+    return sd_clustering_ex(c, h_emb, chunks, d, -1, -1, -1, h_hard, n_clusters);
+}
+extern "C" int sd_clustering_ex(sd_ctx* c, const double* h_emb, int64_t chunks, int d, int num_clusters, int min_clusters, int max_clusters,
+                                int32_t* h_hard, int32_t* n_clusters)
 {
     ENTER(c);
     if (!h_emb || !h_hard || chunks <= 0 || d <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_clustering: bad argument");
@@ -123,7 +130,7 @@ extern "C" int sd_clustering(sd_ctx* c, const double* h_emb, int64_t chunks, int
     DTMP(c, de, M * d * sizeof(double));
     HIPCHK(c, hipMemcpy(de.p, h_emb, M * d * sizeof(double), hipMemcpyHostToDevice));
     std::vector<int> hard; int K = 1;
-    int rc = run_clustering(c, (const double*)de.p, M, d, hard, &K);
+    int rc = run_clustering(c, (const double*)de.p, M, d, hard, &K, num_clusters, min_clusters, max_clusters);
     if (rc) return rc;
     for (int64_t i = 0; i < M; ++i) h_hard[i] = hard[(size_t)i];
     if (n_clusters) *n_clusters = K;
@@ -213,7 +220,7 @@ static int finalize(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t c
     hipLaunchKernelGGL(k_f32_to_f64, GRID1(M * SD_EMB_DIM), 0, c->stream, d_emb, d_e64, M * SD_EMB_DIM);
     KCHECK(c);
     std::vector<int> hard; int K = 1;
-    if ((rc = run_clustering(c, d_e64, M, SD_EMB_DIM, hard, &K))) return rc;
+    if ((rc = run_clustering(c, d_e64, M, SD_EMB_DIM, hard, &K, c->num_clusters, c->min_clusters, c->max_clusters))) return rc;
     HIPCHK(c, hipMemcpyAsync(d_hard, hard.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_mark_inactive, GRID1(M), 0, c->stream, d_hard, d_nact, M);
     KCHECK(c);
@@ -281,4 +288,26 @@ extern "C" int sd_diarize(sd_ctx* c, const int16_t* h_pcm, int64_t n, sd_turn** 
     DTMP(c, dp, n * sizeof(int16_t));
     HIPCHK(c, hipMemcpy(dp.p, h_pcm, n * sizeof(int16_t), hipMemcpyHostToDevice));
     return sd_diarize_dev(c, (const int16_t*)dp.p, n, turns, n_turns);
+}
+
+// ------------------------------------------------------------------ float-sample entry (8 / 32-bit wavs)
+// `wav` holds samples already divided by 32768 exactly as the reference's loop does for every bit depth (sd.cpp:2948-2951)
+extern "C" int sd_diarize_f32(sd_ctx* c, const float* h_wav, int64_t n, sd_turn** turns, int64_t* n_turns)
+{
+    ENTER(c);
+    if (!h_wav || n <= 0 || !turns || !n_turns) SD_FAIL(c, SD_ERR_ARG, "sd_diarize_f32: bad argument");
+    const double t0 = now_ms();
+    const int64_t chunks = sd_num_chunks(n, nullptr);
+    if (chunks <= 0) SD_FAIL(c, SD_ERR_SHORT, "audio of %lld samples yields no chunk", (long long)n);
+    for (int i = 0; i < 4; ++i) c->stage_ms[i] = 0;
+    WS(c, float, d_wav, "wav_f32", n + 512);
+    HIPCHK(c, hipMemcpyAsync(d_wav, h_wav, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    WS(c, float, d_seg, "dz_seg", chunks * SD_FRAMES * 3);
+    WS(c, float, d_emb, "dz_emb", chunks * 3 * SD_EMB_DIM);
+    int rc;
+    if ((rc = shard_infer(c, d_wav, n, 0, chunks, d_seg, d_emb))) return rc;
+    std::vector<sd_turn> v;
+    if ((rc = finalize(c, d_seg, d_emb, chunks, n, v))) return rc;
+    c->stage_ms[3] = now_ms() - t0;
+    return turns_out(c, v, turns, n_turns);
 }

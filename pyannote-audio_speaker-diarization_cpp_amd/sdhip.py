@@ -32,9 +32,10 @@ _lib = None
 EXPORTS = [
     "sd_create", "sd_destroy", "sd_last_error", "sd_create_error", "sd_num_chunks", "sd_segment", "sd_segment_dev",
     "sd_postseg", "sd_count_frames", "sd_embed", "sd_embed_dev", "sd_frontend", "sd_ecapa", "sd_linkage", "sd_cluster",
-    "sd_clustering", "sd_reconstruct", "sd_diarize", "sd_diarize_dev", "sd_free_turns", "sd_shard_infer_dev",
+    "sd_clustering", "sd_clustering_ex", "sd_reconstruct", "sd_diarize", "sd_diarize_dev", "sd_free_turns", "sd_shard_infer_dev",
     "sd_finalize_dev", "sd_read_wav", "sd_free_pcm", "sd_format_turn", "sd_stage_ms", "sd_kernel_stats",
-    "sd_reset_stats", "sd_set_option", "sd_bench_conv", "sd_bench_barrier", "sd_convert_onnx", "sd_convert_error",
+    "sd_reset_stats", "sd_set_option", "sd_bench_conv", "sd_bench_barrier", "sd_convert_onnx", "sd_convert_error", "sd_read_wav_f32", "sd_free_wav", "sd_diarize_f32",
+    "sd_write_rttm",
 ]
 
 
@@ -67,6 +68,7 @@ def lib():
     L.sd_linkage.argtypes = [vp, vp, i64, C.c_int, vp]
     L.sd_cluster.argtypes = [vp, vp, i64, C.c_int, dbl, vp]
     L.sd_clustering.argtypes = [vp, vp, i64, C.c_int, vp, C.POINTER(i32)]
+    L.sd_clustering_ex.argtypes = [vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(i32)]
     L.sd_reconstruct.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
     L.sd_diarize.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
     L.sd_diarize_dev.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
@@ -75,6 +77,10 @@ def lib():
     L.sd_finalize_dev.argtypes = [vp, vp, vp, i64, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
     L.sd_read_wav.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
     L.sd_free_pcm.argtypes = [C.POINTER(C.c_int16)]
+    L.sd_read_wav_f32.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.sd_free_wav.argtypes = [C.POINTER(C.c_float)]
+    L.sd_diarize_f32.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
+    L.sd_write_rttm.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Turn), i64]
     L.sd_format_turn.argtypes = [C.POINTER(Turn), C.c_char_p, C.c_int]
     L.sd_stage_ms.argtypes = [vp, C.POINTER(dbl)]
     L.sd_kernel_stats.argtypes = [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
@@ -138,6 +144,28 @@ def read_wav(path):
     arr = np.ctypeslib.as_array(p, shape=(total,)).copy()
     lib().sd_free_pcm(p)
     return arr[:n.value], sr.value, ch.value
+
+
+def read_wav_f32(path):
+    """8/16/32-bit PCM -> float32 samples / 32768 (reference scaling), sample_rate, channels, bits"""
+    p = C.POINTER(C.c_float)()
+    n, sr, ch, bits = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    rc = lib().sd_read_wav_f32(path.encode(), C.byref(p), C.byref(n), C.byref(sr), C.byref(ch), C.byref(bits))
+    if rc:
+        raise SdError(rc, "cannot read wav " + path)
+    total = n.value * max(ch.value, 1)
+    arr = np.ctypeslib.as_array(p, shape=(total,)).copy()
+    lib().sd_free_wav(p)
+    return arr[:n.value], sr.value, ch.value, bits.value
+
+
+def write_rttm(path, uri, turns):
+    arr = (Turn * max(len(turns), 1))()
+    for i, t in enumerate(turns):
+        arr[i] = Turn(t[0], t[1], t[2], 0)
+    rc = lib().sd_write_rttm(path.encode(), uri.encode(), arr, len(turns))
+    if rc:
+        raise SdError(rc, "cannot write " + path)
 
 
 class Diarizer:
@@ -229,13 +257,13 @@ class Diarizer:
         self._chk(lib().sd_cluster(self._h, _ptr(X), N, d, float(cutoff), _ptr(T)))
         return T
 
-    def clustering(self, emb):
+    def clustering(self, emb, num_clusters=-1, min_clusters=-1, max_clusters=-1):
         emb = np.ascontiguousarray(emb, np.float64)
         c, S, d = emb.shape
         assert S == SPEAKERS
         hard = np.zeros((c, S), np.int32)
         K = C.c_int32(0)
-        self._chk(lib().sd_clustering(self._h, _ptr(emb), c, d, _ptr(hard), C.byref(K)))
+        self._chk(lib().sd_clustering_ex(self._h, _ptr(emb), c, d, num_clusters, min_clusters, max_clusters, _ptr(hard), C.byref(K)))
         return hard, int(K.value)
 
     # ---- a15-a17
@@ -261,6 +289,13 @@ class Diarizer:
         p = C.POINTER(Turn)()
         n = C.c_int64(0)
         self._chk(lib().sd_diarize(self._h, _ptr(pcm), len(pcm), C.byref(p), C.byref(n)))
+        return self._turns(p, n)
+
+    def diarize_f32(self, wav):
+        wav = np.ascontiguousarray(wav, np.float32)
+        p = C.POINTER(Turn)()
+        n = C.c_int64(0)
+        self._chk(lib().sd_diarize_f32(self._h, _ptr(wav), len(wav), C.byref(p), C.byref(n)))
         return self._turns(p, n)
 
     def diarize_dev(self, d_pcm_ptr, n_samples):
