@@ -84,6 +84,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     if (k == "emb_batch_items") c->emb_batch_items = v;
     else if (k == "seg_batch_chunks") c->seg_batch_chunks = v;
     else if (k == "linkage_wgs") c->linkage_wgs = v;
+    else if (k == "skip_dead_rows") c->skip_dead_rows = v != 0;
     else if (k == "num_clusters") c->num_clusters = (int)v;
     else if (k == "min_clusters") c->min_clusters = (int)v;
     else if (k == "max_clusters") c->max_clusters = (int)v;
@@ -176,7 +177,7 @@ extern "C" int sd_ecapa(sd_ctx* c, const float* h_feats, const float* h_lens, in
     HIPCHK(c, hipMemcpy(df.p, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dv.p, nv.data(), items * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dg.p, fl.data(), items * sizeof(int), hipMemcpyHostToDevice));
-    int rc = run_ecapa(c, (const float*)df.p, (const int*)dv.p, (const int*)dg.p, items, (float*)de.p);
+    int rc = run_ecapa(c, (const float*)df.p, (const int*)dv.p, (const int*)dg.p, items, (float*)de.p, c->skip_dead_rows ? nv.data() : nullptr);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(h_emb, de.p, items * SD_EMB_DIM * sizeof(float), hipMemcpyDeviceToHost));

@@ -53,6 +53,10 @@ struct ConvArgs {
     int act1, act2;        // act1: 0 none 1 relu 2 leaky(0.01); act2 (after BN): 0 none 1 tanh 2 sigmoid
     int m_tiles, n_tiles;
     int sched;             // persistent-schedule variant (set by the launcher)
+    const int* mlist;      // optional per-XCD list of the row panels to compute: mlist[xcd * mlist_ld + j]
+    const int* mcount;     // [8] number of listed panels per XCD (rows of skipped panels are left untouched)
+    int mlist_ld;
+    double rows_listed;    // valid rows covered by the listed panels (FLOP accounting)
 };
 
 struct EcapaWeights {
@@ -95,6 +99,7 @@ struct sd_ctx {
     int64_t emb_batch_items = 768;             // multiple of 96
     int64_t seg_batch_chunks = 4096;           // 128 LSTM workgroups per direction: one full wave of CUs
     int num_clusters = -1, min_clusters = -1, max_clusters = -1;   // optional constraints for the whole-path entry points
+    bool skip_dead_rows = true;                 // ECAPA: skip row panels beyond nvalid + receptive field
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
     int num_cu = 256;
 };
@@ -138,7 +143,8 @@ int run_frontend(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks,
                  float* d_feats /*[items][512][96]*/, float* d_wav_lens, int* d_nnorm, int* d_nvalid, int* d_flags,
                  bool compact = false, int* h_n_active = nullptr, int* d_cidx = nullptr);
 // ---- ecapa.hip
-int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_flags, int64_t items, float* d_emb);
+int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_flags, int64_t items, float* d_emb,
+              const int* h_nvalid = nullptr);
 int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item, float* d_emb);
 // ---- pyannet.hip
 int run_segment(sd_ctx* c, const float* d_wav, int64_t n, int64_t chunk_lo, int64_t chunk_hi, float* d_seg);

@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 
     const int w = blockIdx.x, G = gridDim.x;                 // G is a multiple of 8
     const int xcd = w & 7, wl = w >> 3, wpx = G >> 3;
-    const int mx = (a.m_tiles - xcd + 7) >> 3;               // row panels owned by this XCD (m = xcd + 8 j)
+    // row panels owned by this XCD: m = xcd + 8 j, or the j-th entry of its panel list (time rows that cannot
+    // influence any valid output frame are not listed, see run_ecapa)
+    const int mx = a.mlist ? a.mcount[xcd] : ((a.m_tiles - xcd + 7) >> 3);
     // Super-block schedule: the wpx workgroups of an XCD work at the same time on a PM x PN block of tiles
     // (workgroup wl owns position (wl / PN, wl % PN) of every block).  They advance through K roughly in step,
     // so each A and W K-slice is pulled into the XCD's L2 once per block and shared by PN resp. PM workgroups
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     auto set_tile = [&](int sb) {
         int j, nt;
         (void)sb_valid(sb, j, nt);
-        m0l = (xcd + 8 * j) * BM; n0l = nt * BN;
+        m0l = (a.mlist ? a.mlist[xcd * a.mlist_ld + j] : (xcd + 8 * j)) * BM; n0l = nt * BN;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int g = m0l + r0 + 32 * p;
@@ -320,7 +322,8 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     a.sched = SD_CONV_SCHED_DEFAULT;
     const int grid = conv_grid(c, a);
     // algorithmic work: valid rows only (T of every TpOut), un-padded input channels
-    const double rows = (double)(a.M / a.TpOut) * a.T + (double)((a.M % a.TpOut) < a.T ? (a.M % a.TpOut) : a.T);
+    const double rows = a.mlist ? a.rows_listed
+                                : (double)(a.M / a.TpOut) * a.T + (double)((a.M % a.TpOut) < a.T ? (a.M % a.TpOut) : a.T);
     const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
     const double flops = 2.0 * rows * a.Cout * cin * a.KT;
     const double bytes = 4.0 * (rows * cin * (a.X2 ? 2 : 1) + rows * a.Cout + (double)a.Cout * cin * a.KT);

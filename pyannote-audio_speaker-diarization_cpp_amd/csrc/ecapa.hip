@@ -7,6 +7,7 @@
 // attentive softmax pooling) and the layer schedule.  Activations are channels-last
 // [item][512][C]; rows >= 501 are kept at zero.
 #include "common.h"
+#include <algorithm>
 
 // masked mean over the first nvalid[item] frames  -> out[item][C]   (SEBlock, lengths given)
 __global__ void k_masked_mean(const float* __restrict__ x, int ld, const int* __restrict__ nvalid, float* __restrict__ out, int C)
@@ -137,7 +138,8 @@ static ConvArgs conv_args(const ConvLayer& L, const float* X, int x_ld, float* Y
 
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
 
-int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_flags, int64_t items, float* d_emb)
+int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_flags, int64_t items, float* d_emb,
+              const int* h_nvalid)
 {
     const EcapaWeights& E = c->ew;
     if (!E.loaded) SD_FAIL(c, SD_ERR_MODEL, "embedding model not loaded");
@@ -161,14 +163,44 @@ int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d
     int rc;
     hipStream_t st = c->stream;
 
+    // ---- rows that matter.  Frames >= nvalid of an item are excluded from every statistic (SE mean, ASP), and a
+    // frame t only sees frames within the network's receptive field: 2 (block0, k5) + 7*2*(2+3+4) = 128... per
+    // side is the loose bound; the exact reach of one side is 2 + 7*(2 + 3 + 4) = 65 frames (each Res2Net block
+    // chains 7 k3 convs of dilation 2 / 3 / 4; the 1x1 convs and the SE gate add none).  Row panels (128 rows)
+    // that start at or beyond min(501, nvalid + 65) therefore cannot influence the embedding and are not
+    // computed: they are simply absent from the per-XCD panel lists (items are dealt to XCDs round robin so
+    // every XCD gets first, second, ... panels alike).
+    const int* mlist = nullptr; const int* mcount = nullptr; int mlist_ld = 0; double rows_listed = 0;
+    if (h_nvalid) {
+        const int kReach = 65;
+        std::vector<int> lists[8];
+        for (int64_t b = 0; b < items; ++b) {
+            int need = h_nvalid[b] + kReach; if (need > SD_T) need = SD_T;
+            const int npan = (need + 127) / 128;
+            for (int r = 0; r < npan; ++r) lists[b & 7].push_back((int)(b * (SD_TP / 128) + r));
+            rows_listed += (double)(need < npan * 128 ? need : npan * 128);
+        }
+        size_t ld = 1;
+        for (int x = 0; x < 8; ++x) if (lists[x].size() > ld) ld = lists[x].size();
+        std::vector<int> flat(8 * ld, 0), cnt(8);
+        for (int x = 0; x < 8; ++x) { cnt[x] = (int)lists[x].size(); std::copy(lists[x].begin(), lists[x].end(), flat.begin() + x * ld); }
+        WS(c, int, d_mlist, "ec_mlist", 8 * ld);
+        WS(c, int, d_mcount, "ec_mcount", 8);
+        HIPCHK(c, hipMemcpyAsync(d_mlist, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(d_mcount, cnt.data(), 8 * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));                 // host vectors go out of scope
+        mlist = d_mlist; mcount = d_mcount; mlist_ld = (int)ld;
+    }
+#define WITH_LIST(a) do { if (mlist) { (a).mlist = mlist; (a).mcount = mcount; (a).mlist_ld = mlist_ld; (a).rows_listed = rows_listed; } } while (0)
+
     // blocks[0]: TDNNBlock(80 -> C, k5)
-    { ConvArgs a = conv_args(E.block0, d_feats, SD_FEAT_LD, x0, C, M, true); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "block0"))) return rc; }
+    { ConvArgs a = conv_args(E.block0, d_feats, SD_FEAT_LD, x0, C, M, true); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "block0"))) return rc; }
 
     for (int b = 0; b < 3; ++b) {
         const auto& B = E.blk[b];
         const float* xin = (b == 0) ? x0 : cat + (size_t)(b - 1) * C;
         const int xin_ld = (b == 0) ? C : C3;
-        { ConvArgs a = conv_args(B.tdnn1, xin, xin_ld, t1, C, M, true); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "tdnn1"))) return rc; }
+        { ConvArgs a = conv_args(B.tdnn1, xin, xin_ld, t1, C, M, true); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "tdnn1"))) return rc; }
         const int S = C / 8;
         hipLaunchKernelGGL(k_copy_slice, GRID1(M * (S / 4)), 0, st, t1, C, rr, C, S, M);
         KCHECK(c);
@@ -176,9 +208,10 @@ int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d
             ConvArgs a = conv_args(B.res[i - 1], t1 + i * S, C, rr + i * S, C, M, true);
             a.act1 = 1;
             if (i >= 2) { a.X2 = rr + (i - 1) * S; a.x2_ld = C; }
+            WITH_LIST(a);
             if ((rc = launch_conv_gemm(c, a, "res2net"))) return rc;
         }
-        { ConvArgs a = conv_args(B.tdnn2, rr, C, t2, C, M, true); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "tdnn2"))) return rc; }
+        { ConvArgs a = conv_args(B.tdnn2, rr, C, t2, C, M, true); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "tdnn2"))) return rc; }
         {
             ProfScope ps(c, "se_mean", 0, (double)items * SD_T * C * 4.0);
             hipLaunchKernelGGL(k_masked_mean, dim3((C + 255) / 256, (unsigned)items), dim3(256), 0, st, t2, C, d_nvalid, se_s, C);
@@ -193,7 +226,7 @@ int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d
         }
     }
     // mfa: TDNNBlock(3C -> 3C, k1) over cat(x1,x2,x3)
-    { ConvArgs a = conv_args(E.mfa, cat, C3, mfa, C3, M, true); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
+    { ConvArgs a = conv_args(E.mfa, cat, C3, mfa, C3, M, true); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
     // ASP with global context: cat[x, mean, std] @ W == x @ Wx + (mean,std) @ Wms  (per-item bias)
     {
         ProfScope ps(c, "asp_stats", 0, (double)items * SD_T * C3 * 4.0);
@@ -201,9 +234,9 @@ int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d
         KCHECK(c);
     }
     { ConvArgs a = conv_args(E.asp_tdnn_ms, ms, 2 * C3, ib, 128, items, false); if ((rc = launch_conv_gemm(c, a, "asp_ms"))) return rc; }
-    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, C3, hid, 128, M, true); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
+    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, C3, hid, 128, M, true); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
     float* logits = cat;   // cat is dead after mfa
-    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, M, true); if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
+    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, M, true); WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
     {
         ProfScope ps(c, "asp_pool", 0, (double)items * SD_T * C3 * 8.0);
         hipLaunchKernelGGL(k_asp_pool, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, C3, d_nvalid, pooled, C3);
@@ -235,9 +268,15 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
     WS(c, float, emb_c, "emb_compact", items * SD_EMB_DIM);
     int n_active = 0;
     if ((rc = run_frontend(c, d_wav, n, d_masks, items, first_item, feats, lens, nnorm, nvalid, flags, true, &n_active, cidx))) return rc;
+    std::vector<int> h_nvalid((size_t)(n_active > 0 ? n_active : 1));
+    if (n_active > 0) {
+        HIPCHK(c, hipMemcpyAsync(h_nvalid.data(), nvalid, (size_t)n_active * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     for (int64_t a0 = 0; a0 < n_active; a0 += nb) {
         const int64_t cnt = (n_active - a0 < nb) ? n_active - a0 : nb;
-        if ((rc = run_ecapa(c, feats + (size_t)a0 * SD_TP * SD_FEAT_LD, nvalid + a0, nullptr, cnt, emb_c + (size_t)a0 * SD_EMB_DIM))) return rc;
+        if ((rc = run_ecapa(c, feats + (size_t)a0 * SD_TP * SD_FEAT_LD, nvalid + a0, nullptr, cnt, emb_c + (size_t)a0 * SD_EMB_DIM,
+                            c->skip_dead_rows ? h_nvalid.data() + a0 : nullptr))) return rc;
     }
     hipLaunchKernelGGL(k_scatter_emb, GRID1(items * SD_EMB_DIM), 0, c->stream, emb_c, cidx, d_emb, items);
     KCHECK(c);

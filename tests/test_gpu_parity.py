@@ -116,6 +116,26 @@ def test_ecapa_parity(diarizer, weights):
     np.testing.assert_allclose(e_gpu, e_ref, rtol=RTOL, atol=ATOL)
 
 
+def test_ecapa_dead_row_skipping_is_invisible(diarizer, weights):
+    """row panels beyond nvalid + 65 frames (the network's one-sided receptive field) are not computed
+    (DESIGN.md section 2): short items must give the same embedding with and without the skip, and a poisoned
+    workspace (NaN left behind by a previous batch) must not leak into them"""
+    rng = np.random.default_rng(13)
+    lens = np.array([1.0, 0.008, 0.25, 0.5, 0.12, 0.37, 0.62, 0.87, 0.999, 0.3], np.float32)
+    feats = (3.0 * rng.standard_normal((len(lens), 501, 80))).astype(np.float32)
+    poison = np.full((len(lens), 501, 80), np.nan, np.float32)
+    diarizer.set_option("skip_dead_rows", 0)
+    diarizer.ecapa(poison, np.ones(len(lens), np.float32))           # fill every activation buffer with NaN
+    e_full = diarizer.ecapa(feats, lens)
+    diarizer.set_option("skip_dead_rows", 1)
+    diarizer.ecapa(poison, np.ones(len(lens), np.float32))
+    e_skip = diarizer.ecapa(feats, lens)
+    assert np.isfinite(e_skip).all()
+    assert np.array_equal(e_full, e_skip)
+    e_ref = nn.EcapaOracle(weights[3])(feats, lens).numpy()
+    np.testing.assert_allclose(e_skip, e_ref, rtol=RTOL, atol=ATOL)
+
+
 def test_embed_parity(diarizer, weights):
     rng = np.random.default_rng(4)
     wav, masks = _wav_and_masks(rng, 100)
