@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hours-per-gpu", type=float, default=1.0)
     ap.add_argument("--cpu-seconds", type=int, default=20, help="audio seconds for the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) | gloo (plumbing test of the multi-rank code "
+                    "on a box with fewer GPUs than ranks: gathers go through host memory, ranks may share a GPU)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,11 +74,16 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libsdhip has no CPU fallback")
+    if a.backend == "gloo":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import sdhip
     import synth
@@ -120,8 +127,15 @@ def main():
         if nloc > 0:
             d.shard_infer_dev(d_pcm.data_ptr(), first, int(d_pcm.numel()), n_total, lo, hi, d_seg.data_ptr(), d_emb.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(g_seg, d_seg)
-            dist.all_gather_into_tensor(g_emb, d_emb)
+            if a.backend == "gloo":                      # test-only path: same assembly through host memory
+                hs, he = [torch.empty(d_seg.shape) for _ in range(world)], [torch.empty(d_emb.shape) for _ in range(world)]
+                dist.all_gather(hs, d_seg.cpu())
+                dist.all_gather(he, d_emb.cpu())
+                g_seg.copy_(torch.cat(hs))
+                g_emb.copy_(torch.cat(he))
+            else:
+                dist.all_gather_into_tensor(g_seg, d_seg)
+                dist.all_gather_into_tensor(g_emb, d_emb)
             torch.cuda.synchronize()
             if rank == 0:
                 turns_box[0] = d.finalize_dev(g_seg.data_ptr(), g_emb.data_ptr(), C, n_total)
@@ -159,6 +173,14 @@ def main():
         for k in ("stft_mel", "lstm_rec", "pdist", "linkage", "row_nn", "se_apply", "asp_pool"):
             s = d.kernel_stats(k)
             extra[k] = {"ms_per_step": round(s["ms"] / max(a.steps, 1), 3), "launches_per_step": s["launches"] // max(a.steps, 1)}
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_conv_gemm_bench.json")
+        if world == 1 and os.path.exists(pmc_path):
+            try:
+                pj = json.load(open(pmc_path))
+                traffic, traffic_src = pj["bytes_per_launch"], pj["source"]
+            except Exception:
+                pass
         out = {
             "metric": "real-time factor (audio-sec/wall-sec), %g h 16 kHz mono per GPU" % a.hours_per_gpu,
             "value": round(audio_s / (ms_per_step / 1e3), 2),
@@ -167,15 +189,15 @@ def main():
             "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%g h synthetic 16 kHz mono per GPU (%d h total), full pipeline: PyanNet segmentation + "
-                                   "post-seg + STFT/fbank + ECAPA-TDNN + centroid AHC + reconstruction" % (a.hours_per_gpu, round(audio_s / HOUR)),
+            "config": {"workload": "%g h synthetic 16 kHz mono per GPU (%g h total), full pipeline: PyanNet segmentation + "
+                                   "post-seg + STFT/fbank + ECAPA-TDNN + centroid AHC + reconstruction" % (a.hours_per_gpu, audio_s / HOUR),
                        "audio_seconds": audio_s, "chunks": C, "embedding_items": 3 * C,
                        "weights": "seeded synthetic (seg 4321, emb 4322): the reference's ONNX blobs are not in the checkout",
                        "sharding": "contiguous chunk ranges of %d per rank, RCCL all-gather of scores+embeddings, clustering on rank 0" % per,
                        "turns": len(turns_box[0] or []),
                        "stage_ms_last_step": {"segmentation": round(stages[0], 1), "embedding": round(stages[1], 1), "clustering": round(stages[2], 1)}},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_conv_gemm (v_mfma_f32_32x32x2_f32)", "launches_per_step": cg["launches"] // max(a.steps, 1),
                          "kernel_ms_per_step": round(cg["ms"] / max(a.steps, 1), 2),
                          "algorithmic_gflop_per_step": round(cg["flops"] / max(a.steps, 1) / 1e9, 1)},
