@@ -87,7 +87,7 @@ def main():
 
     import sdhip
     import synth
-    from oracle import nn_oracle as nn          # weight *generation* only
+    import weightpack as nn                     # seeded synthetic weights + .sdw container (package data, not the oracle)
 
     tmp = tempfile.mkdtemp(prefix="sdw_r%d_" % rank)
     ws, we = nn.synth_segmentation_weights(4321), nn.synth_embedding_weights(4322)

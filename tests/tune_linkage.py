@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time / verify the linkage kernels: tools/tune_linkage.py [N]"""
+"""Time / verify the linkage kernels: tests/tune_linkage.py [N]  (scratch tuner, not collected by pytest; checks Z against the oracle)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -12,8 +12,8 @@ import argparse
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from oracle import nn_oracle  # noqa: E402  (weight *generation* only; nothing of the oracle ships)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pyannote-audio_speaker-diarization_cpp_amd"))
+import weightpack  # noqa: E402
 
 
 def main():
@@ -23,8 +23,8 @@ def main():
     ap.add_argument("--seed-emb", type=int, default=4322)
     a = ap.parse_args()
     os.makedirs(a.out_dir, exist_ok=True)
-    nn_oracle.save_pack(os.path.join(a.out_dir, "segment.sdw"), nn_oracle.synth_segmentation_weights(a.seed_seg))
-    nn_oracle.save_pack(os.path.join(a.out_dir, "embedding.sdw"), nn_oracle.synth_embedding_weights(a.seed_emb))
+    weightpack.save_pack(os.path.join(a.out_dir, "segment.sdw"), weightpack.synth_segmentation_weights(a.seed_seg))
+    weightpack.save_pack(os.path.join(a.out_dir, "embedding.sdw"), weightpack.synth_embedding_weights(a.seed_emb))
     print(os.path.join(a.out_dir, "segment.sdw"), os.path.join(a.out_dir, "embedding.sdw"))
 
 
