@@ -150,10 +150,12 @@ int sd_format_turn(const sd_turn* t, char* buf, int cap);
 int sd_stage_ms(const sd_ctx*, double* ms4);
 int sd_kernel_stats(const sd_ctx*, const char* kernel, double* total_ms, int64_t* launches, double* flops, double* bytes);
 void sd_reset_stats(sd_ctx*);
+/* keys: "emb_batch_items", "seg_batch_chunks", "profile", "linkage_wgs" (-1 auto, 0 one workgroup), "linkage_threads",
+ * "skip_dead_rows", "num_clusters", "min_clusters", "max_clusters" */
 int sd_set_option(sd_ctx*, const char* key, int64_t value);
 /* tuning hook (tools/tune_conv.py): time one conv_gemm shape on scratch data; dbg selects an ablation */
 int sd_bench_barrier(sd_ctx*, int workgroups, int iters, int dirty_doubles, double* us_per_barrier);
-int sd_bench_conv(sd_ctx*, int64_t items, int Tp, int T, int Cin, int Cout, int KT, int dil, int has_x2, int dbg, int reps, double* ms_per_launch);   /* "emb_batch_items", "seg_batch_chunks", "profile", "linkage_wgs", "num_clusters", "min_clusters", "max_clusters" */
+int sd_bench_conv(sd_ctx*, int64_t items, int Tp, int T, int Cin, int Cout, int KT, int dil, int has_x2, int dbg, int reps, double* ms_per_launch);
 
 #ifdef __cplusplus
 }

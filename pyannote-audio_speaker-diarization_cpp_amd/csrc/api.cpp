@@ -84,6 +84,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     if (k == "emb_batch_items") c->emb_batch_items = v;
     else if (k == "seg_batch_chunks") c->seg_batch_chunks = v;
     else if (k == "linkage_wgs") c->linkage_wgs = v;
+    else if (k == "linkage_threads") c->linkage_threads = v;
     else if (k == "skip_dead_rows") c->skip_dead_rows = v != 0;
     else if (k == "num_clusters") c->num_clusters = (int)v;
     else if (k == "min_clusters") c->min_clusters = (int)v;

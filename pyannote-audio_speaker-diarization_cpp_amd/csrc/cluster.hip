@@ -100,13 +100,40 @@ __device__ __forceinline__ MinIdx better(MinIdx a, MinIdx b)
     if (b.v == a.v && b.i < a.i) return b;
     return a;
 }
+// Wave-wide reductions with DPP lane moves (quad swaps, half-mirror, mirror, row broadcasts) instead of
+// ds_bpermute shuffles: the dependent chain is ~10x shorter, and these reductions sit on the serial path of
+// every merge.  All 64 lanes must be active.  The result (in lane 63 after the last step) is returned to all lanes.
+template <int CTRL, int RM> __device__ __forceinline__ int dppi(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, RM, 0xF, false); }
+template <int CTRL, int RM> __device__ __forceinline__ double dppd(double v)
+{
+    const int lo = dppi<CTRL, RM>(__double2loint(v)), hi = dppi<CTRL, RM>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <int CTRL, int RM> __device__ __forceinline__ MinIdx dpp_step(MinIdx m)
+{
+    MinIdx t; t.v = dppd<CTRL, RM>(m.v); t.i = dppi<CTRL, RM>(m.i);
+    return better(m, t);
+}
+// lanes 31 / 63 end up with the minima of lanes 0-31 / 32-63
+__device__ __forceinline__ MinIdx half_min(MinIdx m)
+{
+    m = dpp_step<0xB1, 0xF>(m);      // quad_perm [1,0,3,2]
+    m = dpp_step<0x4E, 0xF>(m);      // quad_perm [2,3,0,1]
+    m = dpp_step<0x141, 0xF>(m);     // row_half_mirror
+    m = dpp_step<0x140, 0xF>(m);     // row_mirror: every lane holds its row's minimum
+    m = dpp_step<0x142, 0xA>(m);     // row_bcast15 into rows 1 and 3
+    return m;
+}
 __device__ __forceinline__ MinIdx wave_min(MinIdx m)
 {
-    for (int o = 32; o > 0; o >>= 1) {
-        MinIdx t; t.v = __shfl_xor(m.v, o); t.i = __shfl_xor(m.i, o);
-        m = better(m, t);
-    }
-    return m;
+    m = half_min(m);
+    m = dpp_step<0x143, 0xC>(m);     // row_bcast31 into rows 2 and 3
+    MinIdx r; r.v = readlane_d(m.v, 63); r.i = __builtin_amdgcn_readlane(m.i, 63);
+    return r;
 }
 
 __global__ __launch_bounds__(256) void k_row_nn(const double* __restrict__ D, int64_t n, int* __restrict__ nb, double* __restrict__ md)
@@ -254,10 +281,10 @@ __global__ __launch_bounds__(LT) void k_linkage(double* D, int n, int* size, int
 //   4. meets the others at ONE device-scope barrier (agent-scope release before arriving, one relaxed poll,
 //      agent-scope acquire after; placement independent) and reduces the G slots, so all workgroups take the
 //      same decision without a broadcast.
-// A stale candidate (cl.cpp:329-338) costs one extra round in which every workgroup refreshes its own
-// submitted row if that one is stale.  Used for large N, where one CU's memory pipeline is the bottleneck.
+// A stale candidate (cl.cpp:329-338) costs one extra round (see the kernel's own header below).
+// Used from N = 1500 up, where one CU's memory pipeline is the bottleneck.
 #define MWT 256
-struct MwSlot { double nnv; double amv; int nni; int ami; int amy; int fresh; };
+#define MWT_MAX 1024
 // arg-min candidate that carries its neighbour and freshness along through the reductions
 struct Cand { double v; int i; int y; int fresh; };
 
@@ -300,13 +327,23 @@ __device__ __forceinline__ Cand cbetter(Cand a, Cand b)
     if (b.v == a.v && b.i < a.i) return b;
     return a;
 }
+template <int CTRL, int RM> __device__ __forceinline__ Cand dpp_step_c(Cand m)
+{
+    Cand t; t.v = dppd<CTRL, RM>(m.v); t.i = dppi<CTRL, RM>(m.i); t.y = dppi<CTRL, RM>(m.y); t.fresh = dppi<CTRL, RM>(m.fresh);
+    return cbetter(m, t);
+}
+__device__ __forceinline__ Cand wave_min_c(Cand m)
+{
+    m = dpp_step_c<0xB1, 0xF>(m); m = dpp_step_c<0x4E, 0xF>(m); m = dpp_step_c<0x141, 0xF>(m); m = dpp_step_c<0x140, 0xF>(m);
+    m = dpp_step_c<0x142, 0xA>(m); m = dpp_step_c<0x143, 0xC>(m);
+    Cand r; r.v = readlane_d(m.v, 63); r.i = __builtin_amdgcn_readlane(m.i, 63);
+    r.y = __builtin_amdgcn_readlane(m.y, 63); r.fresh = __builtin_amdgcn_readlane(m.fresh, 63);
+    return r;
+}
 __device__ __forceinline__ Cand block_min_c(Cand m, Cand* sh, int nwaves)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int o = 32; o > 0; o >>= 1) {
-        Cand t; t.v = __shfl_xor(m.v, o); t.i = __shfl_xor(m.i, o); t.y = __shfl_xor(m.y, o); t.fresh = __shfl_xor(m.fresh, o);
-        m = cbetter(m, t);
-    }
+    m = wave_min_c(m);
     __syncthreads();
     if (lane == 0) sh[w] = m;
     __syncthreads();
@@ -315,109 +352,254 @@ __device__ __forceinline__ Cand block_min_c(Cand m, Cand* sh, int nwaves)
     return r;
 }
 
-__global__ __launch_bounds__(MWT) void k_linkage_mw(double* D, int n, int* size_all /*[G][n] private copies*/, int* cid, int* nb, double* md,
-                                                    unsigned char* fresh_flag /*[n]: md[r] == D[r, nb[r]] known to hold*/, double* Z,
-                                                    MwSlot* slots /*[2][G]*/, unsigned* sync /*[0]=counter [1]=timeout [2]=retry rounds*/)
-{
-    __shared__ MinIdx sh[MWT / 64];
-    __shared__ Cand shc[MWT / 64];
-    const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
-    const int64_t N = n;
-    // every workgroup applies every merge to its OWN copy of the cluster sizes: a shared array would be
-    // written by fast workgroups while slow ones still read the pre-merge sizes
-    int* size = size_all + (size_t)g * n;
-    unsigned bar = 0;              // barriers passed so far
-    int par = 0;
-    auto barrier = [&]() -> bool { ++bar; return mw_barrier(&sync[0], bar * (unsigned)G, &sync[1]); };
-    // local arg-min over the owned active rows (optionally excluding one row); 4 rows in flight per thread
-    auto local_argmin = [&](int ex) -> Cand {
-        Cand m; m.v = INFINITY; m.i = -1; m.y = -1; m.fresh = 0;
-        for (int r0 = g + G * tid; r0 < n - 1; r0 += G * MWT * 4) {
-            double v[4]; int sz[4], ny_[4]; unsigned char fr[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * G * MWT; const int rc = r < n - 1 ? r : n - 2;
-                v[u] = md[rc]; sz[u] = size[rc]; ny_[u] = nb[rc]; fr[u] = fresh_flag[rc];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * G * MWT;
-                if (r < n - 1 && r != ex && sz[u] > 0 && (m.i < 0 || v[u] < m.v)) { m.v = v[u]; m.i = r; m.y = ny_[u]; m.fresh = fr[u]; }
-            }
-        }
-        return block_min_c(m, shc, MWT / 64);
-    };
-    // whole-row nearest-neighbour scan by this workgroup alone (rows it owns), 8 loads in flight per thread
-    auto own_row_nn = [&](int x) -> MinIdx {
-        MinIdx q = scan_row_nn<8>(D, size, N, n, x, tid, MWT);
-        return block_min_t(q, sh, MWT / 64);
-    };
-    auto reduce_slots = [&](int p, MinIdx& nn, Cand& am) {
-        MinIdx a; a.v = INFINITY; a.i = -1;
-        Cand b; b.v = INFINITY; b.i = -1; b.y = -1; b.fresh = 0;
-        for (int k = tid; k < G; k += MWT) {
-            const MwSlot sl = slots[p * G + k];
-            MinIdx t; t.v = sl.nnv; t.i = sl.nni; a = better(a, t);
-            Cand u; u.v = sl.amv; u.i = sl.ami; u.y = sl.amy; u.fresh = sl.fresh; b = cbetter(b, u);
-        }
-        nn = block_min_t(a, sh, MWT / 64);
-        am = block_min_c(b, shc, MWT / 64);
-    };
-    auto publish = [&](MinIdx q, Cand m) {
-        if (tid == 0) {
-            MwSlot sl; sl.nnv = q.v; sl.nni = q.i; sl.amv = m.v; sl.ami = m.i; sl.amy = m.y; sl.fresh = m.fresh;
-            slots[par * G + g] = sl;
-        }
-    };
+// ---------------------------------------------------------------- k_linkage_mw : the cooperative kernel
+//  * every workgroup keeps its owned ACTIVE rows as a compact list in LDS (swap-with-last removal), so the
+//    Lance-Williams pass and the arg-min touch N-k rows at merge k instead of N (half the random HBM accesses);
+//  * a stale candidate (cl.cpp:329-338) is not rescanned by its owner alone (one CU pulling a 1.4 MB row at
+//    N = 172 773 takes ~60 us): all workgroups see the same published candidates, pick the same KR best stale rows
+//    and each scans its share of the columns of every such row; the partial minima travel in the slots of the
+//    one barrier the round needs anyway.  Refreshing up to KR near-top stale rows per round needs ~5x fewer rounds
+//    than refreshing only the top one (measured 9.3 k vs 49 k rounds at N = 21 573).
+#define KR 8
+struct MwSlot { double nnv; double amv; int nni; int ami; int amy; int fresh; double pv[KR]; int pi[KR]; };
 
-    // initial state: k_row_nn produced exact bounds for every row
-    for (int r = g + G * tid; r < n - 1; r += G * MWT) fresh_flag[r] = 1;
-    __syncthreads();
+__global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* size_all, int* cid, int* nb, double* md,
+                                                         unsigned char* fresh_flag, double* Z, MwSlot* slots /*[2][G]*/,
+                                                         unsigned* sync, int cap /*owned rows per workgroup, upper bound*/)
+{
+    extern __shared__ int dyn_lds[];
+    int* act = dyn_lds;              // [cap] owned active rows, unordered
+    int* pos = dyn_lds + cap;        // [cap] pos[z / G] = index of owned row z in act
+    __shared__ MinIdx sh[MWT_MAX / 64];
+    __shared__ Cand shc[MWT_MAX / 64];
+    __shared__ MinIdx s_part[KR][MWT_MAX / 64];
+    __shared__ Cand s_cand[MWT + 1];        // published local bests of the G <= 256 workgroups (+ row y)
+    __shared__ MinIdx s_nnp[MWT];
+    __shared__ MinIdx s_row[KR];
+    __shared__ int s_L[2][KR];
+    __shared__ int s_nL[2];
+    __shared__ int s_cnt;
+    __shared__ Cand s_best;
+    __shared__ MinIdx s_nn;
+    const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x, lane = tid & 63, wv = tid >> 6;
+    const int T = blockDim.x, NW = T >> 6;
+    const int64_t N = n;
+    int* size = size_all + (size_t)g * n;
+    unsigned bar = 0;
+    int par = 0, lp = 0;             // slot parity, refresh-list parity
+    auto barrier = [&]() -> bool { ++bar; return mw_barrier(&sync[0], bar * (unsigned)G, &sync[1]); };
     MinIdx none; none.v = INFINITY; none.i = -1;
-    Cand m0 = local_argmin(-1);
-    int my_best = m0.i;
-    publish(none, m0);
-    if (!barrier()) return;
-    MinIdx nn; Cand am;
-    reduce_slots(par, nn, am);
-    par ^= 1;
-    int x = am.i, y = am.y; double dist = am.v; bool fresh = am.fresh != 0;
 #ifdef SD_LINKAGE_STAMPS
-    unsigned long long tS = __builtin_amdgcn_s_memrealtime(), acc[6] = {0, 0, 0, 0, 0, 0};
-#define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); acc[i] += t_ - tS; tS = t_; } while (0)
+    unsigned long long tS = __builtin_amdgcn_s_memrealtime(), acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP2(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); acc[i] += t_ - tS; tS = t_; } while (0)
 #else
-#define STAMP(i) do { } while (0)
+#define STAMP2(i) do { } while (0)
 #endif
 
+    // local arg-min over the owned active rows, skipping the rows being refreshed this round
+    auto local_argmin = [&](int nL, const int* L) -> Cand {
+        int ex[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) ex[r] = r < nL ? L[r] : -1;
+        Cand m; m.v = INFINITY; m.i = -1; m.y = -1; m.fresh = 0;
+        const int cnt = s_cnt;
+        for (int p0 = tid; p0 < cnt; p0 += T * 4) {
+            double v[4]; int zz[4], ny_[4]; unsigned char fr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u * T;
+                int z = p < cnt ? act[p] : -1;
+                if (z >= n - 1) z = -1;
+                zz[u] = z;
+                const int zc = z >= 0 ? z : 0;
+                v[u] = md[zc]; ny_[u] = nb[zc]; fr[u] = fresh_flag[zc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int z = zz[u];
+                bool skip = z < 0;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) skip |= (z == ex[r]);
+                if (!skip && (m.i < 0 || v[u] < m.v || (v[u] == m.v && z < m.i))) { m.v = v[u]; m.i = z; m.y = ny_[u]; m.fresh = fr[u]; }
+            }
+        }
+        return block_min_c(m, shc, NW);
+    };
+    // this workgroup's share of the columns of the nL rows in L: wave tasks (row r, sub-slice s)
+    auto scan_rows = [&](int nL, const int* L, MinIdx* outv /*LDS [KR]*/) {
+        if (nL <= 0) return;
+        const int S = NW >= nL ? NW / nL : 1;
+        for (int t = wv; t < nL * S; t += NW) {
+            const int r = t % nL, sidx = t / nL;
+            const int x = L[r];
+            const double* row = D + cidx(N, x, (int64_t)x + 1) - (x + 1);
+            MinIdx q = none;
+            const int64_t step = (int64_t)G * S * 64;
+            for (int64_t j0 = (int64_t)x + 1 + ((int64_t)g * S + sidx) * 64 + lane; j0 < n; j0 += step * 4) {
+                double v[4]; int sz[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t j = j0 + u * step; const int64_t jc = j < n ? j : n - 1;
+                    v[u] = row[jc]; sz[u] = size[jc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t j = j0 + u * step;
+                    if (j < n && sz[u] != 0 && v[u] < q.v) { q.v = v[u]; q.i = (int)j; }
+                }
+            }
+            q = wave_min(q);
+            if (lane == 0) s_part[r][sidx] = q;
+        }
+        __syncthreads();
+        if (tid < nL) {
+            MinIdx q = s_part[tid][0];
+            for (int k2 = 1; k2 < S; ++k2) q = better(q, s_part[tid][k2]);
+            outv[tid] = q;
+        }
+        __syncthreads();
+    };
+    auto publish = [&](MinIdx q, Cand m, int nL, const MinIdx* rows) {
+        MwSlot* sl = &slots[par * G + g];
+        if (tid == 0) { sl->nnv = q.v; sl->nni = q.i; sl->amv = m.v; sl->ami = m.i; sl->amy = m.y; sl->fresh = m.fresh; }
+        if (tid < nL) { sl->pv[tid] = rows[tid].v; sl->pi[tid] = rows[tid].i; }
+    };
+    // after a barrier: gather all slots; reduce the NN(y) partials, the refreshed rows, the global best; pick the next refresh list
+    auto digest = [&](int nLprev, const int* Lprev, int yrow, bool with_nn) {
+        const MwSlot* base = slots + (size_t)par * G;
+        if (tid < G) {
+            const MwSlot* sl = base + tid;
+            Cand c; c.v = sl->amv; c.i = sl->ami; c.y = sl->amy; c.fresh = sl->fresh; s_cand[tid] = c;
+            MinIdx a; a.v = sl->nnv; a.i = sl->nni; s_nnp[tid] = a;
+        }
+        if (wv < (nLprev + 1) / 2) {          // refreshed rows: 2 per wave (one per 32-lane half), all lanes active
+            const int r = tid >> 5, l = tid & 31;
+            MinIdx a = none, pl[8];
+            if (r < nLprev) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int u = l + 32 * e; const int uc = u < G ? u : 0; pl[e].v = base[uc].pv[r]; pl[e].i = u < G ? base[uc].pi[r] : -1; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = better(a, pl[e]);
+            }
+            a = half_min(a);
+            if (l == 31 && r < nLprev) s_row[r] = a;
+        }
+        __syncthreads();
+        if (wv == 0) {                 // global best over the published candidates and the rows refreshed in this round (now exact)
+            Cand b; b.v = INFINITY; b.i = -1; b.y = -1; b.fresh = 0;
+            for (int u = lane; u < G; u += 64) b = cbetter(b, s_cand[u]);
+            if (lane < nLprev) {
+                Cand c; c.i = Lprev[lane]; c.y = s_row[lane].i; c.v = (c.y < 0) ? INFINITY : s_row[lane].v; c.fresh = 1;
+                if (c.y >= 0) b = cbetter(b, c);
+            }
+            b = wave_min_c(b);
+            if (lane == 0) s_best = b;
+        } else if (wv == 1 && with_nn) {
+            MinIdx a = none;
+            for (int u = lane; u < G; u += 64) a = better(a, s_nnp[u]);
+            a = wave_min(a);
+            if (lane == 0) s_nn = a;
+        }
+        // owners store the refreshed rows (read back only by the owner's later arg-mins)
+        if (tid < nLprev && (Lprev[tid] % G) == g) {
+            const int x = Lprev[tid]; const MinIdx q = s_row[tid];
+            nb[x] = q.i; md[x] = (q.i < 0) ? INFINITY : q.v; fresh_flag[x] = 1;
+        }
+        __syncthreads();
+    };
+    // the next refresh list: the KR best stale candidates among s_cand[0..G) and `extra` (row y after a merge); wave 0
+    // extracts them one by one from registers, every workgroup arrives at the same list
+    auto pick_stale = [&](Cand extra, int slot) {
+        if (wv == 0) {
+            MinIdx c[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int idx = lane + 64 * u;
+                c[u] = none;
+                if (idx <= G) {
+                    Cand o = extra;
+                    if (idx < G) o = s_cand[idx];
+                    if (o.i >= 0 && !o.fresh && o.v != INFINITY) { c[u].v = o.v; c[u].i = o.i; }
+                }
+            }
+            // common case: at most KR stale candidates -> take them all (their order is irrelevant), no reduction needed
+            int nl = 0;
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const bool st = c[u].i >= 0;
+                const unsigned long long mk = __ballot(st);
+                const int at = nl + __popcll(mk & ((1ull << lane) - 1ull));
+                if (st && at < KR) s_L[slot][at] = c[u].i;
+                nl += __popcll(mk);
+            }
+            if (nl > KR) {                       // more than KR: the KR best by (bound, row)
+                nl = 0;
+                for (int r = 0; r < KR; ++r) {
+                    MinIdx bq = none;
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) bq = better(bq, c[u]);
+                    bq = wave_min(bq);
+                    if (bq.i < 0) break;
+                    if (lane == 0) s_L[slot][r] = bq.i;
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) if (c[u].i == bq.i) c[u].i = -1;
+                    nl = r + 1;
+                }
+            }
+            if (lane == 0) s_nL[slot] = nl;
+        }
+        __syncthreads();
+    };
+    Cand nocand; nocand.v = INFINITY; nocand.i = -1; nocand.y = -1; nocand.fresh = 1;
+
+    // ---- initial state: exact bounds from k_row_nn; owned rows g, g+G, ...
+    int cnt0 = 0;
+    for (int z = g + G * tid, i2 = tid; z < n; z += G * T, i2 += T) { act[i2] = z; pos[i2] = i2; if (z < n - 1) fresh_flag[z] = 1; }
+    if (tid == 0) { cnt0 = (n - g + G - 1) / G; if (cnt0 < 0) cnt0 = 0; s_cnt = cnt0; s_nL[0] = 0; s_nL[1] = 0; }
+    __syncthreads();
+    {
+        Cand m0 = local_argmin(0, s_L[0]);
+        publish(none, m0, 0, s_row);
+    }
+    if (!barrier()) return;
+    digest(0, s_L[0], -1, false);
+    par ^= 1;
+    Cand best = s_best;
+    if (!(best.fresh && best.y >= 0)) pick_stale(nocand, lp);
+    int x = best.i, y = best.y; double dist = best.v; bool fresh = best.fresh != 0;
+
     for (int k = 0; k < n - 1; ++k) {
-        // ---- lazy validation (cl.cpp:323-339), batched: while the global candidate is stale ("fresh" = its owner
-        // knows md[x] == D[x, nb[x]], cl.cpp:329), EVERY workgroup refreshes the row it submitted if that one is
-        // stale (one whole-row scan each, in parallel), then the arg-min is exchanged again.  The stale global
-        // candidate is one of those rows, so every round makes progress, and the other refreshed rows are
-        // near-top candidates the reference would soon have had to refresh too: ~5x fewer rounds than
-        // refreshing only the top row (measured 9.6 k vs 49 k rounds at N = 21 573).
+        // ---- lazy validation (cl.cpp:323-339): cooperative refresh of the KR best stale candidates per round
         for (int guard = 0; guard <= n - k; ++guard) {
             if (fresh && y >= 0) break;
             if (g == 0 && tid == 0) sync[2] += 1;            // diagnostic: retry rounds
-            if (my_best >= 0 && !fresh_flag[my_best] && md[my_best] != INFINITY) {
-                MinIdx q2 = own_row_nn(my_best);
-                if (tid == 0) { nb[my_best] = q2.i; md[my_best] = (q2.i < 0) ? INFINITY : q2.v; fresh_flag[my_best] = 1; }
-                __syncthreads();
-            }
-            Cand m = local_argmin(-1);
-            my_best = m.i;
-            publish(none, m);
+            const int nL = s_nL[lp]; const int* L = s_L[lp];
+            STAMP2(5);
+            scan_rows(nL, L, s_row);
+            STAMP2(0);
+            Cand m = local_argmin(nL, L);
+            publish(none, m, nL, s_row);
+            STAMP2(1);
             if (!barrier()) return;
-            reduce_slots(par, nn, am);
+            STAMP2(2);
+            digest(nL, L, -1, false);
             par ^= 1;
-            x = am.i; dist = am.v; y = am.y; fresh = am.fresh != 0;
+            best = s_best;
+            STAMP2(3);
+            lp ^= 1;
+            if (!(best.fresh && best.y >= 0)) pick_stale(nocand, lp);
+            STAMP2(4);
+            x = best.i; dist = best.v; y = best.y; fresh = best.fresh != 0;
         }
-        STAMP(0);   // validation / retry rounds
         // ---- merge (x, y) at height dist
         const int nx = size[x], ny = size[y];
         __syncthreads();
         if (tid == 0) {
-            size[x] = 0; size[y] = nx + ny;                   // every workgroup keeps its own view current
+            size[x] = 0; size[y] = nx + ny;
+            if ((x % G) == g) {                               // owner drops x from its active list
+                const int p = pos[x / G], c2 = s_cnt - 1, last = act[c2];
+                act[p] = last; pos[last / G] = p; s_cnt = c2;
+            }
             if (g == 0) {
                 int ix = cid[x], iy = cid[y];
                 if (ix > iy) { const int t = ix; ix = iy; iy = t; }
@@ -428,71 +610,77 @@ __global__ __launch_bounds__(MWT) void k_linkage_mw(double* D, int n, int* size_
         }
         __syncthreads();
         if (k == n - 2) break;
-        STAMP(1);   // bookkeeping
-        // One pass over the owned rows: Lance-Williams update + neighbour patches (cl.cpp:361-392), the
-        // nearest neighbour of row y from the freshly computed distances (cl.cpp:395-404), and the next
-        // local arg-min of the lower bounds.  All loads of a row are issued together (one latency).
+        // ---- one pass over the owned active rows: Lance-Williams update + neighbour patches (cl.cpp:361-392),
+        // NN(y) partial from the fresh distances (cl.cpp:395-404), next local arg-min
+        STAMP2(5);
         MinIdx q = none;
         Cand m; m.v = INFINITY; m.i = -1; m.y = -1; m.fresh = 0;
-        for (int z0 = g + G * tid; z0 < n; z0 += G * MWT * 4) {       // 4 rows per thread, all loads issued together
-            double dzx[4], dzy[4], mdz[4]; int sz[4], nbz[4], frz[4]; int64_t izy[4];
+        const int cnt = s_cnt;
+        int zdummy = 0;                                   // any valid row other than x and y (n >= 3 here)
+        while (zdummy == x || zdummy == y) ++zdummy;
+        for (int p0 = tid; p0 < cnt; p0 += T * 4) {
+            double dzx[4], dzy[4], mdz[4]; int zz[4], nbz[4], frz[4]; int64_t izy[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int z = z0 + u * G * MWT;
-                const int zc = (z < n && z != y) ? z : ((y > 0) ? 0 : 1);            // any valid row other than y
+                const int p = p0 + u * T;
+                int z = p < cnt ? act[p] : -1;
+                if (z == y) z = -1;
+                zz[u] = z;
+                const int zc = z >= 0 ? z : zdummy;
                 izy[u] = cidx(N, zc, y);
-                sz[u] = size[zc];
-                dzx[u] = (zc == x) ? 0.0 : D[cidx(N, zc, x)];
+                dzx[u] = D[cidx(N, zc, x)];
                 dzy[u] = D[izy[u]];
                 const int zr = zc < n - 1 ? zc : n - 2;
                 nbz[u] = nb[zr]; mdz[u] = md[zr]; frz[u] = fresh_flag[zr];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int z = z0 + u * G * MWT;
-                if (z >= n || z == y || sz[u] == 0) continue;
+                const int z = zz[u];
+                if (z < 0) continue;
                 const double nd = lw_centroid(dzx[u], dzy[u], dist, nx, ny);
                 D[izy[u]] = nd;
                 double mz = (z < n - 1) ? mdz[u] : INFINITY; int nz = nbz[u], fz = frz[u];
                 if (z < y) {
                     bool touch = false;
-                    if (z < x && nz == x) { nz = y; touch = true; }            // cl.cpp:374-378 (bound keeps its old value)
-                    else if (nz == y) touch = true;                              // the distance its bound refers to just changed
-                    if (nd < mz) { nz = y; mz = nd; fz = 1; md[z] = nd; nb[z] = y; fresh_flag[z] = 1; }   // cl.cpp:381-392
+                    if (z < x && nz == x) { nz = y; touch = true; }
+                    else if (nz == y) touch = true;
+                    if (nd < mz) { nz = y; mz = nd; fz = 1; md[z] = nd; nb[z] = y; fresh_flag[z] = 1; }
                     else if (touch) { fz = (mz == nd); nb[z] = nz; fresh_flag[z] = (unsigned char)fz; }
-                } else if (nd < q.v) { q.v = nd; q.i = z; }                     // z > y: candidate neighbour of row y (ascending z per thread)
-                if (z < n - 1 && (m.i < 0 || mz < m.v)) { m.v = mz; m.i = z; m.y = nz; m.fresh = fz; }
+                } else if (nd < q.v || (nd == q.v && z < q.i)) { q.v = nd; q.i = z; }
+                if (z < n - 1 && (m.i < 0 || mz < m.v || (mz == m.v && z < m.i))) { m.v = mz; m.i = z; m.y = nz; m.fresh = fz; }
             }
         }
-        STAMP(2);   // LW pass
-        q = block_min_t(q, sh, MWT / 64);
-        m = block_min_c(m, shc, MWT / 64);                   // row y itself is handled through q
-        my_best = m.i;
-        publish(q, m);
-        STAMP(3);   // block reductions + publish
+        STAMP2(6);
+        q = block_min_t(q, sh, NW);
+        m = block_min_c(m, shc, NW);
+        publish(q, m, 0, s_row);
+        STAMP2(7);
         if (!barrier()) return;
-        STAMP(4);   // barrier
-        reduce_slots(par, nn, am);
+        STAMP2(2);
+        digest(0, s_L[lp], y, true);
+        STAMP2(3);
         par ^= 1;
-        STAMP(5);   // slot reduction
-        double mdy; int nby; bool fy;
-        if (y < n - 1 && nn.i >= 0) {
-            mdy = nn.v; nby = nn.i; fy = true;                // exact by construction
-            if (tid == 0 && (y % G) == g) { nb[y] = nby; md[y] = mdy; fresh_flag[y] = 1; }
-        } else {
-            mdy = (y < n - 1) ? md[y] : INFINITY; nby = (y < n - 1) ? nb[y] : -1; fy = false;
-            if (tid == 0 && y < n - 1 && (y % G) == g) fresh_flag[y] = 0;
-        }
-        Cand best = am;
+        best = s_best;
+        const MinIdx nn = s_nn;
+        // row y: exact by construction when it has an active neighbour above (cl.cpp:395-404), else its old (stale) bound
+        Cand cy; cy.i = -1; cy.v = INFINITY; cy.y = -1; cy.fresh = 0;
         if (y < n - 1) {
-            if (best.i < 0 || mdy < best.v || (mdy == best.v && y < best.i)) { best.v = mdy; best.i = y; best.y = nby; best.fresh = fy; }
+            if (nn.i >= 0) {
+                cy.v = nn.v; cy.i = y; cy.y = nn.i; cy.fresh = 1;
+                if (tid == 0 && (y % G) == g) { nb[y] = nn.i; md[y] = nn.v; fresh_flag[y] = 1; }
+            } else {
+                cy.v = md[y]; cy.i = y; cy.y = nb[y]; cy.fresh = 0;
+                if (tid == 0 && (y % G) == g) fresh_flag[y] = 0;
+            }
+            if (best.i < 0 || cy.v < best.v || (cy.v == best.v && y < best.i)) best = cy;
         }
-        if ((y % G) == g && best.i != y) { /* row y competes in this workgroup's later local arg-mins through md[y] */ }
+        lp ^= 1;
+        if (!(best.fresh && best.y >= 0)) pick_stale(cy, lp);
+        STAMP2(4);
         x = best.i; dist = best.v; y = best.y; fresh = best.fresh != 0;
-        __syncthreads();
     }
 #ifdef SD_LINKAGE_STAMPS
-    if (g == 0 && tid == 0) for (int i = 0; i < 6; ++i) sync[8 + i] = (unsigned)(acc[i] / 100);   // microseconds
+    if (g == 0 && tid == 0) for (int i = 0; i < 8; ++i) sync[8 + i] = (unsigned)(acc[i] / 100);   // microseconds
 #endif
 }
 
@@ -557,13 +745,19 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         KCHECK(c);
     }
     int G = (int)c->linkage_wgs;
-    if (G < 0) G = (N >= 6000) ? 64 : 0;                  // auto: one workgroup below ~6k rows (measured crossover on clustered data)
+    if (G < 0) G = N >= 60000 ? 128 : N >= 15000 ? 64 : N >= 1500 ? 32 : 0;     // auto (measured on clustered data, profiles/r01_linkage_scaling.txt)
     if (G > c->num_cu) G = c->num_cu;
+    int TH = (int)c->linkage_threads;
+    if (TH <= 0) TH = 256;
+    TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : 256;
     if (G <= 1) {
         ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
         hipLaunchKernelGGL(k_linkage, dim3(1), dim3(LT), 0, c->stream, D, (int)N, size, cid, nb, md, d_Z);
         KCHECK(c);
     } else {
+        if ((N + G - 1) / G > 7000) G = (int)((N + 6999) / 7000);      // active-row lists live in LDS: 8 B per owned row
+        if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
+        int cap = (int)((N + G - 1) / G) + 1;
         WS(c, MwSlot, slots, "cl_slots", 2 * G);
         WS(c, int, size_all, "cl_size_all", (int64_t)G * N);
         WS(c, unsigned char, fresh_flag, "cl_fresh", N + 16);
@@ -573,7 +767,7 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         HIPCHK(c, hipMemsetAsync(sync, 0, 16 * sizeof(unsigned), c->stream));
         {
             ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
-            hipLaunchKernelGGL(k_linkage_mw, dim3(G), dim3(MWT), 0, c->stream, D, (int)N, size_all, cid, nb, md, fresh_flag, d_Z, slots, sync);
+            hipLaunchKernelGGL(k_linkage_mw, dim3(G), dim3(TH), (size_t)cap * 8, c->stream, D, (int)N, size_all, cid, nb, md, fresh_flag, d_Z, slots, sync, cap);
             KCHECK(c);
         }
         unsigned h[16] = {0};
@@ -583,7 +777,7 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         c->stats["linkage_retry_rounds"].flops += (double)h[2];
         c->stats["linkage_flag_conservative"].flops += (double)h[3];
 #ifdef SD_LINKAGE_STAMPS
-        fprintf(stderr, "linkage stamps (us): retry %u bookkeeping %u lw %u reductions %u barrier %u slots %u\n", h[8], h[9], h[10], h[11], h[12], h[13]);
+        fprintf(stderr, "linkage stamps (us): retry-scan %u retry-argmin %u barrier %u digest %u pick %u bookkeeping %u lw %u reductions %u\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
 #endif
     }
     return SD_OK;

@@ -101,6 +101,7 @@ struct sd_ctx {
     int num_clusters = -1, min_clusters = -1, max_clusters = -1;   // optional constraints for the whole-path entry points
     bool skip_dead_rows = true;                 // ECAPA: skip row panels beyond nvalid + receptive field
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
+    int64_t linkage_threads = 0;               // 0 auto (256, or 1024 for N >= 60000), else 256 / 512 / 1024 threads per cooperative workgroup
     int num_cu = 256;
 };
 

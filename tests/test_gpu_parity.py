@@ -185,6 +185,23 @@ def test_linkage_bit_exact(diarizer, N, d):
     assert np.array_equal(diarizer.cluster(X, cutoff), T_ref)
 
 
+@pytest.mark.parametrize("N,G,T", [(3, 2, 256), (65, 7, 512), (300, 64, 256), (300, 200, 1024), (2000, 16, 256), (2000, 32, 256), (5000, 64, 512)])
+def test_cooperative_linkage_bit_exact(diarizer, N, G, T):
+    """k_linkage_mw (G co-resident workgroups, LDS active-row lists, cooperative refresh of stale rows) gives the
+    oracle's dendrogram bit for bit for any workgroup count / size"""
+    rng = np.random.default_rng(1000 + N + G)
+    X = _blobs(rng, N)
+    _, Z_ref = orc.ahc(X, orc.THRESH_F32)
+    diarizer.set_option("linkage_wgs", G)
+    diarizer.set_option("linkage_threads", T)
+    try:
+        Z = diarizer.linkage(X)
+    finally:
+        diarizer.set_option("linkage_wgs", -1)
+        diarizer.set_option("linkage_threads", 0)
+    assert np.array_equal(Z, Z_ref)
+
+
 def test_linkage_with_exact_ties_gives_same_partition(diarizer):
     # duplicate rows: the heap's order for exactly equal candidates is not reproduced (DESIGN.md);
     # the flat clustering must still agree

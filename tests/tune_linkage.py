@@ -16,20 +16,22 @@ def blobs(N):
 for N in (2, 3, 65, 300, 2000):
     X = blobs(N)
     _, Zr = orc.ahc(X, 0.7)
-    for G in (0, 2, 7, 64):
+    for G, TH, AL in ((0, 0, 2), (2, 256, 2), (7, 512, 2), (64, 256, 2), (64, 1024, 2), (200, 256, 2), (7, 256, 1)):
         d.set_option("linkage_wgs", G)
+        d.set_option("linkage_threads", TH)
         Z = d.linkage(X)
-        print("N=%d G=%d bit-equal %s" % (N, G, np.array_equal(Z, Zr)), flush=True)
+        print("N=%d G=%d T=%d algo=%d bit-equal %s" % (N, G, TH, AL, np.array_equal(Z, Zr)), flush=True)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 21573
 X = blobs(N)
 d.set_option("profile", 1)
 Z0 = None
-for G in (0, 32, 64):
+for G, TH, AL in ((0, 0, 2), (64, 256, 1), (32, 256, 2), (64, 256, 2), (64, 512, 2), (64, 1024, 2), (128, 256, 2)):
     d.set_option("linkage_wgs", G)
+    d.set_option("linkage_threads", TH)
     d.reset_stats()
     t = time.time(); Z = d.linkage(X); t1 = time.time() - t
     st = d.kernel_stats("linkage")
     if Z0 is None: Z0 = Z
     rr = d.kernel_stats("linkage_retry_rounds")["flops"]
     print("   flag-conservative exits:", d.kernel_stats("linkage_flag_conservative")["flops"])
-    print("N=%d G=%3d linkage kernel %.1f ms (%.2f us/merge) wall %.2f s  same-as-G0 %s retry_rounds %d" % (N, G, st["ms"], st["ms"] * 1e3 / (N - 1), t1, np.array_equal(Z, Z0), rr), flush=True)
+    print("N=%d G=%3d T=%d algo=%d linkage kernel %.1f ms (%.2f us/merge) wall %.2f s  same-as-G0 %s retry_rounds %d" % (N, G, TH, AL, st["ms"], st["ms"] * 1e3 / (N - 1), t1, np.array_equal(Z, Z0), rr), flush=True)
