@@ -44,6 +44,7 @@ struct ConvArgs {
     const float* X; const float* X2; const float* W; float* Y;
     const float* bias; const float* scale; const float* shift; const float* item_bias; const float* R;
     int x_ld, x2_ld, y_ld, r_ld, ib_ld;
+    int w_ld;              // floats between consecutive output-channel rows of W (0 = Cin)
     int M;                 // total output rows
     int TpIn, TpOut;       // rows per item in input / output buffers
     int Tin, T;            // valid rows per item in input / output

@@ -38,7 +38,7 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte a
 #define SD_CONV_SCHED_DEFAULT 3
 
 // DBG (micro-benchmark ablations only, never used by the pipeline): 1 = no epilogue stores,
-// 2 = no global loads inside the K loop, 3 = no LDS restaging / barrier inside the K loop
+// 2 = no global loads inside the K loop, 3 = no LDS restaging / barrier inside the K loop, 4 = loads always hit the same cached slices
 template <bool HAS_X2, int DBG>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 {
@@ -84,14 +84,35 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     const int half = a.KT / 2;
 
     // ---- load stream state (runs one K-step ahead of the compute stream) ----
-    int item_base[4], tt[4];
-    size_t wrow[4];
-    const float* pa[4]; const float* pb[4]; const float* px[4];
+    // All global reads are buffer loads: a per-tile resource descriptor in SGPRs, a per-lane byte offset that only
+    // changes with the tap, and the K position as the instruction's scalar offset -- moving to the next K-step is
+    // one scalar add instead of twelve 64-bit vector pointer increments on the MFMA issue path.
+    int rrel[4], tt[4];                 // per part: item offset (rows) relative to the tile's first item, clamped frame
+    unsigned voA[4], voX[HAS_X2 ? 4 : 1], voB[4];
+    const size_t in_rows = (size_t)((a.M + a.TpOut - 1) / a.TpOut) * a.TpIn;
+    auto make_rsrc = [&](const float* base, size_t bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t rA = make_rsrc(a.X, 0), rX = make_rsrc(a.X, 0);
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(a.W, (size_t)a.KT * a.Cout * a.w_ld * sizeof(float));
+#pragma unroll
+    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)(((r0 + 32 * p) * a.w_ld + c4 * 4) * (int)sizeof(float));
     int l_q = q0, l_kk = 0, l_kc = 0, m0l = 0, n0l = 0;
+    // K always runs 0 .. Cin-1 in the same order for every tile: a row's result does not depend on where its tile sits
+    // in the schedule (sharded and unsharded runs, full and dead-row-skipping runs stay bit-identical).  [Tried and
+    // dropped: starting each workgroup of a super-block at a different K-chunk plus a per-tile rendezvous -- it lifts
+    // the 3072x3072 layer's L2 hit rate from 27 % to 73 % (the L2 answers sharers that ask for a line at the same moment
+    // with one miss each: fabric read requests == L2 misses) but not its speed, and it breaks that invariance.]
+    unsigned sK = 0, sB = 0;            // scalar byte offsets: K position, start of this tap's / tile's W rows
     auto set_tile = [&](int sb) {
         int j, nt;
         (void)sb_valid(sb, j, nt);
-        m0l = (a.mlist ? a.mlist[xcd * a.mlist_ld + j] : (xcd + 8 * j)) * BM; n0l = nt * BN;
+        m0l = __builtin_amdgcn_readfirstlane((a.mlist ? a.mlist[xcd * a.mlist_ld + j] : (xcd + 8 * j)) * BM);   // wave-uniform: keeps the descriptors in SGPRs
+        n0l = __builtin_amdgcn_readfirstlane(nt * BN);
+        const int b0 = m0l / a.TpOut;
+        const size_t row0 = (size_t)b0 * a.TpIn;
+        rA = make_rsrc(a.X + row0 * a.x_ld, (in_rows - row0) * a.x_ld * sizeof(float));
+        if (HAS_X2) rX = make_rsrc(a.X2 + row0 * a.x2_ld, (in_rows - row0) * a.x2_ld * sizeof(float));
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int g = m0l + r0 + 32 * p;
@@ -99,14 +120,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
             const int b = g / a.TpOut;
             int t = g - b * a.TpOut;
             if (t > a.T - 1) t = a.T - 1;
-            item_base[p] = b * a.TpIn;
+            rrel[p] = (b - b0) * a.TpIn;
             tt[p] = t;
-            int co = n0l + r0 + 32 * p;
-            if (co > a.Cout - 1) co = a.Cout - 1;
-            wrow[p] = (size_t)co * a.Cin;
         }
     };
-    auto set_tap = [&](int kk) {          // pointers of K-chunk 0 of tap kk (reflect / valid row map)
+    auto set_tap = [&](int kk) {          // per-lane offsets of tap kk (reflect / valid row map)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int qr;
@@ -119,19 +137,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                 qr = tt[p] + kk * a.dil;
                 if (qr > a.Tin - 1) qr = a.Tin - 1;
             }
-            const size_t row = (size_t)(item_base[p] + qr);
-            pa[p] = a.X + row * a.x_ld + c4 * 4;
-            if (HAS_X2) px[p] = a.X2 + row * a.x2_ld + c4 * 4;
-            pb[p] = a.W + (size_t)kk * a.Cout * a.Cin + wrow[p] + c4 * 4;
+            const unsigned row = (unsigned)(rrel[p] + qr);
+            voA[p] = (row * (unsigned)a.x_ld + c4 * 4) * (unsigned)sizeof(float);
+            if (HAS_X2) voX[p] = (row * (unsigned)a.x2_ld + c4 * 4) * (unsigned)sizeof(float);
         }
+        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * sizeof(float));
     };
     auto advance = [&]() {                // move the load stream to the next K-step
-        if (++l_kc < kcs) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) { pa[p] += BK; pb[p] += BK; if (HAS_X2) px[p] += BK; }
-            return;
-        }
-        l_kc = 0;
+        if (DBG == 4) return;             // ablation: every step re-loads the first slices (cache hits, no HBM traffic)
+        if (++l_kc < kcs) { sK += BK * sizeof(float); return; }
+        l_kc = 0; sK = 0;
         if (++l_kk == a.KT) {
             l_kk = 0;
             const int nq = next_sb(l_q);
@@ -140,15 +155,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         set_tap(l_kk);
     };
 
-    f4u ra[4], rb[4];
+    f4u ra[4], rb[4], rx[HAS_X2 ? 4 : 1];
     auto gload_part = [&](int p) {
-        ra[p] = *(const f4u*)pa[p];
-        if (HAS_X2) { const f4u v2 = *(const f4u*)px[p]; ra[p] += v2; }
-        rb[p] = *(const f4u*)pb[p];
+        const unsigned sKa = (DBG == 6) ? 0u : sK, sKb = (DBG == 5) ? 0u : sB + sK;     // ablations 5 / 6: W resp. X slices always cached
+        ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p], sKa, 0));
+        if (HAS_X2) rx[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rX, voX[p], sKa, 0));
+        rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sKb, 0));
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
+            if (HAS_X2) ra[p] += rx[p];          // the add waits for the loads: keep it next to the LDS store
             *(float4*)&As[buf][(r0 + 32 * p) * LDP + c4 * 4] = make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]);
             *(float4*)&Bs[buf][(r0 + 32 * p) * LDP + c4 * 4] = make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]);
         }
@@ -164,15 +181,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 
     const int aoff = (wr * 64 + li) * LDP + lh * 16;
     const int boff = (wc * 64 + li) * LDP + lh * 16;
-    auto mma = [&](int buf, int qq) {
+    // Operand fragments are double-buffered in registers: the ds_reads of K-group qq+1 are issued before the
+    // 16 MFMAs of group qq, so no MFMA waits on LDS latency (the scheduler is pinned with sched_barriers; left
+    // alone it sinks the global loads to the end of the step, right in front of their ds_writes).
+    float4 fa[2][2], fb[2][2];
+    auto lfrag = [&](int buf, int qq, int fbuf) {
         const float* Ab = &As[buf][aoff];
         const float* Bb = &Bs[buf][boff];
-        const float4 a0 = *(const float4*)(Ab + qq * 4);
-        const float4 a1 = *(const float4*)(Ab + 32 * LDP + qq * 4);
-        const float4 b0 = *(const float4*)(Bb + qq * 4);
-        const float4 b1 = *(const float4*)(Bb + 32 * LDP + qq * 4);
-        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-        const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+        fa[fbuf][0] = *(const float4*)(Ab + qq * 4);
+        fa[fbuf][1] = *(const float4*)(Ab + 32 * LDP + qq * 4);
+        fb[fbuf][0] = *(const float4*)(Bb + qq * 4);
+        fb[fbuf][1] = *(const float4*)(Bb + 32 * LDP + qq * 4);
+    };
+    auto mma16 = [&](int fbuf) {
+        const float av0[4] = {fa[fbuf][0].x, fa[fbuf][0].y, fa[fbuf][0].z, fa[fbuf][0].w}, av1[4] = {fa[fbuf][1].x, fa[fbuf][1].y, fa[fbuf][1].z, fa[fbuf][1].w};
+        const float bv0[4] = {fb[fbuf][0].x, fb[fbuf][0].y, fb[fbuf][0].z, fb[fbuf][0].w}, bv1[4] = {fb[fbuf][1].x, fb[fbuf][1].y, fb[fbuf][1].z, fb[fbuf][1].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
@@ -191,16 +214,51 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     lstore(0);
     __syncthreads();
     advance();
+    lfrag(0, 0, 0);
 
     int q = q0, s = 0, buf = 0;
     while (true) {
         const int cb = (DBG == 3) ? 0 : buf;
-        // one basic block: the next step's global loads are spread between the four MFMA groups
-        mma(cb, 0); if (DBG < 2) gload_part(0);
-        mma(cb, 1); if (DBG < 2) gload_part(1);
-        mma(cb, 2); if (DBG < 2) gload_part(2);
-        mma(cb, 3); if (DBG < 2) gload_part(3);
-        if (DBG < 3) { lstore(buf ^ 1); __syncthreads(); }
+        // one K step.  On entry fragment set 0 holds K-group 0 of this step.  Inside each scheduling region the
+        // memory instructions are interleaved one by one with the MFMAs (sched_group_barrier: 0x008 MFMA, 0x020 VMEM
+        // read, 0x100 DS read, 0x200 DS write): a bunch of 4-8 back-to-back VMEM/DS issues takes longer than the 64
+        // cycles one MFMA keeps the pipe busy and leaves a bubble.
+#define SGB_PAIR(mask, n) do { _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); } } while (0)
+        lfrag(cb, 1, 1);
+        if (DBG < 2) { gload_part(0); gload_part(1); }
+        mma16(0);
+        SGB_PAIR(0x100, 4);
+        if (HAS_X2) { SGB_PAIR(0x020, 6); __builtin_amdgcn_sched_group_barrier(0x008, 6, 0); }
+        else {
+#pragma unroll
+            for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lfrag(cb, 2, 0);
+        if (DBG < 2) { gload_part(2); gload_part(3); }
+        mma16(1);
+        SGB_PAIR(0x100, 4);
+        if (HAS_X2) { SGB_PAIR(0x020, 6); __builtin_amdgcn_sched_group_barrier(0x008, 6, 0); }
+        else {
+#pragma unroll
+            for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lfrag(cb, 3, 1);
+        if (DBG < 3) lstore(buf ^ 1);        // restage: the next step's tile slices go to the other LDS buffer
+        mma16(0);
+        SGB_PAIR(0x100, 4);
+        SGB_PAIR(0x200, 8);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // after the barrier the next step's K-group 0 is fetched while this step's last 16 MFMAs (operands already
+        // in registers) run
+        if (DBG < 3) { __syncthreads(); lfrag(buf ^ 1, 0, 0); }
+        else lfrag(0, 0, 0);
+        mma16(1);
+        SGB_PAIR(0x100, 4);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
         const int m0n = m0l, n0n = n0l;           // origin of the tile the load stream is on
         advance();
 
@@ -315,6 +373,7 @@ static int conv_grid(sd_ctx* c, const ConvArgs& a)
 int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
 {
     ConvArgs a = in;
+    if (a.w_ld <= 0) a.w_ld = a.Cin;
     if (a.Cin % BK != 0) SD_FAIL(c, SD_ERR_ARG, "conv_gemm(%s): Cin=%d not a multiple of %d", tag, a.Cin, BK);
     if (a.M <= 0) return SD_OK;
     a.m_tiles = (a.M + BM - 1) / BM;
@@ -350,17 +409,20 @@ extern "C" int sd_bench_conv(sd_ctx* c, int64_t items, int Tp, int T, int Cin, i
     c->err.clear();
     if (hipSetDevice(c->device) != hipSuccess) return SD_ERR_HIP;
     const int64_t M = items * Tp;
-    WS(c, float, X, "bc_X", M * Cin);
-    WS(c, float, X2, "bc_X2", has_x2 ? M * Cin : 16);
-    WS(c, float, W, "bc_W", (int64_t)KT * Cout * Cin);
-    WS(c, float, Y, "bc_Y", M * Cout);
+    const int pad = (dbg / 100) * 32;         // dbg = 100*pad_units + 10*(sched+1) + ablation: leading dimensions padded by pad floats
+    dbg %= 100;
+    const int xld = Cin + pad, wld = Cin + pad, yld = Cout + pad;
+    WS(c, float, X, "bc_X", M * xld);
+    WS(c, float, X2, "bc_X2", has_x2 ? M * xld : 16);
+    WS(c, float, W, "bc_W", (int64_t)KT * Cout * wld);
+    WS(c, float, Y, "bc_Y", M * yld);
     WS(c, float, B, "bc_B", 3 * Cout);
-    hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)((M * Cin + 255) / 256)), dim3(256), 0, c->stream, X, M * Cin, 1u);
-    if (has_x2) hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)((M * Cin + 255) / 256)), dim3(256), 0, c->stream, X2, M * Cin, 2u);
-    hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)(((int64_t)KT * Cout * Cin + 255) / 256)), dim3(256), 0, c->stream, W, (int64_t)KT * Cout * Cin, 3u);
+    hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)((M * xld + 255) / 256)), dim3(256), 0, c->stream, X, M * xld, 1u);
+    if (has_x2) hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)((M * xld + 255) / 256)), dim3(256), 0, c->stream, X2, M * xld, 2u);
+    hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)(((int64_t)KT * Cout * wld + 255) / 256)), dim3(256), 0, c->stream, W, (int64_t)KT * Cout * wld, 3u);
     hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)((3 * Cout + 255) / 256)), dim3(256), 0, c->stream, B, (int64_t)3 * Cout, 4u);
     ConvArgs a; memset(&a, 0, sizeof(a));
-    a.X = X; a.x_ld = Cin; a.X2 = has_x2 ? X2 : nullptr; a.x2_ld = Cin; a.W = W; a.Y = Y; a.y_ld = Cout;
+    a.X = X; a.x_ld = xld; a.X2 = has_x2 ? X2 : nullptr; a.x2_ld = xld; a.W = W; a.w_ld = wld; a.Y = Y; a.y_ld = yld;
     a.bias = B; a.scale = B + Cout; a.shift = B + 2 * Cout; a.act1 = 1;
     a.M = (int)M; a.TpIn = a.TpOut = Tp; a.Tin = a.T = T; a.Cin = Cin; a.Cout = Cout; a.KT = KT; a.dil = dil; a.pad_mode = 0;
     a.m_tiles = (a.M + BM - 1) / BM; a.n_tiles = (a.Cout + BN - 1) / BN;
@@ -370,7 +432,7 @@ extern "C" int sd_bench_conv(sd_ctx* c, int64_t items, int Tp, int T, int Cin, i
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
 #define LAUNCH_V(X2, D) hipLaunchKernelGGL((k_conv_gemm<X2, D>), dim3(grid), dim3(256), 0, c->stream, a)
-#define LAUNCH_S(X2) do { if (dbg == 0) LAUNCH_V(X2, 0); else if (dbg == 1) LAUNCH_V(X2, 1); else if (dbg == 2) LAUNCH_V(X2, 2); else LAUNCH_V(X2, 3); } while (0)
+#define LAUNCH_S(X2) do { if (dbg == 0) LAUNCH_V(X2, 0); else if (dbg == 1) LAUNCH_V(X2, 1); else if (dbg == 2) LAUNCH_V(X2, 2); else if (dbg == 3) LAUNCH_V(X2, 3); else if (dbg == 4) LAUNCH_V(X2, 4); else if (dbg == 5) LAUNCH_V(X2, 5); else LAUNCH_V(X2, 6); } while (0)
     for (int r = -2; r < reps; ++r) {
         if (r == 0) HIPCHK(c, hipEventRecord(e0, c->stream));
         if (has_x2) LAUNCH_S(true); else LAUNCH_S(false);
