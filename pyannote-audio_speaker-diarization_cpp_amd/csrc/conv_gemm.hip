@@ -38,7 +38,7 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte a
 #define SD_CONV_SCHED_DEFAULT 3
 
 // DBG (micro-benchmark ablations only, never used by the pipeline): 1 = no epilogue stores,
-// 2 = no global loads inside the K loop, 3 = no LDS restaging / barrier inside the K loop, 4 = loads always hit the same cached slices
+// 2 = no global loads inside the K loop, 3 = no LDS restaging / barrier inside the K loop
 template <bool HAS_X2, int DBG>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 {
@@ -144,7 +144,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * sizeof(float));
     };
     auto advance = [&]() {                // move the load stream to the next K-step
-        if (DBG == 4) return;             // ablation: every step re-loads the first slices (cache hits, no HBM traffic)
         if (++l_kc < kcs) { sK += BK * sizeof(float); return; }
         l_kc = 0; sK = 0;
         if (++l_kk == a.KT) {
@@ -157,10 +156,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 
     f4u ra[4], rb[4], rx[HAS_X2 ? 4 : 1];
     auto gload_part = [&](int p) {
-        const unsigned sKa = (DBG == 6) ? 0u : sK, sKb = (DBG == 5) ? 0u : sB + sK;     // ablations 5 / 6: W resp. X slices always cached
-        ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p], sKa, 0));
-        if (HAS_X2) rx[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rX, voX[p], sKa, 0));
-        rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sKb, 0));
+        ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p], sK, 0));
+        if (HAS_X2) rx[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rX, voX[p], sK, 0));
+        rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sB + sK, 0));
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -432,7 +430,7 @@ extern "C" int sd_bench_conv(sd_ctx* c, int64_t items, int Tp, int T, int Cin, i
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
 #define LAUNCH_V(X2, D) hipLaunchKernelGGL((k_conv_gemm<X2, D>), dim3(grid), dim3(256), 0, c->stream, a)
-#define LAUNCH_S(X2) do { if (dbg == 0) LAUNCH_V(X2, 0); else if (dbg == 1) LAUNCH_V(X2, 1); else if (dbg == 2) LAUNCH_V(X2, 2); else if (dbg == 3) LAUNCH_V(X2, 3); else if (dbg == 4) LAUNCH_V(X2, 4); else if (dbg == 5) LAUNCH_V(X2, 5); else LAUNCH_V(X2, 6); } while (0)
+#define LAUNCH_S(X2) do { if (dbg == 0) LAUNCH_V(X2, 0); else if (dbg == 1) LAUNCH_V(X2, 1); else if (dbg == 2) LAUNCH_V(X2, 2); else LAUNCH_V(X2, 3); } while (0)
     for (int r = -2; r < reps; ++r) {
         if (r == 0) HIPCHK(c, hipEventRecord(e0, c->stream));
         if (has_x2) LAUNCH_S(true); else LAUNCH_S(false);
