@@ -31,6 +31,7 @@ for p in (ROOT, PKG):
 HOUR = 3600
 SR = 16000
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+F16_MFMA_PEAK_TFLOPS = 2500.0         # same table: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
 def cpu_baseline(ws, we, seconds):
@@ -62,6 +63,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hours-per-gpu", type=float, default=1.0)
     ap.add_argument("--cpu-seconds", type=int, default=20, help="audio seconds for the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="f32 = the measured configuration (f32 MFMA); f16 = "
+                    "BASELINE configs[4]: ECAPA conv layers on the fp16 MFMA with f32 accumulation (secondary, tolerance-checked mode)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) | gloo (plumbing test of the multi-rank code "
                     "on a box with fewer GPUs than ranks: gathers go through host memory, ranks may share a GPU)")
     a = ap.parse_args()
@@ -94,6 +97,8 @@ def main():
     nn.save_pack(os.path.join(tmp, "segment.sdw"), ws)
     nn.save_pack(os.path.join(tmp, "embedding.sdw"), we)
     d = sdhip.Diarizer(os.path.join(tmp, "segment.sdw"), os.path.join(tmp, "embedding.sdw"), local)
+    if a.precision == "f16":
+        d.set_option("ecapa_precision", 1)
 
     # ---- the job: `world` x hours_per_gpu of audio; rank r owns a contiguous, 32-aligned chunk range
     per_samples = int(round(a.hours_per_gpu * HOUR * SR))
@@ -174,8 +179,9 @@ def main():
             s = d.kernel_stats(k)
             extra[k] = {"ms_per_step": round(s["ms"] / max(a.steps, 1), 3), "launches_per_step": s["launches"] // max(a.steps, 1)}
         traffic, traffic_src = None, None
+        peak = F32_MFMA_PEAK_TFLOPS if a.precision == "f32" else F16_MFMA_PEAK_TFLOPS
         pmc_path = os.path.join(ROOT, "profiles", "pmc_conv_gemm_bench.json")
-        if world == 1 and os.path.exists(pmc_path):
+        if world == 1 and a.precision == "f32" and os.path.exists(pmc_path):
             try:
                 pj = json.load(open(pmc_path))
                 traffic, traffic_src = pj["bytes_per_launch"], pj["source"]
@@ -188,7 +194,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "%g h synthetic 16 kHz mono per GPU (%g h total), full pipeline: PyanNet segmentation + "
                                    "post-seg + STFT/fbank + ECAPA-TDNN + centroid AHC + reconstruction" % (a.hours_per_gpu, audio_s / HOUR),
                        "audio_seconds": audio_s, "chunks": C, "embedding_items": 3 * C,
@@ -196,9 +202,9 @@ def main():
                        "sharding": "contiguous chunk ranges of %d per rank, RCCL all-gather of scores+embeddings, clustering on rank 0" % per,
                        "turns": len(turns_box[0] or []),
                        "stage_ms_last_step": {"segmentation": round(stages[0], 1), "embedding": round(stages[1], 1), "clustering": round(stages[2], 1)}},
-            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_conv_gemm (v_mfma_f32_32x32x2_f32)", "launches_per_step": cg["launches"] // max(a.steps, 1),
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_conv_gemm (v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else "k_conv_gemm (v_mfma_f32_32x32x16_f16; segmentation and skinny layers stay f32)", "launches_per_step": cg["launches"] // max(a.steps, 1),
                          "kernel_ms_per_step": round(cg["ms"] / max(a.steps, 1), 2),
                          "algorithmic_gflop_per_step": round(cg["flops"] / max(a.steps, 1) / 1e9, 1)},
             "other_kernels": extra,

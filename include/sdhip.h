@@ -151,7 +151,7 @@ int sd_stage_ms(const sd_ctx*, double* ms4);
 int sd_kernel_stats(const sd_ctx*, const char* kernel, double* total_ms, int64_t* launches, double* flops, double* bytes);
 void sd_reset_stats(sd_ctx*);
 /* keys: "emb_batch_items", "seg_batch_chunks", "profile", "linkage_wgs" (-1 auto, 0 one workgroup), "linkage_threads",
- * "skip_dead_rows", "num_clusters", "min_clusters", "max_clusters" */
+ * "skip_dead_rows", "num_clusters", "min_clusters", "max_clusters", "ecapa_precision" (0 = f32 MFMA, 1 = fp16 MFMA) */
 int sd_set_option(sd_ctx*, const char* key, int64_t value);
 /* tuning hook (tools/tune_conv.py): time one conv_gemm shape on scratch data; dbg selects an ablation */
 int sd_bench_barrier(sd_ctx*, int workgroups, int iters, int dirty_doubles, double* us_per_barrier);

@@ -34,6 +34,7 @@ struct DevBuf {
 // a conv / linear layer in device layout
 struct ConvLayer {
     float* W = nullptr;       // [KT][Cout][CinPad] (Cin contiguous)
+    void* W16 = nullptr;      // the same weights rounded to fp16 (ECAPA conv layers only; option ecapa_precision = 1)
     float* bias = nullptr;    // [Cout] or null
     float* scale = nullptr;   // folded BatchNorm (applied after act1) or null
     float* shift = nullptr;
@@ -42,6 +43,7 @@ struct ConvLayer {
 
 struct ConvArgs {
     const float* X; const float* X2; const float* W; float* Y;
+    const void* W16;       // optional fp16 copy of W (same layout)
     const float* bias; const float* scale; const float* shift; const float* item_bias; const float* R;
     int x_ld, x2_ld, y_ld, r_ld, ib_ld;
     int w_ld;              // floats between consecutive output-channel rows of W (0 = Cin)
@@ -100,6 +102,7 @@ struct sd_ctx {
     int64_t emb_batch_items = 768;             // multiple of 96
     int64_t seg_batch_chunks = 4096;           // 128 LSTM workgroups per direction: one full wave of CUs
     int num_clusters = -1, min_clusters = -1, max_clusters = -1;   // optional constraints for the whole-path entry points
+    int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation
     bool skip_dead_rows = true;                 // ECAPA: skip row panels beyond nvalid + receptive field
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
     int64_t linkage_threads = 0;               // 0 auto (256, or 1024 for N >= 60000), else 256 / 512 / 1024 threads per cooperative workgroup

@@ -39,7 +39,14 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte a
 
 // DBG (micro-benchmark ablations only, never used by the pipeline): 1 = no epilogue stores,
 // 2 = no global loads inside the K loop, 3 = no LDS restaging / barrier inside the K loop
-template <bool HAS_X2, int DBG>
+// F16 (BASELINE.json configs[4], option "ecapa_precision" = 1): the same kernel with v_mfma_f32_32x32x16_f16 -- weights
+// come from an fp16 copy, activations stay f32 in HBM and are rounded to fp16 (RNE) on their way into LDS, accumulation
+// and the whole epilogue stay f32.  16x less MFMA time per K-step: that variant is bound by the load / LDS path.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#define LDH 40            // fp16 LDS row: 32 halves + 8 pad = 80 B (ds_read_b128 of 8 consecutive rows hits 8 distinct 4-bank groups)
+template <bool HAS_X2, int DBG, bool F16>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 {
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDP];
@@ -94,9 +101,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
     };
     __amdgpu_buffer_rsrc_t rA = make_rsrc(a.X, 0), rX = make_rsrc(a.X, 0);
-    const __amdgpu_buffer_rsrc_t rB = make_rsrc(a.W, (size_t)a.KT * a.Cout * a.w_ld * sizeof(float));
+    constexpr int WB = F16 ? 2 : 4;     // bytes per weight element
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(F16 ? (const float*)a.W16 : a.W, (size_t)a.KT * a.Cout * a.w_ld * WB);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)(((r0 + 32 * p) * a.w_ld + c4 * 4) * (int)sizeof(float));
+    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)(((r0 + 32 * p) * a.w_ld + c4 * 4) * WB);
     int l_q = q0, l_kk = 0, l_kc = 0, m0l = 0, n0l = 0;
     // K always runs 0 .. Cin-1 in the same order for every tile: a row's result does not depend on where its tile sits
     // in the schedule (sharded and unsharded runs, full and dead-row-skipping runs stay bit-identical).  [Tried and
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
             voA[p] = (row * (unsigned)a.x_ld + c4 * 4) * (unsigned)sizeof(float);
             if (HAS_X2) voX[p] = (row * (unsigned)a.x2_ld + c4 * 4) * (unsigned)sizeof(float);
         }
-        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * sizeof(float));
+        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * WB);
     };
     auto advance = [&]() {                // move the load stream to the next K-step
         if (++l_kc < kcs) { sK += BK * sizeof(float); return; }
@@ -154,18 +162,32 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         set_tap(l_kk);
     };
 
-    f4u ra[4], rb[4], rx[HAS_X2 ? 4 : 1];
+    f4u ra[4], rb[F16 ? 1 : 4], rx[HAS_X2 ? 4 : 1];
+    u32x2 rbh[F16 ? 4 : 1];
     auto gload_part = [&](int p) {
         ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p], sK, 0));
         if (HAS_X2) rx[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rX, voX[p], sK, 0));
-        rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sB + sK, 0));
+        if constexpr (F16) rbh[p] = __builtin_amdgcn_raw_buffer_load_b64(rB, voB[p], sB + (sK >> 1), 0);
+        else rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sB + sK, 0));
     };
+    _Float16* const Ah = (_Float16*)&As[0][0];       // fp16 view of the same LDS: 2 buffers of BM x LDH halves each
+    _Float16* const Bh = (_Float16*)&Bs[0][0];
     auto lstore = [&](int buf) {
+        if constexpr (F16) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if (HAS_X2) ra[p] += rx[p];          // the add waits for the loads: keep it next to the LDS store
-            *(float4*)&As[buf][(r0 + 32 * p) * LDP + c4 * 4] = make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]);
-            *(float4*)&Bs[buf][(r0 + 32 * p) * LDP + c4 * 4] = make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]);
+            for (int p = 0; p < 4; ++p) {
+                if (HAS_X2) ra[p] += rx[p];
+                const half4 h = {(_Float16)ra[p][0], (_Float16)ra[p][1], (_Float16)ra[p][2], (_Float16)ra[p][3]};
+                *(half4*)&Ah[buf * BM * LDH + (r0 + 32 * p) * LDH + c4 * 4] = h;
+                *(u32x2*)&Bh[buf * BN * LDH + (r0 + 32 * p) * LDH + c4 * 4] = rbh[p];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (HAS_X2) ra[p] += rx[p];          // the add waits for the loads: keep it next to the LDS store
+                *(float4*)&As[buf][(r0 + 32 * p) * LDP + c4 * 4] = make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]);
+                *(float4*)&Bs[buf][(r0 + 32 * p) * LDP + c4 * 4] = make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]);
+            }
         }
     };
 
@@ -203,6 +225,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         }
     };
 
+    // fp16 variant of one K-step: 2 k-blocks of 16, 8 MFMAs; lane (li, lh) holds k = 16 kb + 8 lh .. +7 of row li
+    auto step16 = [&](int buf) {
+        const _Float16* Ab = Ah + buf * BM * LDH + (wr * 64 + li) * LDH + lh * 8;
+        const _Float16* Bb = Bh + buf * BN * LDH + (wc * 64 + li) * LDH + lh * 8;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const half8 a0 = *(const half8*)(Ab + kb * 16), a1 = *(const half8*)(Ab + 32 * LDH + kb * 16);
+            const half8 b0 = *(const half8*)(Bb + kb * 16), b1 = *(const half8*)(Bb + 32 * LDH + kb * 16);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    };
+
     // prologue: stage step 0 of the first tile
     set_tile(l_q);
     set_tap(0);
@@ -212,11 +249,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     lstore(0);
     __syncthreads();
     advance();
-    lfrag(0, 0, 0);
+    if constexpr (!F16) lfrag(0, 0, 0);
 
     int q = q0, s = 0, buf = 0;
     while (true) {
         const int cb = (DBG == 3) ? 0 : buf;
+        if constexpr (F16) {
+            gload_part(0); gload_part(1); gload_part(2); gload_part(3);
+            step16(buf);
+            lstore(buf ^ 1);
+            __syncthreads();
+        } else {
         // one K step.  On entry fragment set 0 holds K-group 0 of this step.  Inside each scheduling region the
         // memory instructions are interleaved one by one with the MFMAs (sched_group_barrier: 0x008 MFMA, 0x020 VMEM
         // read, 0x100 DS read, 0x200 DS write): a bunch of 4-8 back-to-back VMEM/DS issues takes longer than the 64
@@ -257,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         SGB_PAIR(0x100, 4);
         __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         __builtin_amdgcn_sched_barrier(0);
+        }
         const int m0n = m0l, n0n = n0l;           // origin of the tile the load stream is on
         advance();
 
@@ -385,8 +429,12 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     const double flops = 2.0 * rows * a.Cout * cin * a.KT;
     const double bytes = 4.0 * (rows * cin * (a.X2 ? 2 : 1) + rows * a.Cout + (double)a.Cout * cin * a.KT);
     ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
-    if (a.X2) hipLaunchKernelGGL((k_conv_gemm<true, 0>), dim3(grid), dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_conv_gemm<false, 0>), dim3(grid), dim3(256), 0, c->stream, a);
+    const bool f16 = c->ecapa_precision == 1 && a.W16 != nullptr;
+    if (f16) {
+        if (a.X2) hipLaunchKernelGGL((k_conv_gemm<true, 0, true>), dim3(grid), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_conv_gemm<false, 0, true>), dim3(grid), dim3(256), 0, c->stream, a);
+    } else if (a.X2) hipLaunchKernelGGL((k_conv_gemm<true, 0, false>), dim3(grid), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_conv_gemm<false, 0, false>), dim3(grid), dim3(256), 0, c->stream, a);
     KCHECK(c);
     return SD_OK;
 }
@@ -429,7 +477,7 @@ extern "C" int sd_bench_conv(sd_ctx* c, int64_t items, int Tp, int T, int Cin, i
     const int grid = conv_grid(c, a);
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
-#define LAUNCH_V(X2, D) hipLaunchKernelGGL((k_conv_gemm<X2, D>), dim3(grid), dim3(256), 0, c->stream, a)
+#define LAUNCH_V(X2, D) hipLaunchKernelGGL((k_conv_gemm<X2, D, false>), dim3(grid), dim3(256), 0, c->stream, a)
 #define LAUNCH_S(X2) do { if (dbg == 0) LAUNCH_V(X2, 0); else if (dbg == 1) LAUNCH_V(X2, 1); else if (dbg == 2) LAUNCH_V(X2, 2); else LAUNCH_V(X2, 3); } while (0)
     for (int r = -2; r < reps; ++r) {
         if (r == 0) HIPCHK(c, hipEventRecord(e0, c->stream));

@@ -126,7 +126,7 @@ static ConvArgs conv_args(const ConvLayer& L, const float* X, int x_ld, float* Y
 {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.X = X; a.x_ld = x_ld; a.Y = Y; a.y_ld = y_ld; a.W = L.W;
+    a.X = X; a.x_ld = x_ld; a.Y = Y; a.y_ld = y_ld; a.W = L.W; a.W16 = L.W16;
     a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.M = (int)M;
     if (per_item) { a.TpIn = a.TpOut = SD_TP; a.Tin = a.T = SD_T; }

@@ -61,7 +61,7 @@ template <class T> static T* upload(sd_ctx* c, const std::vector<T>& h)
 // optional input-channel slice [ci0, ci0+cin) of the source tensor
 static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const std::string& bname,
                      const std::string& bnprefix, int dil, ConvLayer& L, int ci0 = 0, int cin = -1,
-                     const std::vector<float>* in_scale = nullptr, const std::vector<float>* in_shift = nullptr)
+                     const std::vector<float>* in_scale = nullptr, const std::vector<float>* in_shift = nullptr, bool want16 = false)
 {
     const PackTensor* w = need(c, p, wname);
     if (!w) return SD_ERR_MODEL;
@@ -92,6 +92,13 @@ static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const s
             }
     L.W = upload(c, hw);
     if (!L.W) return SD_ERR_HIP;
+    L.W16 = nullptr;
+    if (want16) {                          // fp16 copy, round to nearest even
+        std::vector<_Float16> h16(hw.size());
+        for (size_t i = 0; i < hw.size(); ++i) h16[i] = (_Float16)hw[i];
+        L.W16 = upload(c, h16);
+        if (!L.W16) return SD_ERR_HIP;
+    }
     L.bias = nullptr;
     if (has_bias) { L.bias = upload(c, hb); if (!L.bias) return SD_ERR_HIP; }
     L.scale = L.shift = nullptr;
@@ -146,28 +153,28 @@ int build_ecapa_weights(sd_ctx* c, const Pack& p)
     if (!E.mel_w || !E.mel_lo || !E.mel_cnt || !E.mel_off || !E.window || !E.tw_cos || !E.tw_nsin) return SD_ERR_HIP;
 
     int rc;
-    if ((rc = make_conv(c, p, "blocks.0.conv.weight", "blocks.0.conv.bias", "blocks.0.norm", 1, E.block0))) return rc;
+    if ((rc = make_conv(c, p, "blocks.0.conv.weight", "blocks.0.conv.bias", "blocks.0.norm", 1, E.block0, 0, -1, nullptr, nullptr, true))) return rc;
     E.C = E.block0.Cout;
     const int dils[3] = {2, 3, 4};
     for (int b = 0; b < 3; ++b) {
         std::string pre = "blocks." + std::to_string(b + 1);
         auto& B = E.blk[b];
         B.dil = dils[b];
-        if ((rc = make_conv(c, p, pre + ".tdnn1.conv.weight", pre + ".tdnn1.conv.bias", pre + ".tdnn1.norm", 1, B.tdnn1))) return rc;
+        if ((rc = make_conv(c, p, pre + ".tdnn1.conv.weight", pre + ".tdnn1.conv.bias", pre + ".tdnn1.norm", 1, B.tdnn1, 0, -1, nullptr, nullptr, true))) return rc;
         for (int i = 0; i < 7; ++i) {
             std::string q = pre + ".res2net." + std::to_string(i);
-            if ((rc = make_conv(c, p, q + ".conv.weight", q + ".conv.bias", q + ".norm", dils[b], B.res[i]))) return rc;
+            if ((rc = make_conv(c, p, q + ".conv.weight", q + ".conv.bias", q + ".norm", dils[b], B.res[i], 0, -1, nullptr, nullptr, true))) return rc;
         }
-        if ((rc = make_conv(c, p, pre + ".tdnn2.conv.weight", pre + ".tdnn2.conv.bias", pre + ".tdnn2.norm", 1, B.tdnn2))) return rc;
+        if ((rc = make_conv(c, p, pre + ".tdnn2.conv.weight", pre + ".tdnn2.conv.bias", pre + ".tdnn2.norm", 1, B.tdnn2, 0, -1, nullptr, nullptr, true))) return rc;
         if ((rc = make_conv(c, p, pre + ".se.conv1.weight", pre + ".se.conv1.bias", "", 1, B.se1))) return rc;
         if ((rc = make_conv(c, p, pre + ".se.conv2.weight", pre + ".se.conv2.bias", "", 1, B.se2))) return rc;
     }
-    if ((rc = make_conv(c, p, "mfa.conv.weight", "mfa.conv.bias", "mfa.norm", 1, E.mfa))) return rc;
+    if ((rc = make_conv(c, p, "mfa.conv.weight", "mfa.conv.bias", "mfa.norm", 1, E.mfa, 0, -1, nullptr, nullptr, true))) return rc;
     const int C3 = E.mfa.Cout;
     // ASP tdnn over cat[x, mean, std]: split into the x part and the (mean,std) part
-    if ((rc = make_conv(c, p, "asp.tdnn.conv.weight", "asp.tdnn.conv.bias", "asp.tdnn.norm", 1, E.asp_tdnn_x, 0, C3))) return rc;
+    if ((rc = make_conv(c, p, "asp.tdnn.conv.weight", "asp.tdnn.conv.bias", "asp.tdnn.norm", 1, E.asp_tdnn_x, 0, C3, nullptr, nullptr, true))) return rc;
     if ((rc = make_conv(c, p, "asp.tdnn.conv.weight", "", "", 1, E.asp_tdnn_ms, C3, 2 * C3))) return rc;
-    if ((rc = make_conv(c, p, "asp.conv.weight", "asp.conv.bias", "", 1, E.asp_conv))) return rc;
+    if ((rc = make_conv(c, p, "asp.conv.weight", "asp.conv.bias", "", 1, E.asp_conv, 0, -1, nullptr, nullptr, true))) return rc;
     // asp_bn (eval BatchNorm on the pooled vector) folded into fc
     {
         const PackTensor *g = need(c, p, "asp_bn.weight"), *be = need(c, p, "asp_bn.bias"),

@@ -136,6 +136,29 @@ def test_ecapa_dead_row_skipping_is_invisible(diarizer, weights):
     np.testing.assert_allclose(e_skip, e_ref, rtol=RTOL, atol=ATOL)
 
 
+def test_ecapa_fp16_mfma_within_reference_tolerance(diarizer, weights):
+    """BASELINE.json configs[4]: ECAPA conv layers on the fp16 MFMA (fp16 weights, activations rounded to fp16 on the
+    way into LDS, f32 accumulation) against the f32 oracle.  Bar: embedding cosine distance <= 1e-3 (north star /
+    verifyEveryStepResult.py); the element-wise tolerance of the f32 path does not apply to a 10-bit mantissa."""
+    rng = np.random.default_rng(21)
+    lens = np.array([1.0, 0.5, 0.25, 0.9, 0.7, 0.33, 1.0, 0.6], np.float32)
+    feats = (3.0 * rng.standard_normal((len(lens), 501, 80))).astype(np.float32)
+    e32 = diarizer.ecapa(feats, lens)
+    diarizer.set_option("ecapa_precision", 1)
+    try:
+        e16 = diarizer.ecapa(feats, lens)
+    finally:
+        diarizer.set_option("ecapa_precision", 0)
+    e_ref = nn.EcapaOracle(weights[3])(feats, lens).numpy().astype(np.float64)
+    assert np.isfinite(e16).all() and not np.array_equal(e16, e32)      # the fp16 kernels really ran
+    g = e16.astype(np.float64)
+    cos = (g * e_ref).sum(1) / np.linalg.norm(g, axis=1) / np.linalg.norm(e_ref, axis=1)
+    assert (1 - cos).max() < 1e-3, (1 - cos).max()
+    rel = np.linalg.norm(g - e_ref, axis=1) / np.linalg.norm(e_ref, axis=1)
+    assert rel.max() < 2e-2, rel.max()
+    assert np.array_equal(diarizer.ecapa(feats, lens), e32)                 # and the f32 path is back, bit for bit
+
+
 def test_embed_parity(diarizer, weights):
     rng = np.random.default_rng(4)
     wav, masks = _wav_and_masks(rng, 100)
