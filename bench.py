@@ -178,6 +178,10 @@ def main():
         for k in ("stft_mel", "lstm_rec", "pdist", "linkage", "row_nn", "se_apply", "asp_pool"):
             s = d.kernel_stats(k)
             extra[k] = {"ms_per_step": round(s["ms"] / max(a.steps, 1), 3), "launches_per_step": s["launches"] // max(a.steps, 1)}
+            if k == "stft_mel" and s["ms"] > 0:       # front end (north star: HBM GB/s for the STFT): algorithmic bytes of SURVEY 8(d), 481 492 B per live item
+                extra[k].update({"hbm_GBps_algorithmic": round(s["bytes"] / s["ms"] / 1e6, 1), "hbm_frac_of_8TBps": round(s["bytes"] / s["ms"] / 1e6 / 8000.0, 4),
+                                 "fp64_mfma_TFLOPs": round(s["flops"] / s["ms"] / 1e9, 1), "fp64_mfma_frac_of_78.6": round(s["flops"] / s["ms"] / 1e9 / 78.6, 3),
+                                 "bound": "fp64 MFMA (400-point DFT as GEMM), not HBM, at this size"})
         traffic, traffic_src = None, None
         peak = F32_MFMA_PEAK_TFLOPS if a.precision == "f32" else F16_MFMA_PEAK_TFLOPS
         pmc_path = os.path.join(ROOT, "profiles", "pmc_conv_gemm_bench.json")
