@@ -401,6 +401,70 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     }
 }
 
+// ---------------------------------------------------------------- k_skinny_gemm
+// The per-utterance layers (SE bottleneck 1024->128->1024, ASP statistics bias 6144->128, fc 6144->192) have one row per
+// item: a 128x128 tile grid keeps 6-48 workgroups busy for a K of up to 6144.  Here one workgroup owns a 32x32 output
+// tile, its 4 waves split K and accumulate a 32x32 partial each with MFMA operands read straight from global memory;
+// the partials are added in wave order through LDS (deterministic), wave 0 runs the epilogue.
+__global__ __launch_bounds__(256) void k_skinny_gemm(ConvArgs a)
+{
+    __shared__ float part[3][16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    int row = m0 + li; if (row > a.M - 1) row = a.M - 1;
+    int col = n0 + li; if (col > a.Cout - 1) col = a.Cout - 1;
+    const float* pa = a.X + (size_t)row * a.x_ld + lh * 4;
+    const float* pb = a.W + (size_t)col * a.w_ld + lh * 4;
+    const int Kq = ((a.Cin / 4 + 7) / 8) * 8;
+    const int k0 = w * Kq, k1 = (k0 + Kq < a.Cin) ? k0 + Kq : a.Cin;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    int k = k0;
+    for (; k + 32 <= k1; k += 32) {                   // 4 x (8 k) per trip: 8 loads in flight per lane
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { av[u] = *(const float4*)(pa + k + 8 * u); bv[u] = *(const float4*)(pb + k + 8 * u); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+        }
+    }
+    for (; k < k1; k += 8) {
+        const float4 av = *(const float4*)(pa + k), bv = *(const float4*)(pb + k);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[w - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (w != 0) return;
+    const int co = n0 + li;
+    const bool col_ok = co < a.Cout;
+    const float cb = (a.bias && col_ok) ? a.bias[co] : 0.0f;
+    const float cs = (a.scale && col_ok) ? a.scale[co] : 1.0f, ch = (a.scale && col_ok) ? a.shift[co] : 0.0f;
+    const float slope = (a.act1 == 1) ? 0.0f : ((a.act1 == 2) ? 0.01f : 1.0f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = ((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane];      // fixed order: waves 0,1,2,3
+        v += cb;
+        v = v > 0.0f ? v : v * slope;
+        v = v * cs + ch;
+        if (a.act2 == 1) v = tanhf(v);
+        else if (a.act2 == 2) v = 1.0f / (1.0f + expf(-v));
+        const int g = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;          // C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        if (g < a.M && col_ok) a.Y[(size_t)g * a.y_ld + co] = v;
+    }
+}
+
 static int conv_grid(sd_ctx* c, const ConvArgs& a)
 {
     int g = 2 * c->num_cu;
@@ -418,6 +482,15 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     if (a.w_ld <= 0) a.w_ld = a.Cin;
     if (a.Cin % BK != 0) SD_FAIL(c, SD_ERR_ARG, "conv_gemm(%s): Cin=%d not a multiple of %d", tag, a.Cin, BK);
     if (a.M <= 0) return SD_OK;
+    if (a.KT == 1 && a.M <= 2048 && a.TpIn == a.M && a.TpOut == a.M && a.T == a.M && a.Tin == a.M && !a.X2 && !a.item_bias && !a.R && !a.mlist &&
+        (a.x_ld & 3) == 0 && (a.w_ld & 3) == 0) {
+        const int cinr = a.cin_real > 0 ? a.cin_real : a.Cin;
+        ProfScope ps(c, c->profile_detail ? std::string("skinny_gemm:") + tag : std::string("skinny_gemm"), 2.0 * a.M * a.Cout * cinr,
+                     4.0 * ((double)a.M * cinr + (double)a.M * a.Cout + (double)a.Cout * cinr));
+        hipLaunchKernelGGL(k_skinny_gemm, dim3((a.M + 31) / 32, (a.Cout + 31) / 32), dim3(256), 0, c->stream, a);
+        KCHECK(c);
+        return SD_OK;
+    }
     a.m_tiles = (a.M + BM - 1) / BM;
     a.n_tiles = (a.Cout + BN - 1) / BN;
     a.sched = SD_CONV_SCHED_DEFAULT;

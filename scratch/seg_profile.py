@@ -13,7 +13,7 @@ names = ["chunk_norm", "pool_norm", "lstm_rec", "classifier", "stft_mel", "fbank
          "cluster_means", "assign", "mask_prefix", "wav_lens", "compact_active", "nan_rows", "scatter_emb", "binarize_masks", "count", "activations", "topk"]
 tags = ["sinc0", "sinc1", "sinc2", "lstm_ih", "lin0", "lin1", "block0", "tdnn1", "tdnn2", "res2net", "se1", "se2", "mfa", "asp_tdnn", "asp_tdnn_ms", "asp_conv", "fc", "blk_tdnn1", "blk_tdnn2", "res", "asp_ms"]
 tot = 0
-for n in names + ["conv_gemm:" + t for t in tags]:
+for n in names + ["conv_gemm:" + t for t in tags] + ["skinny_gemm:" + t for t in tags]:
     s = d.kernel_stats(n)
     if s["launches"]:
         tot += s["ms"]
