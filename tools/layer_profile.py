@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Per-kernel / per-layer HIP-event profile (option profile = 2) of one 1 h diarization: tools/layer_profile.py"""
 import os, sys, tempfile, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "pyannote-audio_speaker-diarization_cpp_amd"))
