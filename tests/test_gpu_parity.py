@@ -366,3 +366,48 @@ def test_full_size_linkage_properties(diarizer):
     sub = X[:3000]
     from scipy.spatial.distance import pdist
     assert Z[0, 2] <= pdist(sub).min() + 1e-15
+
+
+def test_full_size_one_hour_whole_path_properties(diarizer):
+    """BASELINE.json configs[2] (1 h synthetic, the bench workload) through the C ABI: the run is deterministic, a 4-way
+    chunk-range split (the 4-GPU plan, exercised on one GPU) reproduces it turn for turn, the stage outputs have the
+    reference's geometry, and the rows the reference would overwrite with NaN are exactly the NaN rows."""
+    import sdhip
+    import synth
+    pcm = synth.make_pcm(3600.0, seed=1234)
+    n = len(pcm)
+    C, _ = sdhip.num_chunks(n)
+    assert C == 7191                                                   # SURVEY 8 size table
+    dev = torch.device("cuda", 0)
+    d_pcm = torch.from_numpy(pcm).to(dev)
+    torch.cuda.synchronize()
+    whole = diarizer.diarize_dev(d_pcm.data_ptr(), n)
+    assert whole == diarizer.diarize_dev(d_pcm.data_ptr(), n)
+    starts = [t[0] for t in whole]
+    assert starts == sorted(starts)                                    # Annotation::finalResult order (sd.cpp:962-978)
+    assert all(0.0 <= t[0] < t[1] <= 3600.0 + 0.02 for t in whole)
+    seg = torch.zeros((C, 293, 3), dtype=torch.float32, device=dev)
+    emb = torch.zeros((C * 3, 192), dtype=torch.float32, device=dev)
+    per, ranges = sdhip.plan_shards(n, 4)
+    assert per % 32 == 0
+    for lo, hi in ranges:
+        s0, s1 = sdhip.shard_sample_range(lo, hi, n)
+        shard = d_pcm[s0:s1].contiguous()
+        torch.cuda.synchronize()
+        diarizer.shard_infer_dev(shard.data_ptr(), s0, s1 - s0, n, lo, hi, seg[lo:].data_ptr(), emb[lo * 3:].data_ptr())
+    assert diarizer.finalize_dev(seg.data_ptr(), emb.data_ptr(), C, n) == whole
+    # NaN rows == the reference's "too short" rule evaluated by the oracle on the same scores (sd.cpp:2479-2549)
+    seg_h = seg.cpu().numpy()
+    assert ((seg_h >= 0) & (seg_h <= 1)).all()
+    b = orc.binarize(seg_h)
+    masks = orc.select_masks(b)
+    idx = (np.arange(80000, dtype=np.int64) * 293) // 80000            # Helper::interpolate, sd.cpp:746-767
+    per_frame = np.bincount(idx, minlength=293)                        # samples each mask frame selects
+    counts = ((masks > 0.5) * per_frame[None, :]).sum(1).astype(np.int64)
+    bad = np.zeros(3 * C, bool)
+    for b0 in range(0, 3 * C, 32):
+        _, ts, an = orc.wav_lens(counts[b0:b0 + 32])
+        bad[b0:b0 + 32] = ts | an
+    assert np.array_equal(np.isnan(emb.cpu().numpy()[:, 0]), bad)
+    cnt, _, _ = orc.speaker_count(b)
+    assert len(cnt) == int(sdhip.lib().sd_count_frames(C))
