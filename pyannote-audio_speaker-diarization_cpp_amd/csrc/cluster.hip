@@ -278,9 +278,9 @@ __global__ __launch_bounds__(LT) void k_linkage(double* D, int n, int* size, int
 //   2. runs the Lance-Williams update for its rows, folding the nearest-neighbour search of row y into the
 //      same pass (the new D[z,y], z > y, are in registers: row y is never re-read),
 //   3. computes its local arg-min of the lower bounds and publishes {NN(y) partial, arg-min} in a slot,
-//   4. meets the others at ONE device-scope barrier (agent-scope release before arriving, one relaxed poll,
-//      agent-scope acquire after; placement independent) and reduces the G slots, so all workgroups take the
-//      same decision without a broadcast.
+//   4. meets the others at ONE device-scope barrier (a counter; everything the workgroups hand each other travels in
+//      agent-scope `sc1` loads / stores, see LDG / STG below, so no L2 write-back / invalidate is needed; placement
+//      independent) and reduces the G slots, so all workgroups take the same decision without a broadcast.
 // A stale candidate (cl.cpp:329-338) costs one extra round (see the kernel's own header below).
 // Used from N = 1500 up, where one CU's memory pipeline is the bottleneck.
 #define MWT 256
@@ -303,6 +303,30 @@ __device__ __forceinline__ bool mw_barrier(unsigned* counter, unsigned target, u
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    return ok;
+}
+
+// Cross-workgroup data of the cooperative kernel (distance matrix, bounds, neighbours, slots) is moved with agent-scope
+// relaxed atomics only: on gfx950 these are `sc1` loads / stores (write-through past the per-XCD L2, loads that do not
+// trust a non-coherent line).  Every wave drains its stores (the workgroup barrier's release does `s_waitcnt vmcnt(0)`)
+// before thread 0 arrives at the counter, so no agent-scope release / acquire -- an L2 write-back and a full L2
+// invalidate per merge -- is needed, and each workgroup's private state (cluster sizes, freshness flags) stays cached.
+template <class T> __device__ __forceinline__ T LDG(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void STG(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool mw_barrier_nf(unsigned* counter, unsigned target, unsigned* timeout_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's write-through stores have been acknowledged
+    __syncthreads();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 26)) { *timeout_flag = 1; ok = false; break; }
+        }
     }
     __syncthreads();
     return ok;
@@ -387,7 +411,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     int* size = size_all + (size_t)g * n;
     unsigned bar = 0;
     int par = 0, lp = 0;             // slot parity, refresh-list parity
-    auto barrier = [&]() -> bool { ++bar; return mw_barrier(&sync[0], bar * (unsigned)G, &sync[1]); };
+    auto barrier = [&]() -> bool { ++bar; return mw_barrier_nf(&sync[0], bar * (unsigned)G, &sync[1]); };
     MinIdx none; none.v = INFINITY; none.i = -1;
 #ifdef SD_LINKAGE_STAMPS
     unsigned long long tS = __builtin_amdgcn_s_memrealtime(), acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -440,7 +464,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int64_t j = j0 + u * step; const int64_t jc = j < n ? j : n - 1;
-                    v[u] = row[jc]; sz[u] = size[jc];
+                    v[u] = LDG(&row[jc]); sz[u] = size[jc];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -461,23 +485,23 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     };
     auto publish = [&](MinIdx q, Cand m, int nL, const MinIdx* rows) {
         MwSlot* sl = &slots[par * G + g];
-        if (tid == 0) { sl->nnv = q.v; sl->nni = q.i; sl->amv = m.v; sl->ami = m.i; sl->amy = m.y; sl->fresh = m.fresh; }
-        if (tid < nL) { sl->pv[tid] = rows[tid].v; sl->pi[tid] = rows[tid].i; }
+        if (tid == 0) { STG(&sl->nnv, q.v); STG(&sl->nni, q.i); STG(&sl->amv, m.v); STG(&sl->ami, m.i); STG(&sl->amy, m.y); STG(&sl->fresh, m.fresh); }
+        if (tid < nL) { STG(&sl->pv[tid], rows[tid].v); STG(&sl->pi[tid], rows[tid].i); }
     };
     // after a barrier: gather all slots; reduce the NN(y) partials, the refreshed rows, the global best; pick the next refresh list
     auto digest = [&](int nLprev, const int* Lprev, int yrow, bool with_nn) {
         const MwSlot* base = slots + (size_t)par * G;
         if (tid < G) {
             const MwSlot* sl = base + tid;
-            Cand c; c.v = sl->amv; c.i = sl->ami; c.y = sl->amy; c.fresh = sl->fresh; s_cand[tid] = c;
-            MinIdx a; a.v = sl->nnv; a.i = sl->nni; s_nnp[tid] = a;
+            Cand c; c.v = LDG(&sl->amv); c.i = LDG(&sl->ami); c.y = LDG(&sl->amy); c.fresh = LDG(&sl->fresh); s_cand[tid] = c;
+            MinIdx a; a.v = LDG(&sl->nnv); a.i = LDG(&sl->nni); s_nnp[tid] = a;
         }
         if (wv < (nLprev + 1) / 2) {          // refreshed rows: 2 per wave (one per 32-lane half), all lanes active
             const int r = tid >> 5, l = tid & 31;
             MinIdx a = none, pl[8];
             if (r < nLprev) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const int u = l + 32 * e; const int uc = u < G ? u : 0; pl[e].v = base[uc].pv[r]; pl[e].i = u < G ? base[uc].pi[r] : -1; }
+                for (int e = 0; e < 8; ++e) { const int u = l + 32 * e; const int uc = u < G ? u : 0; pl[e].v = LDG(&base[uc].pv[r]); pl[e].i = u < G ? LDG(&base[uc].pi[r]) : -1; }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a = better(a, pl[e]);
             }
@@ -503,7 +527,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         // owners store the refreshed rows (read back only by the owner's later arg-mins)
         if (tid < nLprev && (Lprev[tid] % G) == g) {
             const int x = Lprev[tid]; const MinIdx q = s_row[tid];
-            nb[x] = q.i; md[x] = (q.i < 0) ? INFINITY : q.v; fresh_flag[x] = 1;
+            STG(&nb[x], q.i); STG(&md[x], (q.i < 0) ? (double)INFINITY : q.v); fresh_flag[x] = 1;
         }
         __syncthreads();
     };
@@ -628,8 +652,8 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                 zz[u] = z;
                 const int zc = z >= 0 ? z : zdummy;
                 izy[u] = cidx(N, zc, y);
-                dzx[u] = D[cidx(N, zc, x)];
-                dzy[u] = D[izy[u]];
+                dzx[u] = LDG(&D[cidx(N, zc, x)]);
+                dzy[u] = LDG(&D[izy[u]]);
                 const int zr = zc < n - 1 ? zc : n - 2;
                 nbz[u] = nb[zr]; mdz[u] = md[zr]; frz[u] = fresh_flag[zr];
             }
@@ -638,14 +662,14 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                 const int z = zz[u];
                 if (z < 0) continue;
                 const double nd = lw_centroid(dzx[u], dzy[u], dist, nx, ny);
-                D[izy[u]] = nd;
+                STG(&D[izy[u]], nd);
                 double mz = (z < n - 1) ? mdz[u] : INFINITY; int nz = nbz[u], fz = frz[u];
                 if (z < y) {
                     bool touch = false;
                     if (z < x && nz == x) { nz = y; touch = true; }
                     else if (nz == y) touch = true;
-                    if (nd < mz) { nz = y; mz = nd; fz = 1; md[z] = nd; nb[z] = y; fresh_flag[z] = 1; }
-                    else if (touch) { fz = (mz == nd); nb[z] = nz; fresh_flag[z] = (unsigned char)fz; }
+                    if (nd < mz) { nz = y; mz = nd; fz = 1; STG(&md[z], nd); STG(&nb[z], y); fresh_flag[z] = 1; }
+                    else if (touch) { fz = (mz == nd); STG(&nb[z], nz); fresh_flag[z] = (unsigned char)fz; }
                 } else if (nd < q.v || (nd == q.v && z < q.i)) { q.v = nd; q.i = z; }
                 if (z < n - 1 && (m.i < 0 || mz < m.v || (mz == m.v && z < m.i))) { m.v = mz; m.i = z; m.y = nz; m.fresh = fz; }
             }
@@ -667,9 +691,9 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         if (y < n - 1) {
             if (nn.i >= 0) {
                 cy.v = nn.v; cy.i = y; cy.y = nn.i; cy.fresh = 1;
-                if (tid == 0 && (y % G) == g) { nb[y] = nn.i; md[y] = nn.v; fresh_flag[y] = 1; }
+                if (tid == 0 && (y % G) == g) { STG(&nb[y], nn.i); STG(&md[y], nn.v); fresh_flag[y] = 1; }
             } else {
-                cy.v = md[y]; cy.i = y; cy.y = nb[y]; cy.fresh = 0;
+                cy.v = LDG(&md[y]); cy.i = y; cy.y = LDG(&nb[y]); cy.fresh = 0;
                 if (tid == 0 && (y % G) == g) fresh_flag[y] = 0;
             }
             if (best.i < 0 || cy.v < best.v || (cy.v == best.v && y < best.i)) best = cy;
