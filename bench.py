@@ -18,6 +18,7 @@ import os
 import sys
 import tempfile
 import time
+import zlib
 
 import numpy as np
 import torch
@@ -65,6 +66,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=int, default=20, help="audio seconds for the cpu_baseline sample (0 = skip)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="f32 = the measured configuration (f32 MFMA); f16 = "
                     "BASELINE configs[4]: ECAPA conv layers on the fp16 MFMA with f32 accumulation (secondary, tolerance-checked mode)")
+    ap.add_argument("--finalizer", default="auto", choices=["auto", "shared", "dedicated"], help="shared: rank 0 infers its shard and then "
+                    "finalizes (count / clustering / reconstruction); dedicated: rank 0 only finalizes, ranks 1..N-1 split the audio, and "
+                    "finalize(step k) on rank 0 overlaps inference(step k+1) on the others; auto = dedicated from 6 GPUs up (there the serial "
+                    "clustering of N hours outweighs one rank's share of the inference)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) | gloo (plumbing test of the multi-rank code "
                     "on a box with fewer GPUs than ranks: gathers go through host memory, ranks may share a GPU)")
     a = ap.parse_args()
@@ -104,7 +109,8 @@ def main():
     per_samples = int(round(a.hours_per_gpu * HOUR * SR))
     n_total = per_samples * world
     C, _ = sdhip.num_chunks(n_total)
-    per, ranges = sdhip.plan_shards(n_total, world)
+    dedicated = world > 1 and (a.finalizer == "dedicated" or (a.finalizer == "auto" and world >= 6))
+    per, ranges, gather_off = sdhip.plan_ranks(n_total, world, dedicated)     # dedicated: rank 0 holds no chunks
     lo, hi = ranges[rank]
     first, need_hi = sdhip.shard_sample_range(lo, hi, n_total)
     # synthesise only what this rank reads: its own hour(s) + the 72 000-sample halo of the next one
@@ -143,7 +149,10 @@ def main():
                 dist.all_gather_into_tensor(g_emb, d_emb)
             torch.cuda.synchronize()
             if rank == 0:
-                turns_box[0] = d.finalize_dev(g_seg.data_ptr(), g_emb.data_ptr(), C, n_total)
+                # gathered layout: rank r's shard at [r * per, (r + 1) * per); with a dedicated finalizer rank 0's slot is empty
+                # and chunk 0 starts at slot 1.  Rank 0 returns to the next all-gather only after this call: the other ranks'
+                # next inference runs meanwhile (software pipeline over steps)
+                turns_box[0] = d.finalize_dev(g_seg[gather_off:].data_ptr(), g_emb[gather_off * 3:].data_ptr(), C, n_total)
         else:
             turns_box[0] = d.finalize_dev(d_seg.data_ptr(), d_emb.data_ptr(), C, n_total)
 
@@ -203,8 +212,11 @@ def main():
                                    "post-seg + STFT/fbank + ECAPA-TDNN + centroid AHC + reconstruction" % (a.hours_per_gpu, audio_s / HOUR),
                        "audio_seconds": audio_s, "chunks": C, "embedding_items": 3 * C,
                        "weights": "seeded synthetic (seg 4321, emb 4322): the reference's ONNX blobs are not in the checkout",
-                       "sharding": "contiguous chunk ranges of %d per rank, RCCL all-gather of scores+embeddings, clustering on rank 0" % per,
+                       "sharding": ("contiguous chunk ranges of %d per rank, RCCL all-gather of scores+embeddings, clustering on rank 0" % per) if not dedicated else
+                                   ("contiguous chunk ranges of %d on ranks 1..%d, RCCL all-gather of scores+embeddings, rank 0 only finalizes: "
+                                    "finalize(step k) overlaps inference(step k+1)" % (per, world - 1)),
                        "turns": len(turns_box[0] or []),
+                       "turns_crc32": zlib.crc32("\n".join(sdhip.format_turn(t) for t in (turns_box[0] or [])).encode()),
                        "stage_ms_last_step": {"segmentation": round(stages[0], 1), "embedding": round(stages[1], 1), "clustering": round(stages[2], 1)}},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,

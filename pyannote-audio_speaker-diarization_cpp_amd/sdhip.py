@@ -109,6 +109,17 @@ def plan_shards(n_total, world):
     return per, [(min(C, r * per), min(C, (r + 1) * per)) for r in range(world)]
 
 
+def plan_ranks(n_total, world, dedicated_finalizer=False):
+    """chunk range of every rank and where chunk 0 sits in the all-gathered buffer (in chunks).
+    dedicated_finalizer: rank 0 holds no chunks (it only finalizes), ranks 1..world-1 split the audio; the gathered
+    buffer is [world][per] with rank r's shard in slot r, so chunk 0 starts at slot 1."""
+    if dedicated_finalizer and world > 1:
+        per, rr = plan_shards(n_total, world - 1)
+        return per, [(0, 0)] + rr, per
+    per, rr = plan_shards(n_total, world)
+    return per, rr, 0
+
+
 def shard_sample_range(lo, hi, n_total):
     """samples a rank must hold for chunks [lo, hi): [lo*8000, min(n, (hi-1)*8000 + 80000))"""
     if hi <= lo:

@@ -20,12 +20,12 @@ def _fake_infer(lo, hi):
     return seg.contiguous(), emb.contiguous()
 
 
-def _worker(rank, world, port, n_total, q):
+def _worker(rank, world, port, n_total, q, dedicated=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     C, _ = sdhip.num_chunks(n_total)
-    per, ranges = sdhip.plan_shards(n_total, world)
+    per, ranges, off = sdhip.plan_ranks(n_total, world, dedicated)
     lo, hi = ranges[rank]
     seg = torch.zeros((per, 293, 3))
     emb = torch.zeros((per * 3, 192))
@@ -37,7 +37,7 @@ def _worker(rank, world, port, n_total, q):
     dist.all_gather(gs, seg)
     dist.all_gather(ge, emb)
     if rank == 0:
-        S, E = torch.cat(gs)[:C], torch.cat(ge)[:C * 3]
+        S, E = torch.cat(gs)[off:off + C], torch.cat(ge)[off * 3:(off + C) * 3]
         s0, e0 = _fake_infer(0, C)
         q.put((bool(torch.equal(S, s0)), bool(torch.equal(E, e0)), per, ranges))
     dist.barrier()
@@ -60,6 +60,26 @@ def test_two_rank_gather_reassembles_single_process_arrays():
         assert p.exitcode == 0
     assert ok_s and ok_e
     assert per % 32 == 0 and ranges[0] == (0, per) and ranges[1][0] == per
+
+
+def test_three_rank_gather_with_dedicated_finalizer():
+    """bench.py's plan from 4 GPUs up, at world 3 here: rank 0 holds no chunks and finalizes, ranks 1-2 infer; the
+    gathered buffer holds chunk 0 at slot 1"""
+    n_total = 16000 * 900
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, n_total, q, True)) for r in range(3)]
+    for p in procs:
+        p.start()
+    ok_s, ok_e, per, ranges = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok_s and ok_e
+    assert ranges[0] == (0, 0) and ranges[1] == (0, per) and ranges[2][0] == per
 
 
 def test_shard_plan_properties():
