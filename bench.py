@@ -222,7 +222,8 @@ def main():
                          "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_conv_gemm (v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else "k_conv_gemm (v_mfma_f32_32x32x16_f16; segmentation and skinny layers stay f32)", "launches_per_step": cg["launches"] // max(a.steps, 1),
                          "kernel_ms_per_step": round(cg["ms"] / max(a.steps, 1), 2),
-                         "algorithmic_gflop_per_step": round(cg["flops"] / max(a.steps, 1) / 1e9, 1)},
+                         "algorithmic_gflop_per_step": round(cg["flops"] / max(a.steps, 1) / 1e9, 1),
+                         "algorithmic_bytes_per_launch": round(cg["bytes"] / max(cg["launches"], 1))},
             "other_kernels": extra,
         }
         if world == 1 and a.cpu_seconds > 0:
