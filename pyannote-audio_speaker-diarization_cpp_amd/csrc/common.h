@@ -10,7 +10,7 @@
 #include "../../include/sdhip.h"
 
 #define SD_T 501          // STFT frames per item (1 + 80000/160), sd.cpp:1980-2008
-#define SD_TP 512         // rows per item in activation buffers (T padded)
+#define SD_TP 501         // rows per item in activation buffers (= T: no padding rows; a 128-row tile may span two items)
 #define SD_NBINS 201
 #define SD_NMELS 80
 #define SD_FEAT_LD 96     // mel channels padded to a multiple of 32

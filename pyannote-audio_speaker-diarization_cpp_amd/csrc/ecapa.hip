@@ -5,7 +5,7 @@
 // All dense contractions run through conv_gemm.hip (f32 MFMA).  This file holds the
 // HBM-bound glue kernels (masked SE mean, SE apply + residual, ASP statistics and the
 // attentive softmax pooling) and the layer schedule.  Activations are channels-last
-// [item][512][C]; rows >= 501 are kept at zero.
+// [item][501][C] (no padding rows).
 #include "common.h"
 #include <algorithm>
 
@@ -168,18 +168,21 @@ int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d
     // side is the loose bound; the exact reach of one side is 2 + 7*(2 + 3 + 4) = 65 frames (each Res2Net block
     // chains 7 k3 convs of dilation 2 / 3 / 4; the 1x1 convs and the SE gate add none).  Row panels (128 rows)
     // that start at or beyond min(501, nvalid + 65) therefore cannot influence the embedding and are not
-    // computed: they are simply absent from the per-XCD panel lists (items are dealt to XCDs round robin so
-    // every XCD gets first, second, ... panels alike).
+    // computed: they are simply absent from the per-XCD panel lists (panel p goes to list p % 8).
     const int* mlist = nullptr; const int* mcount = nullptr; int mlist_ld = 0; double rows_listed = 0;
     if (h_nvalid) {
         const int kReach = 65;
         std::vector<int> lists[8];
-        for (int64_t b = 0; b < items; ++b) {
+        const int64_t npanels = (M + 127) / 128;
+        std::vector<char> live((size_t)npanels, 0);
+        for (int64_t b = 0; b < items; ++b) {              // a panel is computed if it holds a needed row of any item it overlaps
             int need = h_nvalid[b] + kReach; if (need > SD_T) need = SD_T;
-            const int npan = (need + 127) / 128;
-            for (int r = 0; r < npan; ++r) lists[b & 7].push_back((int)(b * (SD_TP / 128) + r));
-            rows_listed += (double)(need < npan * 128 ? need : npan * 128);
+            if (need <= 0) continue;
+            const int64_t r0 = b * SD_TP, r1 = r0 + need - 1;
+            for (int64_t pnl = r0 / 128; pnl <= r1 / 128; ++pnl) live[(size_t)pnl] = 1;
+            rows_listed += (double)need;
         }
+        for (int64_t pnl = 0; pnl < npanels; ++pnl) if (live[(size_t)pnl]) lists[pnl & 7].push_back((int)pnl);
         size_t ld = 1;
         for (int x = 0; x < 8; ++x) if (lists[x].size() > ld) ld = lists[x].size();
         std::vector<int> flat(8 * ld, 0), cnt(8);

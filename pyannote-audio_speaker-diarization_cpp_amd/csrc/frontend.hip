@@ -14,7 +14,7 @@
 //                   twiddles from a 400-entry LDS table), power in fp32, sparse mel, dB,
 //                   per-item max (atomic)
 //   k_fbank_norm  : top-dB clamp, mean over the first round(len*501) frames, subtract,
-//                   write channels-last [512][96] zero-padded rows for the MFMA convs
+//                   write channels-last [501][96] rows for the MFMA convs
 #include "common.h"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));

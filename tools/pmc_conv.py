@@ -13,5 +13,5 @@ if __name__ == "__main__":
     items = int(sys.argv[1]) if len(sys.argv) > 1 else 768
     d = sdhip.Diarizer(None, None)
     for name, cin, cout, kt, dil, x2 in SHAPES:
-        ms = d.bench_conv(items, 512, 501, cin, cout, kt, dil, x2, int(sys.argv[3]) if len(sys.argv) > 3 else 0, 1)
+        ms = d.bench_conv(items, 501, 501, cin, cout, kt, dil, x2, int(sys.argv[3]) if len(sys.argv) > 3 else 0, 1)
         print("%-26s %.2f ms" % (name, ms), flush=True)

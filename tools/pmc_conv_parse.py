@@ -9,7 +9,7 @@ def rows(path):
     return [float(x["Counter_Value"]) * 1024 for x in r]
 f, w = rows(sys.argv[1]), rows(sys.argv[2])
 assert len(f) == len(w) == 3 * len(SHAPES), (len(f), len(w))
-M = items * 512
+M = items * 501
 print("%-24s %12s %12s %12s %12s %12s" % ("shape", "alg read MB", "FETCH MB", "FETCHx2 MB", "alg write MB", "WRITE MB"))
 for i, (name, cin, cout, kt, dil, x2) in enumerate(SHAPES):
     ar = 4.0 * (M * cin * (2 if x2 else 1) + cout * cin * kt); aw = 4.0 * M * cout

@@ -12,7 +12,7 @@ shapes = [("block0 96->1024 k5", 96, 1024, 5, 1, 0), ("tdnn 1024->1024", 1024, 1
 for name, cin, cout, kt, dil, x2 in shapes:
     row = []
     for dbg in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2,3".split(","))]:
-        ms = d.bench_conv(items, 512, 501, cin, cout, kt, dil, x2, dbg, 5)
-        fl = 2.0 * items * 512 * cin * cout * kt
+        ms = d.bench_conv(items, 501, 501, cin, cout, kt, dil, x2, dbg, 5)
+        fl = 2.0 * items * 501 * cin * cout * kt
         row.append("d%-3d %6.2f ms %5.1f TF" % (dbg, ms, fl / ms / 1e9))
     print("%-26s %s" % (name, " | ".join(row)), flush=True)
