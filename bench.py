@@ -57,6 +57,19 @@ def cpu_baseline(ws, we, seconds):
             "turns": len(turns)}
 
 
+def rank0_share_estimate(world, hours_per_gpu):
+    """share of the chunks for rank 0 such that its finalize + inference takes as long as the other ranks' inference.
+    Stage rates measured on MI355X (profiles/r01_bench_1h_v5_summary.txt, r01_bench_8h_on_1gpu.json): inference 2.26 s per hour
+    of audio, finalize 0.147 s at 1 h and 2.1 s at 8 h (~ h^1.28).  A wrong estimate only unbalances the ranks."""
+    if world == 1:
+        return 1.0
+    total_h = world * hours_per_gpu
+    t_inf = 2.26 * total_h
+    t_fin = 0.147 * total_h ** 1.28 + 0.02
+    s0 = (t_inf - (world - 1) * t_fin) / world              # s0 + t_fin == (t_inf - s0) / (world - 1)
+    return max(0.0, min(1.0 / world, s0 / t_inf))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,10 +79,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=int, default=20, help="audio seconds for the cpu_baseline sample (0 = skip)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="f32 = the measured configuration (f32 MFMA); f16 = "
                     "BASELINE configs[4]: ECAPA conv layers on the fp16 MFMA with f32 accumulation (secondary, tolerance-checked mode)")
-    ap.add_argument("--finalizer", default="auto", choices=["auto", "shared", "dedicated"], help="shared: rank 0 infers its shard and then "
-                    "finalizes (count / clustering / reconstruction); dedicated: rank 0 only finalizes, ranks 1..N-1 split the audio, and "
-                    "finalize(step k) on rank 0 overlaps inference(step k+1) on the others; auto = dedicated from 6 GPUs up (there the serial "
-                    "clustering of N hours outweighs one rank's share of the inference)")
+    ap.add_argument("--rank0-share", type=float, default=-1.0, help="fraction of the chunks rank 0 infers itself (it also finalizes: count / "
+                    "clustering / reconstruction).  The other ranks start step k+1 right after the all-gather of step k, so rank 0's finalize(k) "
+                    "overlaps their inference; a smaller rank-0 share balances finalize + inference on rank 0 against inference on the others. "
+                    "-1 = from the measured stage rates (see rank0_share_estimate), 1/N = equal shares, 0 = rank 0 only finalizes")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) | gloo (plumbing test of the multi-rank code "
                     "on a box with fewer GPUs than ranks: gathers go through host memory, ranks may share a GPU)")
     a = ap.parse_args()
@@ -109,8 +122,10 @@ def main():
     per_samples = int(round(a.hours_per_gpu * HOUR * SR))
     n_total = per_samples * world
     C, _ = sdhip.num_chunks(n_total)
-    dedicated = world > 1 and (a.finalizer == "dedicated" or (a.finalizer == "auto" and world >= 6))
-    per, ranges, gather_off = sdhip.plan_ranks(n_total, world, dedicated)     # dedicated: rank 0 holds no chunks
+    share0 = a.rank0_share if a.rank0_share >= 0 else rank0_share_estimate(world, a.hours_per_gpu)
+    per, ranges = sdhip.plan_ranks(n_total, world, share0 if world > 1 else None)
+    pieces_g = sdhip.gather_pieces(per, ranges)
+    contiguous = all(off == sum(n for _, n in pieces_g[:i]) for i, (off, _) in enumerate(pieces_g))
     lo, hi = ranges[rank]
     first, need_hi = sdhip.shard_sample_range(lo, hi, n_total)
     # synthesise only what this rank reads: its own hour(s) + the 72 000-sample halo of the next one
@@ -149,10 +164,15 @@ def main():
                 dist.all_gather_into_tensor(g_emb, d_emb)
             torch.cuda.synchronize()
             if rank == 0:
-                # gathered layout: rank r's shard at [r * per, (r + 1) * per); with a dedicated finalizer rank 0's slot is empty
-                # and chunk 0 starts at slot 1.  Rank 0 returns to the next all-gather only after this call: the other ranks'
-                # next inference runs meanwhile (software pipeline over steps)
-                turns_box[0] = d.finalize_dev(g_seg[gather_off:].data_ptr(), g_emb[gather_off * 3:].data_ptr(), C, n_total)
+                # gathered layout: rank r's shard in slot [r * per, (r + 1) * per).  Rank 0 returns to the next all-gather only
+                # after this call: the other ranks' next inference runs meanwhile (software pipeline over steps)
+                if contiguous:
+                    fs, fe = g_seg, g_emb
+                else:
+                    fs = torch.cat([g_seg[o:o + m] for o, m in pieces_g])
+                    fe = torch.cat([g_emb[3 * o:3 * (o + m)] for o, m in pieces_g])
+                    torch.cuda.synchronize()
+                turns_box[0] = d.finalize_dev(fs.data_ptr(), fe.data_ptr(), C, n_total)
         else:
             turns_box[0] = d.finalize_dev(d_seg.data_ptr(), d_emb.data_ptr(), C, n_total)
 
@@ -212,9 +232,9 @@ def main():
                                    "post-seg + STFT/fbank + ECAPA-TDNN + centroid AHC + reconstruction" % (a.hours_per_gpu, audio_s / HOUR),
                        "audio_seconds": audio_s, "chunks": C, "embedding_items": 3 * C,
                        "weights": "seeded synthetic (seg 4321, emb 4322): the reference's ONNX blobs are not in the checkout",
-                       "sharding": ("contiguous chunk ranges of %d per rank, RCCL all-gather of scores+embeddings, clustering on rank 0" % per) if not dedicated else
-                                   ("contiguous chunk ranges of %d on ranks 1..%d, RCCL all-gather of scores+embeddings, rank 0 only finalizes: "
-                                    "finalize(step k) overlaps inference(step k+1)" % (per, world - 1)),
+                       "sharding": "contiguous 32-aligned chunk ranges %s, RCCL all-gather of scores+embeddings (slots of %d chunks), clustering on rank 0; "
+                                   "rank 0 infers %.1f %% of the chunks so that its finalize(step k) + inference balances the other ranks' "
+                                   "inference(step k+1), which starts right after the all-gather" % (ranges if world <= 8 else ranges[:8], per, 100.0 * (ranges[0][1] - ranges[0][0]) / max(C, 1)),
                        "turns": len(turns_box[0] or []),
                        "turns_crc32": zlib.crc32("\n".join(sdhip.format_turn(t) for t in (turns_box[0] or [])).encode()),
                        "stage_ms_last_step": {"segmentation": round(stages[0], 1), "embedding": round(stages[1], 1), "clustering": round(stages[2], 1)}},

@@ -109,15 +109,25 @@ def plan_shards(n_total, world):
     return per, [(min(C, r * per), min(C, (r + 1) * per)) for r in range(world)]
 
 
-def plan_ranks(n_total, world, dedicated_finalizer=False):
-    """chunk range of every rank and where chunk 0 sits in the all-gathered buffer (in chunks).
-    dedicated_finalizer: rank 0 holds no chunks (it only finalizes), ranks 1..world-1 split the audio; the gathered
-    buffer is [world][per] with rank r's shard in slot r, so chunk 0 starts at slot 1."""
-    if dedicated_finalizer and world > 1:
-        per, rr = plan_shards(n_total, world - 1)
-        return per, [(0, 0)] + rr, per
-    per, rr = plan_shards(n_total, world)
-    return per, rr, 0
+def plan_ranks(n_total, world, rank0_fraction=None):
+    """chunk range of every rank when rank 0, which also finalizes (count / clustering / reconstruction), is given a
+    smaller share of the chunks: rank0_fraction of all chunks (0 = none), the other ranks split the rest evenly.
+    None = equal shares (plan_shards).  Every shard starts on a multiple of 32 chunks.
+    Returns (per, [(lo, hi)] by rank): per = slot size of the padded all-gather, rank r's shard sits in slot r."""
+    if rank0_fraction is None or world == 1:
+        return plan_shards(n_total, world)
+    C, _ = num_chunks(n_total)
+    c0 = min(C, int(round(C * max(0.0, min(1.0, rank0_fraction)) / 32.0)) * 32)
+    rest = C - c0
+    per_r = -(-rest // (world - 1))
+    per_r = -(-per_r // 32) * 32
+    ranges = [(0, c0)] + [(min(C, c0 + r * per_r), min(C, c0 + (r + 1) * per_r)) for r in range(world - 1)]
+    return max(c0, per_r, 32), ranges
+
+
+def gather_pieces(per, ranges):
+    """[(offset in the gathered buffer, chunks)] in chunk order: what rank 0 concatenates before finalizing"""
+    return [(r * per, hi - lo) for r, (lo, hi) in enumerate(ranges) if hi > lo]
 
 
 def shard_sample_range(lo, hi, n_total):

@@ -20,12 +20,12 @@ def _fake_infer(lo, hi):
     return seg.contiguous(), emb.contiguous()
 
 
-def _worker(rank, world, port, n_total, q, dedicated=False):
+def _worker(rank, world, port, n_total, q, share0=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     C, _ = sdhip.num_chunks(n_total)
-    per, ranges, off = sdhip.plan_ranks(n_total, world, dedicated)
+    per, ranges = sdhip.plan_ranks(n_total, world, share0)
     lo, hi = ranges[rank]
     seg = torch.zeros((per, 293, 3))
     emb = torch.zeros((per * 3, 192))
@@ -37,7 +37,11 @@ def _worker(rank, world, port, n_total, q, dedicated=False):
     dist.all_gather(gs, seg)
     dist.all_gather(ge, emb)
     if rank == 0:
-        S, E = torch.cat(gs)[off:off + C], torch.cat(ge)[off * 3:(off + C) * 3]
+        G, H = torch.cat(gs), torch.cat(ge)
+        pieces = sdhip.gather_pieces(per, ranges)
+        S = torch.cat([G[o:o + m] for o, m in pieces])
+        E = torch.cat([H[3 * o:3 * (o + m)] for o, m in pieces])
+        assert S.shape[0] == C
         s0, e0 = _fake_infer(0, C)
         q.put((bool(torch.equal(S, s0)), bool(torch.equal(E, e0)), per, ranges))
     dist.barrier()
@@ -62,29 +66,42 @@ def test_two_rank_gather_reassembles_single_process_arrays():
     assert per % 32 == 0 and ranges[0] == (0, per) and ranges[1][0] == per
 
 
-def test_three_rank_gather_with_dedicated_finalizer():
-    """bench.py's plan from 4 GPUs up, at world 3 here: rank 0 holds no chunks and finalizes, ranks 1-2 infer; the
-    gathered buffer holds chunk 0 at slot 1"""
-    n_total = 16000 * 900
+def _run(world, n_total, share0):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 3, port, n_total, q, True)) for r in range(3)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q, share0)) for r in range(world)]
     for p in procs:
         p.start()
-    ok_s, ok_e, per, ranges = q.get(timeout=120)
+    out = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return out
+
+
+def test_three_rank_gather_with_reduced_rank0_share():
+    """bench.py's plan for N > 1: rank 0 also finalizes and therefore infers a smaller share (here 10 %, and none at all);
+    the padded slots are re-assembled in chunk order"""
+    n_total = 16000 * 900
+    C, _ = sdhip.num_chunks(n_total)
+    ok_s, ok_e, per, ranges = _run(3, n_total, 0.1)
     assert ok_s and ok_e
-    assert ranges[0] == (0, 0) and ranges[1] == (0, per) and ranges[2][0] == per
+    assert ranges[0][0] == 0 and 0 < ranges[0][1] < C // 3 and ranges[0][1] % 32 == 0 and ranges[1][0] == ranges[0][1] and ranges[-1][1] == C
+    ok_s, ok_e, per, ranges = _run(3, n_total, 0.0)
+    assert ok_s and ok_e and ranges[0] == (0, 0) and ranges[1][0] == 0
 
 
 def test_shard_plan_properties():
     for n_total, world in [(57600000, 1), (57600000 * 2, 2), (57600000 * 8, 8), (944000, 4), (100000, 8)]:
         C, _ = sdhip.num_chunks(n_total)
+        for share0 in (None, 0.0, 0.03, 1.0 / max(world, 1)):
+            p2, r2 = sdhip.plan_ranks(n_total, world, share0)
+            assert len(r2) == world and r2[0][0] == 0 and r2[-1][1] == C and p2 % 32 == 0
+            assert all(b == c for (a, b), (c, d) in zip(r2, r2[1:])) and all(lo % 32 == 0 or hi == lo for lo, hi in r2)
+            assert all(hi - lo <= p2 for lo, hi in r2) and sum(m for _, m in sdhip.gather_pieces(p2, r2)) == C
         per, ranges = sdhip.plan_shards(n_total, world)
         assert per % 32 == 0 and len(ranges) == world
         assert ranges[0][0] == 0 and ranges[-1][1] == C
