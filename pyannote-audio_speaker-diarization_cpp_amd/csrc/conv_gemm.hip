@@ -551,7 +551,12 @@ extern "C" int sd_bench_conv(sd_ctx* c, int64_t items, int Tp, int T, int Cin, i
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
 #define LAUNCH_V(X2, D) hipLaunchKernelGGL((k_conv_gemm<X2, D, false>), dim3(grid), dim3(256), 0, c->stream, a)
+#ifdef SD_CONV_ABLATIONS      // make EXTRA=-DSD_CONV_ABLATIONS: 6 more instantiations of the kernel (minutes of compile time), tuning only
 #define LAUNCH_S(X2) do { if (dbg == 0) LAUNCH_V(X2, 0); else if (dbg == 1) LAUNCH_V(X2, 1); else if (dbg == 2) LAUNCH_V(X2, 2); else LAUNCH_V(X2, 3); } while (0)
+#else
+    if (dbg != 0) SD_FAIL(c, SD_ERR_ARG, "sd_bench_conv: ablation %d needs a build with -DSD_CONV_ABLATIONS", dbg);
+#define LAUNCH_S(X2) LAUNCH_V(X2, 0)
+#endif
     for (int r = -2; r < reps; ++r) {
         if (r == 0) HIPCHK(c, hipEventRecord(e0, c->stream));
         if (has_x2) LAUNCH_S(true); else LAUNCH_S(false);
