@@ -19,8 +19,8 @@
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-#define FT 64                         // STFT frames per workgroup
-#define SIG_LEN ((FT - 1) * 160 + 400)  // 10480 samples feed FT frames
+#define FT 16                         // STFT frames per workgroup: one MFMA row tile; the 4 waves split the 13 bin tiles
+#define SIG_LEN ((FT - 1) * 160 + 400)  // 2800 samples feed FT frames
 #define SIG_LDS (SIG_LEN + 2 * (SIG_LEN / 160) + 8)
 #define PW_LD 209
 #define MEL_MAX_NNZ 1536
@@ -92,7 +92,7 @@ __device__ __forceinline__ void dft_tiles(const float* sig, const float* win, co
                                           float* pw, int w, int lane, int tile0)
 {
     const int i = lane & 15, kq = lane >> 4;
-    const int fl = 16 * w + i;
+    const int fl = i;                      // every wave works on the workgroup's 16 frames, on its own bin tiles
     const int sbase = 162 * fl;            // padded LDS position of the frame's first sample
     f64x4 re[NT], im[NT];
     int idx[NT], inc[NT];
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_stft_mel(
     __shared__ double tc[400], ts[400];
     __shared__ float sig[SIG_LDS];
     __shared__ float win[400];
-    __shared__ float pw[4][16 * PW_LD];
+    __shared__ float pw[16 * PW_LD];
     __shared__ float mw[MEL_MAX_NNZ];
     __shared__ int pre[296];
     __shared__ int mlo[SD_NMELS], mcnt[SD_NMELS], moff[SD_NMELS];
@@ -184,23 +184,22 @@ __global__ __launch_bounds__(256) void k_stft_mel(
     }
     __syncthreads();
 
-    float* mypw = pw[w];
-    dft_tiles<4>(sig, win, tc, ts, mypw, w, lane, 0);
-    dft_tiles<4>(sig, win, tc, ts, mypw, w, lane, 4);
-    dft_tiles<4>(sig, win, tc, ts, mypw, w, lane, 8);
-    dft_tiles<1>(sig, win, tc, ts, mypw, w, lane, 12);
+    // 13 bin tiles of 16: wave 0 takes tiles 0-3, waves 1-3 three each (4 waves per 16 frames keep 3 workgroups = 12 waves
+    // resident per CU; with 64 frames per workgroup the LDS footprint allowed one wave per SIMD)
+    if (w == 0) dft_tiles<4>(sig, win, tc, ts, pw, w, lane, 0);
+    else dft_tiles<3>(sig, win, tc, ts, pw, w, lane, 1 + 3 * w);
     __syncthreads();
 
     float vmax = -INFINITY;
-    for (int o = lane; o < 16 * SD_NMELS; o += 64) {
+    for (int o = tid; o < 16 * SD_NMELS; o += 256) {
         const int fr = o / SD_NMELS, m = o - fr * SD_NMELS;
-        const float* p = &mypw[fr * PW_LD + mlo[m]];
+        const float* p = &pw[fr * PW_LD + mlo[m]];
         const float* q = &mw[moff[m]];
         float acc = 0.0f;
         const int c = mcnt[m];
         for (int b = 0; b < c; ++b) acc = fmaf(p[b], q[b], acc);
         const float v = 10.0f * log10f(fmaxf(acc, 1e-10f));
-        const int t = t0 + 16 * w + fr;
+        const int t = t0 + fr;
         if (t < SD_T) {
             db[((size_t)slot * SD_T + t) * SD_NMELS + m] = v;
             vmax = fmaxf(vmax, v);
