@@ -299,6 +299,52 @@ def test_whole_path_against_oracle(diarizer, weights):
         assert a[2] == b[2] and abs(a[0] - b[0]) <= 0.016875 + 1e-9 and abs(a[1] - b[1]) <= 0.016875 + 1e-9
 
 
+@pytest.mark.parametrize("n", [79999, 80000, 80001, 87999, 88000, 88001, 151999, 168000])
+def test_whole_path_chunk_rule_edges(diarizer, weights, n):
+    """lengths around the chunk rule (strict `<` loop + last-chunk branch, sd.cpp:1419, 1457): a recording shorter than
+    one window, exactly one window, one sample more, and both sides of the next hop; the non-neural stages must agree bit
+    for bit with the oracle fed the GPU's network outputs, the full oracle within +-1 frame"""
+    import synth
+    pcm = synth.make_pcm(n / 16000.0 + 0.01, seed=31)[:n]
+    assert len(pcm) == n
+    turns = diarizer.diarize(pcm)
+    wav = pcm.astype(np.float32) / np.float32(32768.0)
+    seg = diarizer.segment(wav)
+    assert seg.shape[0] == orc.num_chunks(n)[0]
+    masks = orc.select_masks(orc.binarize(seg))
+    emb = diarizer.embed(wav, masks)
+    t1 = pipeline_oracle.diarize_ref(pcm, weights[2], weights[3], seg_override=seg, emb_override=emb)
+    assert sorted(turns, key=tkey) == sorted(t1, key=tkey)
+    t2 = pipeline_oracle.diarize_ref(pcm, weights[2], weights[3])
+    assert len(t2) == len(turns)
+    for a, b in zip(sorted(turns, key=tkey), sorted(t2, key=tkey)):
+        assert a[2] == b[2] and abs(a[0] - b[0]) <= 0.016875 + 1e-9 and abs(a[1] - b[1]) <= 0.016875 + 1e-9
+
+
+@pytest.mark.parametrize("kind", ["silence", "full_scale_square", "dc", "one_sample"])
+def test_whole_path_degenerate_audio(diarizer, weights, kind):
+    """inputs the reference would not survive gracefully (no active frame anywhere: fewer than two embeddings, sd.cpp:2081-2088)
+    or that sit at the edge of the int16 range: same turns as the oracle, no error, no NaN leaking into the output"""
+    n = 16000 * 12
+    if kind == "silence":
+        pcm = np.zeros(n, np.int16)
+    elif kind == "full_scale_square":
+        pcm = np.where((np.arange(n) // 40) % 2 == 0, 32767, -32768).astype(np.int16)
+    elif kind == "dc":
+        pcm = np.full(n, 12345, np.int16)
+    else:
+        pcm = np.zeros(n, np.int16); pcm[n // 2] = -32768
+    turns = diarizer.diarize(pcm)
+    assert all(np.isfinite(t[0]) and np.isfinite(t[1]) and t[0] < t[1] for t in turns)
+    wav = pcm.astype(np.float32) / np.float32(32768.0)
+    seg = diarizer.segment(wav)
+    assert np.isfinite(seg).all()
+    masks = orc.select_masks(orc.binarize(seg))
+    emb = diarizer.embed(wav, masks)
+    t1 = pipeline_oracle.diarize_ref(pcm, weights[2], weights[3], seg_override=seg, emb_override=emb)
+    assert sorted(turns, key=tkey) == sorted(t1, key=tkey)
+
+
 def test_sharded_equals_unsharded_and_is_idempotent(diarizer):
     """multi-GPU split exercised on one GPU: two 32-aligned shards == one shot"""
     import sdhip
