@@ -15,16 +15,18 @@
 // 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).  LDS rows are padded to 36 floats:
 // ds_read_b128 of 16 distinct rows then hits 16 distinct 4-bank slots (conflict
 // free), and every row start stays 16-byte aligned.  Global->LDS goes through
-// registers: the next step's loads are issued before the current step's MFMAs and
-// written to the other LDS buffer half-way through them (one barrier per K step).
+// registers (buffer loads: descriptor in SGPRs, K position as scalar offset): the
+// next step's loads are issued during the first two MFMA groups of a step and
+// written to the other LDS buffer during the third; one barrier per K step, placed
+// before the fourth group, whose operands are already in registers.
 //
-// Persistent schedule: the grid is 2 workgroups per CU; workgroup w (XCD = w % 8 under
-// round-robin dispatch, a speed assumption only) walks a contiguous slice of its XCD's
-// tile list (row panels m = xcd + 8j, all column tiles of a panel consecutively, so the
-// A panel it just read is re-read from its own L2).  The K-step pipeline runs straight
-// across tile boundaries: the first loads of tile i+1 are in flight while tile i's
-// accumulators go through the epilogue, so short-K layers (Res2Net K=384, ASP K=128)
-// do not pay a load-latency bubble per tile.
+// Persistent schedule: the grid is 2 workgroups per CU; the workgroups whose id is
+// equal mod 8 (one XCD under round-robin dispatch, a speed assumption only) walk
+// PM x PN super-blocks of tiles together (row panels m = xcd + 8j or the j-th entry
+// of the XCD's panel list).  The K-step pipeline runs straight across tile
+// boundaries: the first loads of tile i+1 are in flight while tile i's accumulators
+// go through the epilogue, so short-K layers (Res2Net K=384, ASP K=128) do not pay
+// a load-latency bubble per tile.
 #include "common.h"
 #include <type_traits>
 
