@@ -278,9 +278,10 @@ __global__ __launch_bounds__(LT) void k_linkage(double* D, int n, int* size, int
 //   2. runs the Lance-Williams update for its rows, folding the nearest-neighbour search of row y into the
 //      same pass (the new D[z,y], z > y, are in registers: row y is never re-read),
 //   3. computes its local arg-min of the lower bounds and publishes {NN(y) partial, arg-min} in a slot,
-//   4. meets the others at ONE device-scope barrier (a counter; everything the workgroups hand each other travels in
-//      agent-scope `sc1` loads / stores, see LDG / STG below, so no L2 write-back / invalidate is needed; placement
-//      independent) and reduces the G slots, so all workgroups take the same decision without a broadcast.
+//   4. exchanges slots with the others: the slot is a set of tagged 8-byte granules {payload word, round number} that
+//      the readers poll directly -- no counter, no flag, no fence (everything the workgroups hand each other travels in
+//      agent-scope `sc1` loads / stores, see LDG / STG below; placement independent); every workgroup reduces the G
+//      slots itself, so all take the same decision without a broadcast.
 // A stale candidate (cl.cpp:329-338) costs one extra round (see the kernel's own header below).
 // Used from N = 1500 up, where one CU's memory pipeline is the bottleneck.
 #define MWT 256
@@ -385,10 +386,15 @@ __device__ __forceinline__ Cand block_min_c(Cand m, Cand* sh, int nwaves)
 //    one barrier the round needs anyway.  Refreshing up to KR near-top stale rows per round needs ~5x fewer rounds
 //    than refreshing only the top one (measured 9.3 k vs 49 k rounds at N = 21 573).
 #define KR 8
-struct MwSlot { double nnv; double amv; int nni; int ami; int amy; int fresh; double pv[KR]; int pi[KR]; };
+// A slot is SLOT_WORDS 8-byte granules {32-bit payload word, 32-bit round tag}: a reader that sees the tag of the round it
+// waits for has the payload of that round (8-byte stores are single transactions), so publishing needs no separate
+// "ready" flag and no counter -- the readers poll the granules themselves.  Words: 0-1 arg-min bound (double), 2 its row,
+// 3 its neighbour, 4 freshness, 5-6 NN(y) partial (double), 7 its row, 8+3r.. refreshed-row partial r (double, row).
+#define SLOT_WORDS 32
+typedef unsigned long long MwGran;
 
 __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* size_all, int* cid, int* nb, double* md,
-                                                         unsigned char* fresh_flag, double* Z, MwSlot* slots /*[2][G]*/,
+                                                         unsigned char* fresh_flag, double* Z, MwGran* gran /*[2][G][SLOT_WORDS], zeroed*/,
                                                          unsigned* sync, int cap /*owned rows per workgroup, upper bound*/)
 {
     extern __shared__ int dyn_lds[];
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     __shared__ MinIdx sh[MWT_MAX / 64];
     __shared__ Cand shc[MWT_MAX / 64];
     __shared__ MinIdx s_part[KR][MWT_MAX / 64];
+    __shared__ unsigned s_words[MWT][SLOT_WORDS];      // this round's slots of all workgroups, as received
     __shared__ Cand s_cand[MWT + 1];        // published local bests of the G <= 256 workgroups (+ row y)
     __shared__ MinIdx s_nnp[MWT];
     __shared__ MinIdx s_row[KR];
@@ -411,7 +418,24 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     int* size = size_all + (size_t)g * n;
     unsigned bar = 0;
     int par = 0, lp = 0;             // slot parity, refresh-list parity
-    auto barrier = [&]() -> bool { ++bar; return mw_barrier_nf(&sync[0], bar * (unsigned)G, &sync[1]); };
+    // receive round `bar` of every workgroup's slot (nw words each) into s_words; returns false on timeout
+    auto consume = [&](int nw) -> bool {
+        const MwGran* base = gran + (size_t)par * G * SLOT_WORDS;
+        bool ok = true;
+        for (int idx = tid; idx < G * nw; idx += T) {
+            const int sl = idx / nw, wd = idx - sl * nw;
+            const MwGran* p = base + (size_t)sl * SLOT_WORDS + wd;
+            MwGran v = LDG(p);
+            unsigned spins = 0;
+            while ((unsigned)(v >> 32) != bar) {
+                __builtin_amdgcn_s_sleep(1);
+                v = LDG(p);
+                if (++spins > (1u << 24)) { sync[1] = 1; ok = false; break; }     // ~seconds: never in a healthy run
+            }
+            s_words[sl][wd] = (unsigned)v;
+        }
+        return __syncthreads_and(ok ? 1 : 0) != 0;
+    };
     MinIdx none; none.v = INFINITY; none.i = -1;
 #ifdef SD_LINKAGE_STAMPS
     unsigned long long tS = __builtin_amdgcn_s_memrealtime(), acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -483,25 +507,40 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         }
         __syncthreads();
     };
+    // publish this workgroup's slot for the next round.  Every wave first drains its write-through stores (distance
+    // matrix, bounds): whoever sees the slot may read them.
     auto publish = [&](MinIdx q, Cand m, int nL, const MinIdx* rows) {
-        MwSlot* sl = &slots[par * G + g];
-        if (tid == 0) { STG(&sl->nnv, q.v); STG(&sl->nni, q.i); STG(&sl->amv, m.v); STG(&sl->ami, m.i); STG(&sl->amy, m.y); STG(&sl->fresh, m.fresh); }
-        if (tid < nL) { STG(&sl->pv[tid], rows[tid].v); STG(&sl->pi[tid], rows[tid].i); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ++bar;
+        MwGran* sl = gran + ((size_t)par * G + g) * SLOT_WORDS;
+        const MwGran tag = (MwGran)bar << 32;
+        if (tid == 0) {
+            const unsigned long long av = (unsigned long long)__double_as_longlong(m.v), nv = (unsigned long long)__double_as_longlong(q.v);
+            STG(&sl[0], tag | (unsigned)av); STG(&sl[1], tag | (unsigned)(av >> 32)); STG(&sl[2], tag | (unsigned)m.i);
+            STG(&sl[3], tag | (unsigned)m.y); STG(&sl[4], tag | (unsigned)m.fresh);
+            STG(&sl[5], tag | (unsigned)nv); STG(&sl[6], tag | (unsigned)(nv >> 32)); STG(&sl[7], tag | (unsigned)q.i);
+        }
+        if (tid < nL) {
+            const unsigned long long pv = (unsigned long long)__double_as_longlong(rows[tid].v);
+            STG(&sl[8 + 3 * tid], tag | (unsigned)pv); STG(&sl[9 + 3 * tid], tag | (unsigned)(pv >> 32)); STG(&sl[10 + 3 * tid], tag | (unsigned)rows[tid].i);
+        }
+    };
+    auto word_d = [&](int sl, int wd) -> double {
+        return __longlong_as_double((long long)(((unsigned long long)s_words[sl][wd + 1] << 32) | s_words[sl][wd]));
     };
     // after a barrier: gather all slots; reduce the NN(y) partials, the refreshed rows, the global best; pick the next refresh list
     auto digest = [&](int nLprev, const int* Lprev, int yrow, bool with_nn) {
-        const MwSlot* base = slots + (size_t)par * G;
         if (tid < G) {
-            const MwSlot* sl = base + tid;
-            Cand c; c.v = LDG(&sl->amv); c.i = LDG(&sl->ami); c.y = LDG(&sl->amy); c.fresh = LDG(&sl->fresh); s_cand[tid] = c;
-            MinIdx a; a.v = LDG(&sl->nnv); a.i = LDG(&sl->nni); s_nnp[tid] = a;
+            Cand c; c.v = word_d(tid, 0); c.i = (int)s_words[tid][2]; c.y = (int)s_words[tid][3]; c.fresh = (int)s_words[tid][4]; s_cand[tid] = c;
+            MinIdx a; a.v = word_d(tid, 5); a.i = (int)s_words[tid][7]; s_nnp[tid] = a;
         }
         if (wv < (nLprev + 1) / 2) {          // refreshed rows: 2 per wave (one per 32-lane half), all lanes active
             const int r = tid >> 5, l = tid & 31;
             MinIdx a = none, pl[8];
             if (r < nLprev) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const int u = l + 32 * e; const int uc = u < G ? u : 0; pl[e].v = LDG(&base[uc].pv[r]); pl[e].i = u < G ? LDG(&base[uc].pi[r]) : -1; }
+                for (int e = 0; e < 8; ++e) { const int u = l + 32 * e; const int uc = u < G ? u : 0; pl[e].v = word_d(uc, 8 + 3 * r); pl[e].i = u < G ? (int)s_words[uc][10 + 3 * r] : -1; }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a = better(a, pl[e]);
             }
@@ -585,7 +624,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         Cand m0 = local_argmin(0, s_L[0]);
         publish(none, m0, 0, s_row);
     }
-    if (!barrier()) return;
+    if (!consume(8)) return;
     digest(0, s_L[0], -1, false);
     par ^= 1;
     Cand best = s_best;
@@ -604,7 +643,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
             Cand m = local_argmin(nL, L);
             publish(none, m, nL, s_row);
             STAMP2(1);
-            if (!barrier()) return;
+            if (!consume(8 + 3 * nL)) return;
             STAMP2(2);
             digest(nL, L, -1, false);
             par ^= 1;
@@ -679,7 +718,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         m = block_min_c(m, shc, NW);
         publish(q, m, 0, s_row);
         STAMP2(7);
-        if (!barrier()) return;
+        if (!consume(8)) return;
         STAMP2(2);
         digest(0, s_L[lp], y, true);
         STAMP2(3);
@@ -772,7 +811,7 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     if (G < 0) G = N >= 60000 ? 128 : N >= 15000 ? 64 : N >= 1500 ? 32 : 0;     // auto (measured on clustered data, profiles/r01_linkage_scaling.txt)
     if (G > c->num_cu) G = c->num_cu;
     int TH = (int)c->linkage_threads;
-    if (TH <= 0) TH = 256;
+    if (TH <= 0) TH = N >= 15000 ? 512 : 256;          // measured: 327 vs 337 ms at N = 21 573, 4.68 vs 4.85 s at N = 172 773
     TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : 256;
     if (G <= 1) {
         ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
@@ -782,7 +821,8 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         if ((N + G - 1) / G > 7000) G = (int)((N + 6999) / 7000);      // active-row lists live in LDS: 8 B per owned row
         if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
         int cap = (int)((N + G - 1) / G) + 1;
-        WS(c, MwSlot, slots, "cl_slots", 2 * G);
+        WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * SLOT_WORDS);
+        HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * SLOT_WORDS * sizeof(MwGran), c->stream));
         WS(c, int, size_all, "cl_size_all", (int64_t)G * N);
         WS(c, unsigned char, fresh_flag, "cl_fresh", N + 16);
         hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)(((int64_t)G * N + 255) / 256)), dim3(256), 0, c->stream, size_all, 1, (int64_t)G * N, 0);
@@ -791,7 +831,7 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         HIPCHK(c, hipMemsetAsync(sync, 0, 16 * sizeof(unsigned), c->stream));
         {
             ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
-            hipLaunchKernelGGL(k_linkage_mw, dim3(G), dim3(TH), (size_t)cap * 8, c->stream, D, (int)N, size_all, cid, nb, md, fresh_flag, d_Z, slots, sync, cap);
+            hipLaunchKernelGGL(k_linkage_mw, dim3(G), dim3(TH), (size_t)cap * 8, c->stream, D, (int)N, size_all, cid, nb, md, fresh_flag, d_Z, gran, sync, cap);
             KCHECK(c);
         }
         unsigned h[16] = {0};
