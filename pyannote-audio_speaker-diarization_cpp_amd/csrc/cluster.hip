@@ -311,28 +311,11 @@ __device__ __forceinline__ bool mw_barrier(unsigned* counter, unsigned target, u
 
 // Cross-workgroup data of the cooperative kernel (distance matrix, bounds, neighbours, slots) is moved with agent-scope
 // relaxed atomics only: on gfx950 these are `sc1` loads / stores (write-through past the per-XCD L2, loads that do not
-// trust a non-coherent line).  Every wave drains its stores (the workgroup barrier's release does `s_waitcnt vmcnt(0)`)
-// before thread 0 arrives at the counter, so no agent-scope release / acquire -- an L2 write-back and a full L2
-// invalidate per merge -- is needed, and each workgroup's private state (cluster sizes, freshness flags) stays cached.
+// trust a non-coherent line).  Every wave drains its stores (`s_waitcnt vmcnt(0)`) before the workgroup publishes its
+// slot, so no agent-scope release / acquire -- an L2 write-back and a full L2 invalidate per merge -- is needed, and
+// each workgroup's private state (cluster sizes, freshness flags) stays cached.
 template <class T> __device__ __forceinline__ T LDG(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void STG(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool mw_barrier_nf(unsigned* counter, unsigned target, unsigned* timeout_flag)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's write-through stores have been acknowledged
-    __syncthreads();
-    bool ok = true;
-    if (threadIdx.x == 0) {
-        (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 26)) { *timeout_flag = 1; ok = false; break; }
-        }
-    }
-    __syncthreads();
-    return ok;
-}
-
 __device__ __forceinline__ MinIdx block_min_t(MinIdx m, MinIdx* sh, int nwaves)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
