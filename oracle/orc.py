@@ -93,6 +93,30 @@ def ref():
     return R
 
 
+_REFWAV = None
+
+
+def ref_wav_read(path):
+    """the reference's own WavReader (frontend/wav.h, oracle/_ref/libref_wav.so): raw sample values as WavReader::data()
+    holds them (not yet divided by 32768), sample rate, channels, bits.  None when oracle/_ref is absent."""
+    global _REFWAV
+    if _REFWAV is None:
+        p = os.path.join(_HERE, "_ref", "libref_wav.so")
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        R.ref_wav_read.restype = C.c_long
+        R.ref_wav_read.argtypes = [C.c_char_p, C.c_void_p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _REFWAV = R
+    sr, ch, bits = C.c_int(0), C.c_int(0), C.c_int(0)
+    n = _REFWAV.ref_wav_read(path.encode(), None, 0, C.byref(sr), C.byref(ch), C.byref(bits))
+    if n < 0:
+        raise IOError("reference WavReader cannot open " + path)
+    out = np.zeros(max(n, 1), np.float32)
+    _REFWAV.ref_wav_read(path.encode(), out.ctypes.data_as(C.c_void_p), n, None, None, None)
+    return out[:n], sr.value, ch.value, bits.value
+
+
 # ---- constants of the reference (SURVEY Appendix A) ----
 SR = 16000
 WINDOW = 80000

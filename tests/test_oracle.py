@@ -203,6 +203,47 @@ def test_wav_reader(golden_dir, tmp_path):
     assert len(w1) == 944000 and sr1 == 16000
 
 
+def _write_wav(path, samples, bits, channels=1, extra_chunk=False, fmt_extra=0):
+    import struct
+    dt = {8: np.int8, 16: np.int16, 32: np.int32}[bits]
+    raw = np.asarray(samples, dt).tobytes()
+    body = b""
+    if extra_chunk:
+        body += b"LIST" + struct.pack("<I", 6) + b"abcdef"
+    body += b"data" + struct.pack("<I", len(raw)) + raw
+    fmt = struct.pack("<HHIIHH", 1, channels, 16000, 16000 * channels * bits // 8, channels * bits // 8, bits) + b"\0" * fmt_extra
+    hdr = b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + len(body)) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    with open(path, "wb") as f:
+        f.write(hdr + body)
+
+
+@pytest.mark.parametrize("bits,channels,extra,fmt_extra", [(16, 1, False, 0), (16, 1, True, 0), (16, 2, False, 0), (8, 1, False, 0),
+                                                           (32, 1, True, 0), (16, 1, False, 2), (16, 1, True, 2)])
+def test_wav_readers_against_the_reference_reader(tmp_path, bits, channels, extra, fmt_extra):
+    """a1 pinned on the reference's OWN WavReader (frontend/wav.h compiled in place, oracle/_ref/libref_wav.so): bit depths
+    8 / 16 / 32, an extra sub-chunk before "data", a fmt chunk longer than 16 bytes, interleaved stereo read as one stream
+    (wav.h:95-97).  The oracle's and the library's readers must return exactly data()/32768 (sd.cpp:2948-2951)."""
+    rng = np.random.default_rng(bits + 7 * channels + extra)
+    lim = {8: 127, 16: 32767, 32: 2 ** 31 - 1}[bits]
+    smp = rng.integers(-lim - 1, lim + 1, 1000 * channels)
+    p = str(tmp_path / "r.wav")
+    _write_wav(p, smp, bits, channels, extra, fmt_extra)
+    ref = orc.ref_wav_read(p)
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    raw, sr, ch, b = ref
+    assert (sr, ch, b) == (16000, channels, bits) and len(raw) == len(smp)
+    assert np.array_equal(raw, smp.astype(np.float32))                  # what WavReader::data() holds
+    w, sr2, ch2, b2 = orc.read_wav(p)
+    assert (sr2, ch2, b2) == (sr, ch, b)
+    import sdhip
+    wl, srl, chl, bl = sdhip.read_wav_f32(p)                            # host-only entry point of the library
+    assert (srl, chl, bl) == (sr, ch, b)
+    expect = raw / np.float32(32768.0)
+    # the oracle returns num_samples (per channel) values, the library all interleaved values: compare the common prefix
+    assert np.array_equal(w, expect[:len(w)]) and np.array_equal(wl[:len(expect)], expect[:len(wl)])
+
+
 def test_stft_oracle_against_direct_dft():
     import torch
     from oracle import nn_oracle as nn
