@@ -83,6 +83,8 @@ def main():
                     "clustering / reconstruction).  The other ranks start step k+1 right after the all-gather of step k, so rank 0's finalize(k) "
                     "overlaps their inference; a smaller rank-0 share balances finalize + inference on rank 0 against inference on the others. "
                     "-1 = from the measured stage rates (see rank0_share_estimate), 1/N = equal shares, 0 = rank 0 only finalizes")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (process group, all-gather, assembly) even with "
+                    "one rank: exercises RCCL and the collectives on a 1-GPU box")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) | gloo (plumbing test of the multi-rank code "
                     "on a box with fewer GPUs than ranks: gathers go through host memory, ranks may share a GPU)")
     a = ap.parse_args()
@@ -99,7 +101,10 @@ def main():
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         if a.backend == "gloo":
             dist.init_process_group("gloo")
@@ -142,7 +147,7 @@ def main():
     nloc = hi - lo
     d_seg = torch.zeros((per, sdhip.FRAMES, 3), dtype=torch.float32, device=dev)
     d_emb = torch.zeros((per * 3, sdhip.EMB_DIM), dtype=torch.float32, device=dev)
-    if world > 1:
+    if use_dist:
         g_seg = torch.empty((world * per, sdhip.FRAMES, 3), dtype=torch.float32, device=dev)
         g_emb = torch.empty((world * per * 3, sdhip.EMB_DIM), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
@@ -152,7 +157,7 @@ def main():
     def step():
         if nloc > 0:
             d.shard_infer_dev(d_pcm.data_ptr(), first, int(d_pcm.numel()), n_total, lo, hi, d_seg.data_ptr(), d_emb.data_ptr())
-        if world > 1:
+        if use_dist:
             if a.backend == "gloo":                      # test-only path: same assembly through host memory
                 hs, he = [torch.empty(d_seg.shape) for _ in range(world)], [torch.empty(d_emb.shape) for _ in range(world)]
                 dist.all_gather(hs, d_seg.cpu())
@@ -178,7 +183,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -192,7 +197,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -252,7 +257,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     d.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
