@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hours-per-gpu", type=float, default=1.0)
-    ap.add_argument("--cpu-seconds", type=int, default=20, help="audio seconds for the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=int, default=60, help="audio seconds for the cpu_baseline sample (0 = skip)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="f32 = the measured configuration (f32 MFMA); f16 = "
                     "BASELINE configs[4]: ECAPA conv layers on the fp16 MFMA with f32 accumulation (secondary, tolerance-checked mode)")
     ap.add_argument("--rank0-share", type=float, default=-1.0, help="fraction of the chunks rank 0 infers itself (it also finalizes: count / "
