@@ -895,7 +895,15 @@ __global__ void k_cluster_means(const double* __restrict__ X, int d, const int* 
     if (q >= d) return;
     double s = 0.0;
     const int a = off[k], b = off[k + 1];
-    for (int t = a; t < b; ++t) s += X[(size_t)order[t] * d + q];
+    int t = a;
+    for (; t + 16 <= b; t += 16) {          // 16 rows in flight, added in member order (the sum itself stays sequential)
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = X[(size_t)order[t + u] * d + q];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; t < b; ++t) s += X[(size_t)order[t] * d + q];
     cen[(size_t)k * d + q] = s / (double)(b - a);
 }
 
