@@ -59,13 +59,13 @@ def cpu_baseline(ws, we, seconds):
 
 def rank0_share_estimate(world, hours_per_gpu):
     """share of the chunks for rank 0 such that its finalize + inference takes as long as the other ranks' inference.
-    Stage rates measured on MI355X (profiles/r01_bench_1h_v5_summary.txt, r01_bench_8h_on_1gpu.json): inference 2.26 s per hour
-    of audio, finalize 0.147 s at 1 h and 2.1 s at 8 h (~ h^1.28).  A wrong estimate only unbalances the ranks."""
+    Stage rates measured on MI355X (profiles/r01_bench_1h_v5_summary.txt, r01_bench_8h_on_1gpu.json): inference 2.23 s per hour
+    of audio, finalize 0.13 s at 1 h and about 1.9 s at 8 h (~ h^1.28).  A wrong estimate only unbalances the ranks."""
     if world == 1:
         return 1.0
     total_h = world * hours_per_gpu
-    t_inf = 2.26 * total_h
-    t_fin = 0.147 * total_h ** 1.28 + 0.02
+    t_inf = 2.23 * total_h
+    t_fin = 0.132 * total_h ** 1.28 + 0.02
     s0 = (t_inf - (world - 1) * t_fin) / world              # s0 + t_fin == (t_inf - s0) / (world - 1)
     return max(0.0, min(1.0 / world, s0 / t_inf))
 
