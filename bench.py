@@ -216,13 +216,14 @@ def main():
                 extra[k].update({"hbm_GBps_algorithmic": round(s["bytes"] / s["ms"] / 1e6, 1), "hbm_frac_of_8TBps": round(s["bytes"] / s["ms"] / 1e6 / 8000.0, 4),
                                  "fp64_mfma_TFLOPs": round(s["flops"] / s["ms"] / 1e9, 1), "fp64_mfma_frac_of_78.6": round(s["flops"] / s["ms"] / 1e9 / 78.6, 3),
                                  "bound": "fp64 MFMA (400-point DFT as GEMM), not HBM, at this size"})
-        traffic, traffic_src = None, None
+        traffic, traffic_src, mfma_util = None, None, None
         peak = F32_MFMA_PEAK_TFLOPS if a.precision == "f32" else F16_MFMA_PEAK_TFLOPS
         pmc_path = os.path.join(ROOT, "profiles", "pmc_conv_gemm_bench.json")
         if world == 1 and a.precision == "f32" and os.path.exists(pmc_path):
             try:
                 pj = json.load(open(pmc_path))
                 traffic, traffic_src = pj["bytes_per_launch"], pj["source"]
+                mfma_util = pj.get("mfma")
             except Exception:
                 pass
         out = {
@@ -248,7 +249,8 @@ def main():
                          "kernel": "k_conv_gemm (v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else "k_conv_gemm (v_mfma_f32_32x32x16_f16; segmentation and skinny layers stay f32)", "launches_per_step": cg["launches"] // max(a.steps, 1),
                          "kernel_ms_per_step": round(cg["ms"] / max(a.steps, 1), 2),
                          "algorithmic_gflop_per_step": round(cg["flops"] / max(a.steps, 1) / 1e9, 1),
-                         "algorithmic_bytes_per_launch": round(cg["bytes"] / max(cg["launches"], 1))},
+                         "algorithmic_bytes_per_launch": round(cg["bytes"] / max(cg["launches"], 1)),
+                         "mfma_utilisation_pmc": mfma_util},
             "other_kernels": extra,
         }
         if world == 1 and a.cpu_seconds > 0:
