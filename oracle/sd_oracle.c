@@ -16,6 +16,9 @@
  *   - orc_pdist / orc_linkage_centroid / orc_fcluster_distance : pinned against
  *     oracle/_ref/libref_clustering.so (the reference's own clustering.cpp built
  *     in place) and scipy.cluster.hierarchy.
+ *   - orc_read_wav : pinned against oracle/_ref/libref_wav.so (the reference's own
+ *     header-only WavReader, frontend/wav.h, built in place) on 8 / 16 / 32-bit files,
+ *     extra sub-chunks, long fmt chunks and interleaved stereo.
  *   - everything else is a line-by-line restatement whose only in-repo golden
  *     is the README sample output (needs the missing ONNX blobs) => those
  *     stages are "parity unpinned" beyond the restatement itself.
