@@ -127,6 +127,16 @@ int sd_shard_infer_dev(sd_ctx*, const int16_t* d_pcm_shard, int64_t first_sample
 int sd_finalize_dev(sd_ctx*, const float* d_seg, const float* d_emb, int64_t chunks, int64_t n,
                     sd_turn** turns, int64_t* n_turns);
 
+/* ---- planted workload (measurement / test hook, SURVEY 8d: "with synthetic weights force a deterministic activity
+ * pattern for stage >= a4 (override sigmoid outputs from the schedule) so N is controlled").  With seeded random
+ * weights PyanNet and ECAPA do not follow the talkers, so every stage after them would only ever see one degenerate
+ * case (K = 1, one turn).  After this call sd_diarize* / sd_shard_infer_dev still run both networks at full cost, then
+ * replace the segmentation scores of chunks [chunk_lo, chunk_lo + chunks) by d_scores [chunks][293][3] before
+ * post-segmentation, and the embedding rows of those chunks that are not NaN by the reference's own rule
+ * (sd.cpp:2479-2549) by d_emb [chunks*3][192] before the all-gather / clustering.  Either pointer may be NULL; the
+ * buffers stay owned by the caller and must outlive the calls; chunks = 0 removes the hook.  Never set by the CLI. */
+int sd_set_planted(sd_ctx*, const float* d_scores, const float* d_emb, int64_t chunk_lo, int64_t chunks);
+
 /* ---- a1: wav::WavReader::Open (wav.h:62-126).  Returns malloc'd pcm (free with
  * sd_free_pcm); only 16-bit PCM is accepted (README.md:37), channels are read
  * interleaved-as-mono exactly like the reference (wav.h:95-97). */

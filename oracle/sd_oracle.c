@@ -762,6 +762,7 @@ long orc_reconstruct(const float *seg, long c, int F, int S, const int *hard,
 }
 
 typedef struct { double start, end; int label; } orc_turn;
+void orc_final_sort(orc_turn *t, long n);            /* final_sort.cpp */
 
 static int cmp_seg(const void *a, const void *b)
 {
@@ -773,8 +774,11 @@ static int cmp_seg(const void *a, const void *b)
 /* a17 to_annotation + support + finalResult, sd.cpp:2852-2935,          */
 /* 911-941, 962-978.  scores [rows][K].  min_off is the reference's      */
 /* float-typed constant promoted to double (sd.cpp:3210).                */
-/* NOTE std::sort (unstable) is used by the reference for equal starts;  */
-/* we use a stable merge order = track order for ties.                   */
+/* finalResult() orders the turns with std::sort (unstable): turns with   */
+/* EQUAL start times come out in whatever order libstdc++'s introsort     */
+/* leaves them, so that call is made for real in final_sort.cpp (g++, the */
+/* same libstdc++ the reference links) on the same input order (tracks in */
+/* ascending label, segments in time order).                              */
 /* ------------------------------------------------------------------ */
 long orc_to_annotation(const double *scores, long rows, int K, double w_start,
                        double w_step, double w_dur, double onset, double offset,
@@ -822,24 +826,7 @@ long orc_to_annotation(const double *scores, long rows, int K, double w_start,
         for (long i = 0; i < ns; ++i) { if (nout < cap) out[nout] = segs[i]; nout++; }
     }
     free(ts); free(segs);
-    if (nout <= cap) {
-        /* finalResult: sort by start (stable here) */
-        orc_turn *tmp = (orc_turn *)malloc(sizeof(orc_turn) * (size_t)(nout + 1));
-        /* stable insertion-merge via indices */
-        for (long i = 0; i < nout; ++i) tmp[i] = out[i];
-        /* simple stable merge sort */
-        for (long width = 1; width < nout; width *= 2) {
-            for (long lo = 0; lo < nout; lo += 2 * width) {
-                long mid = lo + width < nout ? lo + width : nout, hi = lo + 2 * width < nout ? lo + 2 * width : nout;
-                long a = lo, b = mid, w = lo;
-                while (a < mid && b < hi) out[w++] = (cmp_seg(&tmp[b], &tmp[a]) < 0) ? tmp[b++] : tmp[a++];
-                while (a < mid) out[w++] = tmp[a++];
-                while (b < hi) out[w++] = tmp[b++];
-            }
-            for (long i = 0; i < nout; ++i) tmp[i] = out[i];
-        }
-        free(tmp);
-    }
+    if (nout <= cap) orc_final_sort(out, nout);       /* finalResult: std::sort by start, sd.cpp:973 (final_sort.cpp) */
     return nout;
 }
 

@@ -107,6 +107,9 @@ struct sd_ctx {
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
     int64_t linkage_threads = 0;               // 0 auto (256, or 1024 for N >= 60000), else 256 / 512 / 1024 threads per cooperative workgroup
     int num_cu = 256;
+    const float* planted_scores = nullptr;      // sd_set_planted: measurement / test hook
+    const float* planted_emb = nullptr;
+    int64_t planted_lo = 0, planted_n = 0;
 };
 
 #define SD_FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (ctx)->err = _b; return (code); } while (0)

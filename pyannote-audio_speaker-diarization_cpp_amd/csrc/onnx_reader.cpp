@@ -49,7 +49,7 @@ bool parse_tensor(PB pb, OTensor& t)
     while (pb.tag(f, wt)) {
         if (f == 1) { if (wt == 2) { PB s = pb.sub(); while (!s.done()) t.dims.push_back((int64_t)s.varint()); } else t.dims.push_back((int64_t)pb.varint()); }
         else if (f == 2 && wt == 0) t.dtype = (int)pb.varint();
-        else if (f == 4) { if (wt == 2) { PB s = pb.sub(); while (s.e - s.p >= 4) { float v; memcpy(&v, s.p, 4); s.p += 4; t.f.push_back(v); } } else if (wt == 5) { float v; memcpy(&v, pb.p, 4); pb.p += 4; t.f.push_back(v); } else pb.skip(wt); }
+        else if (f == 4) { if (wt == 2) { PB s = pb.sub(); while (s.e - s.p >= 4) { float v; memcpy(&v, s.p, 4); s.p += 4; t.f.push_back(v); } } else if (wt == 5) { if (pb.e - pb.p < 4) { pb.ok = false; break; } float v; memcpy(&v, pb.p, 4); pb.p += 4; t.f.push_back(v); } else pb.skip(wt); }
         else if (f == 7) { if (wt == 2) { PB s = pb.sub(); while (!s.done()) t.i64.push_back((int64_t)s.varint()); } else t.i64.push_back((int64_t)pb.varint()); }
         else if (f == 8 && wt == 2) t.name = pb.str();
         else if (f == 9 && wt == 2) raw = pb.str();
@@ -72,7 +72,7 @@ bool parse_attr(PB pb, OAttr& a)
     int f, wt;
     while (pb.tag(f, wt)) {
         if (f == 1 && wt == 2) a.name = pb.str();
-        else if (f == 2 && wt == 5) { memcpy(&a.f, pb.p, 4); pb.p += 4; }
+        else if (f == 2 && wt == 5) { if (pb.e - pb.p < 4) { pb.ok = false; break; } memcpy(&a.f, pb.p, 4); pb.p += 4; }
         else if (f == 3 && wt == 0) a.i = (int64_t)pb.varint();
         else if (f == 4 && wt == 2) a.s = pb.str();
         else if (f == 5 && wt == 2) { a.has_t = true; if (!parse_tensor(pb.sub(), a.t)) return false; }

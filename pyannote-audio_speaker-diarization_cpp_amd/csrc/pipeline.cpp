@@ -2,6 +2,7 @@
 // speakerDiarization() (sd.cpp:2937-3234) re-stated as: scale pcm -> segmentation -> post-seg ->
 // embeddings -> [multi-GPU: all-gather here] -> count, clustering, reconstruction, annotation.
 #include "common.h"
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -31,6 +32,17 @@ __global__ void k_mark_inactive(int* __restrict__ hard, const int* __restrict__ 
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && nact[i] == 0) hard[i] = -2;                                  // sd.cpp:3172-3191
+}
+
+// planted workload (sd_set_planted): rows that are not NaN by the reference's rule take the planted embedding.
+// One 192-thread block per row: every thread reads element 0 before anyone overwrites it.
+__global__ void k_plant_emb(float* __restrict__ emb, const float* __restrict__ planted)
+{
+    const size_t i = (size_t)blockIdx.x * SD_EMB_DIM + threadIdx.x;
+    const float first = emb[(size_t)blockIdx.x * SD_EMB_DIM];
+    const float v = planted[i];
+    __syncthreads();
+    if (first == first) emb[i] = v;
 }
 
 static double now_ms()
@@ -193,12 +205,22 @@ static int shard_infer(sd_ctx* c, const float* d_wav, int64_t n, int64_t lo, int
     int rc;
     const double t0 = now_ms();
     if ((rc = run_segment(c, d_wav, n, lo, hi, d_seg))) return rc;
+    // planted workload: chunks [pa, pb) of this shard take their scores / embeddings from the caller's buffers
+    const int64_t pa = std::max(lo, c->planted_lo), pb = std::min(hi, c->planted_lo + c->planted_n);
+    if (pb > pa && c->planted_scores)
+        HIPCHK(c, hipMemcpyAsync(d_seg + (size_t)(pa - lo) * SD_FRAMES * 3, c->planted_scores + (size_t)(pa - c->planted_lo) * SD_FRAMES * 3,
+                                 (size_t)(pb - pa) * SD_FRAMES * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     WS(c, float, d_masks, "sh_masks", nc * 3 * SD_FRAMES);
     if ((rc = run_postseg(c, d_seg, nc, nullptr, d_masks, nullptr))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const double t1 = now_ms();
     c->stage_ms[0] += t1 - t0;
     if ((rc = run_embed(c, d_wav, n, d_masks, nc * 3, lo * 3, d_emb))) return rc;
+    if (pb > pa && c->planted_emb) {
+        hipLaunchKernelGGL(k_plant_emb, dim3((unsigned)((pb - pa) * 3)), dim3(SD_EMB_DIM), 0, c->stream,
+                           d_emb + (size_t)(pa - lo) * 3 * SD_EMB_DIM, c->planted_emb + (size_t)(pa - c->planted_lo) * 3 * SD_EMB_DIM);
+        KCHECK(c);
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stage_ms[1] += now_ms() - t1;
     return SD_OK;
@@ -256,9 +278,19 @@ extern "C" int sd_finalize_dev(sd_ctx* c, const float* d_seg, const float* d_emb
     ENTER(c);
     if (!d_seg || !d_emb || !turns || !n_turns || chunks <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_finalize_dev: bad argument");
     std::vector<sd_turn> v;
+    c->stage_ms[2] = 0;                      // per call: a rank that only finalizes never passes through sd_shard_infer_dev
     int rc = finalize(c, d_seg, d_emb, chunks, n, v);
     if (rc) return rc;
     return turns_out(c, v, turns, n_turns);
+}
+
+extern "C" int sd_set_planted(sd_ctx* c, const float* d_scores, const float* d_emb, int64_t chunk_lo, int64_t chunks)
+{
+    if (!c || chunk_lo < 0 || chunks < 0) return SD_ERR_ARG;
+    c->planted_scores = chunks > 0 ? d_scores : nullptr;
+    c->planted_emb = chunks > 0 ? d_emb : nullptr;
+    c->planted_lo = chunk_lo; c->planted_n = (d_scores || d_emb) ? chunks : 0;
+    return SD_OK;
 }
 
 extern "C" int sd_diarize_dev(sd_ctx* c, const int16_t* d_pcm, int64_t n, sd_turn** turns, int64_t* n_turns)

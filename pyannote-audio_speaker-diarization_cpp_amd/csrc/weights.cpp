@@ -65,6 +65,7 @@ static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const s
 {
     const PackTensor* w = need(c, p, wname);
     if (!w) return SD_ERR_MODEL;
+    if (w->dims.size() < 2 || w->dims.size() > 3) SD_FAIL(c, SD_ERR_MODEL, "tensor '%s' has rank %zu (conv / linear weights are [Cout][Cin] or [Cout][Cin][K])", wname.c_str(), w->dims.size());
     const int Cout = (int)w->dims[0];
     const int CinAll = (int)w->dims[1];
     const int K = w->dims.size() > 2 ? (int)w->dims[2] : 1;
@@ -199,6 +200,7 @@ int build_seg_weights(sd_ctx* c, const Pack& p)
     {
         const PackTensor* w = need(c, p, "sincnet.conv0.weight");
         if (!w) return SD_ERR_MODEL;
+        if (w->dims.size() != 3) SD_FAIL(c, SD_ERR_MODEL, "sincnet.conv0.weight must be [Cout][1][K]");
         const int Cout = (int)w->dims[0], K = (int)w->dims[2];
         if (K > 256) SD_FAIL(c, SD_ERR_MODEL, "sincnet.conv0 kernel %d > 256", K);
         std::vector<float> hw((size_t)Cout * 256, 0.0f);

@@ -35,7 +35,7 @@ EXPORTS = [
     "sd_clustering", "sd_clustering_ex", "sd_reconstruct", "sd_diarize", "sd_diarize_dev", "sd_free_turns", "sd_shard_infer_dev",
     "sd_finalize_dev", "sd_read_wav", "sd_free_pcm", "sd_format_turn", "sd_stage_ms", "sd_kernel_stats",
     "sd_reset_stats", "sd_set_option", "sd_bench_conv", "sd_bench_barrier", "sd_convert_onnx", "sd_convert_error", "sd_read_wav_f32", "sd_free_wav", "sd_diarize_f32",
-    "sd_write_rttm",
+    "sd_write_rttm", "sd_set_planted",
 ]
 
 
@@ -81,6 +81,7 @@ def lib():
     L.sd_free_wav.argtypes = [C.POINTER(C.c_float)]
     L.sd_diarize_f32.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
     L.sd_write_rttm.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Turn), i64]
+    L.sd_set_planted.argtypes = [vp, vp, vp, i64, i64]
     L.sd_format_turn.argtypes = [C.POINTER(Turn), C.c_char_p, C.c_int]
     L.sd_stage_ms.argtypes = [vp, C.POINTER(dbl)]
     L.sd_kernel_stats.argtypes = [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
@@ -335,6 +336,10 @@ class Diarizer:
         self._chk(lib().sd_finalize_dev(self._h, C.c_void_p(d_seg_ptr), C.c_void_p(d_emb_ptr), chunks, n_samples,
                                         C.byref(p), C.byref(n)))
         return self._turns(p, n)
+
+    def set_planted(self, d_scores_ptr, d_emb_ptr, chunk_lo, chunks):
+        """planted workload hook: device pointers (0 = none) for chunks [chunk_lo, chunk_lo + chunks)"""
+        self._chk(lib().sd_set_planted(self._h, C.c_void_p(d_scores_ptr or None), C.c_void_p(d_emb_ptr or None), chunk_lo, chunks))
 
     # ---- measurement
     def stage_ms(self):

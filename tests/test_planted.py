@@ -1,0 +1,191 @@
+"""Planted multi-speaker workload: segmentation scores derived from the synthetic turn
+schedule (4 talkers, overlaps, silence) and one planted embedding per (chunk, local speaker) item,
+NaN rows by the reference's own rule.  With them every stage after the two networks sees a
+NON-degenerate case -- clean-mask branch, partial-length items, K >= 4 clusters, small -> large
+re-assignment, top-count selection among several clusters, gap merging -- and the turns that come
+out of the C ABI are compared bit for bit, order included, with the oracle at the 10-min
+(BASELINE.json configs[1]) and 1-h (configs[2]) sizes."""
+import numpy as np
+import pytest
+
+import synth
+from oracle import nn_oracle as nn
+from oracle import orc, pipeline_oracle
+
+RTOL, ATOL = 1e-3, 1e-4
+
+
+def planted_case(seconds, seed, outlier_every=211):
+    pcm = synth.make_pcm(seconds, seed)
+    n = len(pcm)
+    turns = synth.with_duets(synth.schedule(seconds, seed))
+    nc = synth.num_chunks(n)
+    scores, assign = synth.planted_scores(turns, n, 0, nc)
+    emb = synth.planted_embeddings(assign, outlier_every=outlier_every)
+    return pcm, scores, assign, emb
+
+
+def nan_rule(scores):
+    """rows the reference overwrites with NaN (sd.cpp:2479-2549), from the oracle's masks of these scores"""
+    b = orc.binarize(scores)
+    masks = orc.select_masks(b)
+    per_frame = np.bincount((np.arange(80000, dtype=np.int64) * 293) // 80000, minlength=293)     # Helper::interpolate, sd.cpp:746-767
+    counts = ((masks > 0.5) * per_frame[None, :]).sum(1).astype(np.int64)
+    bad = np.zeros(len(counts), bool)
+    for b0 in range(0, len(counts), 32):
+        _, ts, an = orc.wav_lens(counts[b0:b0 + 32])
+        bad[b0:b0 + 32] = ts | an
+    return b, masks, counts, bad
+
+
+# ------------------------------------------------------------------ CPU: the planted workload itself
+def test_planted_workload_is_shard_invariant_and_non_degenerate():
+    pcm, scores, assign, emb = planted_case(600.0, 1234)
+    n = len(pcm)
+    nc = scores.shape[0]
+    assert nc == 1191 == orc.num_chunks(n)[0]                              # SURVEY 8 size table, configs[1]
+    turns = synth.with_duets(synth.schedule(600.0, 1234))
+    s2, a2 = synth.planted_scores(turns, n, 64, 160)
+    assert np.array_equal(scores[64:160], s2) and np.array_equal(assign[64:160], a2)
+    assert np.array_equal(emb[192:480], synth.planted_embeddings(a2, chunk_lo=64, outlier_every=211))
+    b, masks, counts, bad = nan_rule(scores)
+    live = ~bad
+    assert 0.3 < live.mean() < 0.8                                         # dead third speakers, silence
+    assert ((counts[live] < 80000).mean() > 0.5)                           # most live items are partial length
+    clean_used = (masks.reshape(nc, 3, 293) != b.transpose(0, 2, 1)).any(2)
+    assert clean_used.sum() > 20                                           # overlap frames removed from some masks (sd.cpp:3071)
+    e = emb.astype(np.float64)
+    e[bad] = np.nan
+    t, info = pipeline_oracle.diarize_ref(pcm, None, None, seg_override=scores, emb_override=e, return_all=True)
+    assert info["K"] == 4 and len(t) > 60
+    assert len({x[2] for x in t}) == 4
+    assert info["count"].max() >= 2                                        # overlapped speech survives counting
+    starts = [x[0] for x in t]
+    assert len(starts) > len(set(starts))                                  # equal-start turns: finalResult's std::sort order matters
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seconds,seed", [(600.0, 1234), (3600.0, 1234)])
+def test_finalize_from_planted_inputs_matches_oracle_bit_for_bit(diarizer, seconds, seed):
+    """sd_finalize_dev alone (count, a10-a14 clustering, a15-a17 reconstruction) at configs[1] / configs[2] size"""
+    import torch
+    pcm, scores, assign, emb = planted_case(seconds, seed)
+    n = len(pcm)
+    nc = scores.shape[0]
+    _, _, _, bad = nan_rule(scores)
+    e32 = emb.copy()
+    e32[bad] = np.nan
+    dev = torch.device("cuda", 0)
+    d_seg = torch.from_numpy(scores).to(dev)
+    d_emb = torch.from_numpy(e32).to(dev)
+    torch.cuda.synchronize()
+    turns = diarizer.finalize_dev(d_seg.data_ptr(), d_emb.data_ptr(), nc, n)
+    t_ref, info = pipeline_oracle.diarize_ref(pcm, None, None, seg_override=scores, emb_override=e32.astype(np.float64), return_all=True)
+    assert turns == t_ref                                                  # same turns, same order (std::sort of finalResult included)
+    assert info["K"] >= 4 and len(turns) >= (60 if seconds < 1000 else 400)
+    # the interesting branches really fired
+    X = e32[~bad].astype(np.float64)
+    N = len(X)
+    Xn = X / np.sqrt((X * X).sum(1)).astype(np.float32).astype(np.float64)[:, None]      # float norm, sd.cpp:332-357
+    T, Z = orc.ahc(Xn, orc.THRESH_F32)
+    mcs = min(15, max(1, int(round(0.1 * N))))
+    sizes = np.bincount(T)[1:]
+    assert (sizes < mcs).any() and (sizes >= mcs).sum() == info["K"]       # small clusters existed and were re-assigned (sd.cpp:2377-2412)
+    assert len(orc.to_annotation(info["binary"], info["start"], min_off=0.0)) > len(t_ref)   # Track::support merged gaps (sd.cpp:911-941)
+    assert (info["hard"] == -2).any() and info["count"].max() >= 2
+    # a12 at this size: dendrogram bit-identical (N ~ 2 000 at 10 min, ~ 12 000 at 1 h)
+    assert N > (1500 if seconds < 1000 else 9000)
+    assert np.array_equal(diarizer.linkage(Xn), Z)
+    h, K = diarizer.clustering(e32.astype(np.float64).reshape(nc, 3, 192))
+    assert K == info["K"] and np.array_equal(orc.mark_inactive(info["binarized"], h), info["hard"])
+
+
+@pytest.mark.gpu
+def test_whole_path_with_planted_scores_and_embeddings(diarizer):
+    """sd_diarize_dev end to end at the 10-min size: both networks run, their outputs are replaced by the planted ones
+    (sd_set_planted), everything after them must give the oracle's turns"""
+    import torch
+    pcm, scores, assign, emb = planted_case(600.0, 1234)
+    n, nc = len(pcm), scores.shape[0]
+    _, _, _, bad = nan_rule(scores)
+    e = emb.astype(np.float64)
+    e[bad] = np.nan
+    t_ref, info = pipeline_oracle.diarize_ref(pcm, None, None, seg_override=scores, emb_override=e, return_all=True)
+    dev = torch.device("cuda", 0)
+    d_pcm = torch.from_numpy(pcm).to(dev)
+    d_sc, d_em = torch.from_numpy(scores).to(dev), torch.from_numpy(emb).to(dev)
+    torch.cuda.synchronize()
+    diarizer.set_planted(d_sc.data_ptr(), d_em.data_ptr(), 0, nc)
+    try:
+        turns = diarizer.diarize_dev(d_pcm.data_ptr(), n)
+        # the 2-GPU plan on one GPU: shards see their part of the planted buffers
+        import sdhip
+        seg = torch.zeros((nc, 293, 3), dtype=torch.float32, device=dev)
+        em = torch.zeros((nc * 3, 192), dtype=torch.float32, device=dev)
+        per, ranges = sdhip.plan_shards(n, 2)
+        for lo, hi in ranges:
+            s0, s1 = sdhip.shard_sample_range(lo, hi, n)
+            shard = d_pcm[s0:s1].contiguous()
+            torch.cuda.synchronize()
+            diarizer.shard_infer_dev(shard.data_ptr(), s0, s1 - s0, n, lo, hi, seg[lo:].data_ptr(), em[lo * 3:].data_ptr())
+        sharded = diarizer.finalize_dev(seg.data_ptr(), em.data_ptr(), nc, n)
+    finally:
+        diarizer.set_planted(0, 0, 0, 0)
+    assert info["K"] == 4 and len(t_ref) > 60
+    assert turns == t_ref and sharded == t_ref
+    assert np.array_equal(np.isnan(em.cpu().numpy()[:, 0]), bad)
+    assert np.array_equal(seg.cpu().numpy(), scores)
+
+
+@pytest.mark.gpu
+def test_whole_path_with_planted_scores_and_real_embeddings(diarizer, weights):
+    """planted scores only: the masks are partial (clean-mask branch, nvalid < 501, dead-row panel lists non-trivial) and the
+    real ECAPA embeddings of those items go through clustering; the oracle is fed the GPU's embeddings, so every
+    non-neural stage must agree bit for bit; a sample of 96 items is checked against the torch oracle"""
+    import torch
+    seconds = 600.0
+    pcm = synth.make_pcm(seconds, 77)
+    n = len(pcm)
+    nc = synth.num_chunks(n)
+    scores, _ = synth.planted_scores(synth.schedule(seconds, 77), n, 0, nc)
+    b, masks, counts, bad = nan_rule(scores)
+    wav = pcm.astype(np.float32) / np.float32(32768.0)
+    emb = diarizer.embed(wav, masks)
+    assert np.array_equal(np.isnan(emb[:, 0]), bad)
+    dev = torch.device("cuda", 0)
+    d_pcm = torch.from_numpy(pcm).to(dev)
+    d_sc = torch.from_numpy(scores).to(dev)
+    torch.cuda.synchronize()
+    diarizer.set_planted(d_sc.data_ptr(), 0, 0, nc)
+    try:
+        turns = diarizer.diarize_dev(d_pcm.data_ptr(), n)
+    finally:
+        diarizer.set_planted(0, 0, 0, 0)
+    t_ref, info = pipeline_oracle.diarize_ref(pcm, weights[2], weights[3], seg_override=scores, emb_override=emb.astype(np.float64), return_all=True)
+    assert turns == t_ref and len(turns) > 10
+    # embed-level: 3 whole reference batches (96 items) of partial-length items against the torch oracle
+    c0 = 320                                                               # multiple of 32 chunks -> item 960 starts a batch
+    sub_wav = wav[c0 * 8000:(c0 + 31) * 8000 + 80000]
+    sub_masks = masks[3 * c0:3 * c0 + 96]
+    e_gpu = diarizer.embed(sub_wav, sub_masks)
+    assert np.array_equal(e_gpu, emb[3 * c0:3 * c0 + 96], equal_nan=True)   # batch placement does not change a row's bits
+    sigs = np.zeros((96, 80000), np.float32)
+    cnts = np.zeros(96, np.int64)
+    for i in range(96):
+        sigs[i], cnts[i] = orc.mask_compact(orc.crop(sub_wav, (i // 3) * 8000), sub_masks[i])
+    assert np.array_equal(cnts, counts[3 * c0:3 * c0 + 96])
+    lens = np.zeros(96, np.float32)
+    sbad = np.zeros(96, bool)
+    for b0 in range(0, 96, 32):
+        l, ts, an = orc.wav_lens(cnts[b0:b0 + 32])
+        lens[b0:b0 + 32] = l
+        sbad[b0:b0 + 32] = ts | an
+    ok = ~sbad
+    assert ok.sum() >= 30 and (lens[ok] < 0.999).sum() >= 20               # partial lengths: nvalid < 501
+    st = nn.stft_ref(sigs[ok], weights[3]["stft.window"])
+    f = nn.fbank_norm_ref(st, lens[ok], weights[3]["fbank.matrix"])
+    e_ref = nn.EcapaOracle(weights[3])(f, lens[ok]).numpy()
+    g = e_gpu[ok].astype(np.float64)
+    cos = (g * e_ref).sum(1) / np.linalg.norm(g, axis=1) / np.linalg.norm(e_ref, axis=1)
+    assert (1 - cos).max() < 1e-3
+    np.testing.assert_allclose(g, e_ref, rtol=RTOL, atol=ATOL * np.abs(e_ref).max())
