@@ -9,13 +9,12 @@
 //
 // Design: the condensed fp64 distance matrix (N(N-1)/2 doubles, 1.86 GB at N = 21 573) stays
 // resident in HBM.  k_pdist builds it from LDS tiles with the reference's sequential
-// per-pair summation order.  k_linkage is one persistent 1024-thread workgroup that performs
-// the N-1 dependent merges: per merge a parallel arg-min over the per-row lower bounds
-// (replacing the reference's binary heap), lazy validation of the candidate exactly as
-// fast_linkage does it, the Lance-Williams centroid update of row/column y, the neighbour
-// patches, and the nearest-neighbour refresh of row y.  Equal lower bounds are resolved to
-// the lowest row index (the heap's order for exact ties is not reproduced; distinct merge
-// heights give a bit-identical Z).  fcluster is O(N) pointer chasing and runs on the host.
+// per-pair summation order.  The N-1 dependent merges run in one of two persistent kernels:
+// k_linkage_mw (N >= 1500) replaces the reference's binary heap by a parallel arg-min over the
+// per-row lower bounds on G co-resident workgroups and takes a merge only while the closest pair
+// is unique; k_linkage_heap (small N, and the fallback at the first exact tie) is one workgroup
+// that replays the reference's heap operation by operation, so Z is bit-identical to the
+// reference for every input, ties included.  fcluster is O(N) pointer chasing and runs on the host.
 #include "common.h"
 #include <algorithm>
 #include <cfloat>
@@ -199,36 +198,91 @@ __device__ __forceinline__ MinIdx block_min(MinIdx m, MinIdx* sh)
     return r;
 }
 
-// ---------------------------------------------------------------- k_linkage : persistent single workgroup (cl.cpp:289-406)
+// ---------------------------------------------------------------- k_linkage_heap : persistent single workgroup, the reference's heap included
+// fast_linkage (cl.cpp:289-406) with its indexed binary min-heap (cl.cpp:28-119) kept bit for bit: thread 0 replays every
+// Heap operation the reference performs, in the reference's order -- heapify (cl.cpp:94), get_min / change_value in the lazy
+// validation loop (cl.cpp:323-339), remove_min (cl.cpp:340), change_value for the rows whose lower bound dropped IN ASCENDING z
+// (cl.cpp:381-392), change_value for row y (cl.cpp:395-404) -- while the O(n) parts of a merge (Lance-Williams update, neighbour
+// patches, nearest-neighbour scans) run on all threads.  Which of several rows with EXACTLY equal lower bounds the heap hands
+// out first depends on the whole history of its array, so nothing short of replaying it reproduces the reference's merge
+// order on data with ties (duplicate embeddings, lattice points); with it Z is bit-identical for any input.
+// The heap (values / key_by_index / index_by_key) lives in LDS up to HEAP_LDS entries, in global memory above.
+// The rows whose bound dropped are collected in an LDS bitmap and drained in ascending order by wave 0.
 // (no __restrict__: every array here is written by one thread and re-read by others across barriers)
-__global__ __launch_bounds__(LT) void k_linkage(double* D, int n, int* size, int* cid, int* nb, double* md, double* Z)
+#define HEAP_LDS 2048
+struct HeapRef { double* val; int* key; int* pos; int size; };
+__device__ __forceinline__ void hp_swap(HeapRef& h, int a, int b)                          // cl.cpp:70-78
 {
+    const double va = h.val[a], vb = h.val[b];
+    h.val[a] = vb; h.val[b] = va;
+    const int ka = h.key[a], kb = h.key[b];
+    h.key[a] = kb; h.key[b] = ka;
+    h.pos[ka] = b; h.pos[kb] = a;
+}
+__device__ __forceinline__ void hp_down(HeapRef& h, int idx)                                // cl.cpp:53-68
+{
+    int ch = 2 * idx + 1;
+    while (ch < h.size) {
+        if (ch + 1 < h.size && h.val[ch + 1] < h.val[ch]) ch += 1;
+        if (h.val[idx] > h.val[ch]) { hp_swap(h, idx, ch); idx = ch; ch = 2 * idx + 1; }
+        else break;
+    }
+}
+__device__ __forceinline__ void hp_up(HeapRef& h, int idx)                                  // cl.cpp:44-51
+{
+    int par = (idx - 1) >> 1;
+    while (idx > 0 && h.val[par] > h.val[idx]) { hp_swap(h, idx, par); idx = par; par = (idx - 1) >> 1; }
+}
+__device__ __forceinline__ void hp_change(HeapRef& h, int key, double v)                    // cl.cpp:108-117
+{
+    const int idx = h.pos[key];
+    const double old = h.val[idx];
+    h.val[idx] = v;
+    if (v < old) hp_up(h, idx); else hp_down(h, idx);
+}
+
+__global__ __launch_bounds__(LT) void k_linkage_heap(double* D, int n, int* size, int* cid, int* nb, double* md, double* Z,
+                                                      double* g_hval, int* g_hkey, int* g_hpos)
+{
+    extern __shared__ unsigned changed[];                 // bitmap of the rows whose bound dropped in this merge
     __shared__ MinIdx sh[LT / 64];
-    __shared__ int s_ok;
-    const int tid = threadIdx.x;
+    __shared__ int s_ok, s_x, s_y;
+    __shared__ double s_dist;
+    __shared__ double s_hv[HEAP_LDS];
+    __shared__ int s_hk[HEAP_LDS], s_hp[HEAP_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
     const int64_t N = n;
+    const bool in_lds = (n - 1) <= HEAP_LDS;
+    HeapRef h;
+    h.val = in_lds ? s_hv : g_hval; h.key = in_lds ? s_hk : g_hkey; h.pos = in_lds ? s_hp : g_hpos; h.size = n - 1;
+    const int nwords = (n + 31) / 32;
+    for (int i = tid; i < nwords; i += LT) changed[i] = 0u;
+    for (int i = tid; i < n - 1; i += LT) { h.val[i] = md[i]; h.key[i] = i; h.pos[i] = i; }         // cl.cpp:80-91
+    __syncthreads();
+    if (tid == 0) for (int i = h.size / 2; i >= 0; --i) hp_down(h, i);                                // cl.cpp:94
+    __syncthreads();
     for (int k = 0; k < n - 1; ++k) {
-        int x, y; double dist;
-        for (int guard = 0; guard <= n - k; ++guard) {
-            MinIdx m; m.v = INFINITY; m.i = -1;
-            for (int r0 = tid; r0 < n - 1; r0 += LT * 4) {           // 4 rows per thread in flight
-                double v[4]; int sz[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int r = r0 + u * LT; const int rc = r < n - 1 ? r : n - 2; v[u] = md[rc]; sz[u] = size[rc]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int r = r0 + u * LT; if (r < n - 1 && sz[u] > 0 && (m.i < 0 || v[u] < m.v)) { m.v = v[u]; m.i = r; } }
+        int x = 0, y = 0; double dist = 0.0;
+        for (int guard = 0; guard < n - k; ++guard) {                                                // cl.cpp:323
+            if (tid == 0) {
+                const int hx = h.key[0]; const double hd = h.val[0]; const int hy = nb[hx];          // get_min
+                s_x = hx; s_y = hy; s_dist = hd;
+                s_ok = (hy >= 0) && (hd == D[cidx(N, hx, hy)]);                                     // cl.cpp:329
             }
-            m = block_min(m, sh);
-            x = m.i; dist = m.v; y = nb[x];
-            if (tid == 0) s_ok = (y >= 0) && (dist == D[cidx(N, x, y)]);          // cl.cpp:329
             __syncthreads();
-            if (s_ok) break;
-            // stale candidate: recompute row x's true nearest neighbour (cl.cpp:333-338)
+            x = s_x; y = s_y; dist = s_dist;
+            const int ok = s_ok;
+            __syncthreads();
+            if (ok) break;
+            // stale candidate: row x's true nearest neighbour (cl.cpp:333-338)
             MinIdx q = scan_row_nn<4>(D, size, N, n, x, tid, LT);
             q = block_min(q, sh);
-            if (tid == 0) { nb[x] = q.i; md[x] = (q.i < 0) ? INFINITY : q.v; }
+            y = q.i; dist = (q.i < 0) ? (double)INFINITY : q.v;
+            if (tid == 0) { nb[x] = y; md[x] = dist; hp_change(h, x, dist); }
             __syncthreads();
         }
+        if (tid == 0) { hp_swap(h, 0, h.size - 1); h.size -= 1; hp_down(h, 0); }                      // remove_min, cl.cpp:101-105
+        if (y < 0) { if (tid == 0) Z[(size_t)k * 4 + 3] = NAN; return; }                             // cannot happen while two clusters are active
         const int nx = size[x], ny = size[y];
         __syncthreads();
         if (tid == 0) {
@@ -259,14 +313,34 @@ __global__ __launch_bounds__(LT) void k_linkage(double* D, int n, int* size, int
                 const double nd = lw_centroid(dzx[u], dzy[u], dist, nx, ny);           // cl.cpp:367
                 D[izy[u]] = nd;
                 if (z < x && nbz[u] == x) nb[z] = y;                                    // cl.cpp:374-378
-                if (z < y && nd < mdz[u]) { nb[z] = y; md[z] = nd; }                    // cl.cpp:381-392
+                if (z < y && nd < mdz[u]) { nb[z] = y; md[z] = nd; atomicOr(&changed[z >> 5], 1u << (z & 31)); }   // cl.cpp:381-392
+            }
+        }
+        __syncthreads();
+        // change_value(z, D[z,y]) for the rows whose bound dropped, ascending z (cl.cpp:381-392): wave 0 walks the bitmap
+        if (tid < 64) {
+            for (int w0 = 0; w0 < nwords; w0 += 64) {
+                const int wi = w0 + lane;
+                const unsigned wd = wi < nwords ? changed[wi] : 0u;
+                unsigned long long live = __ballot(wd != 0u);
+                if (wd != 0u) changed[wi] = 0u;
+                while (live) {
+                    const int l = __builtin_ctzll(live);
+                    live &= live - 1;
+                    unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)wd, l);
+                    while (bits) {
+                        const int z = (w0 + l) * 32 + __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        if (lane == 0) hp_change(h, z, md[z]);
+                    }
+                }
             }
         }
         __syncthreads();
         if (y < n - 1) {                                                              // cl.cpp:395-404
             MinIdx q = scan_row_nn<4>(D, size, N, n, y, tid, LT);
             q = block_min(q, sh);
-            if (tid == 0 && q.i >= 0) { nb[y] = q.i; md[y] = q.v; }
+            if (tid == 0 && q.i >= 0) { nb[y] = q.i; md[y] = q.v; hp_change(h, y, q.v); }
         }
         __syncthreads();
     }
@@ -286,7 +360,10 @@ __global__ __launch_bounds__(LT) void k_linkage(double* D, int n, int* size, int
 // Used from N = 1500 up, where one CU's memory pipeline is the bottleneck.
 #define MWT 256
 #define MWT_MAX 1024
-// arg-min candidate that carries its neighbour and freshness along through the reductions
+// arg-min candidate that carries its neighbour and its flags along through the reductions.
+// fresh bit 0: the bound is exact (== D[i, y]); bit 1 (CAND_TIE): some OTHER row holds exactly the same bound -- the case in
+// which the reference's heap, not the value, decides who comes first (see k_linkage_heap)
+#define CAND_TIE 2
 struct Cand { double v; int i; int y; int fresh; };
 
 __device__ __forceinline__ bool mw_barrier(unsigned* counter, unsigned target, unsigned* timeout_flag)
@@ -332,8 +409,22 @@ __device__ __forceinline__ Cand cbetter(Cand a, Cand b)
     if (b.i < 0) return a;
     if (a.i < 0) return b;
     if (b.v < a.v) return b;
-    if (b.v == a.v && b.i < a.i) return b;
+    if (b.v == a.v) {
+        Cand r = (b.i < a.i) ? b : a;
+        if (a.i != b.i && a.v < INFINITY) r.fresh |= CAND_TIE | ((a.fresh | b.fresh) & CAND_TIE);
+        return r;
+    }
     return a;
+}
+// sequential accumulation of one row into a thread's running candidate (same rules as cbetter)
+__device__ __forceinline__ void cand_acc(Cand& m, double v, int z, int y, int fresh)
+{
+    if (m.i < 0 || v < m.v) { m.v = v; m.i = z; m.y = y; m.fresh = fresh; }
+    else if (v == m.v) {
+        const int tie = (v < INFINITY) ? CAND_TIE : 0;
+        if (z < m.i) { m.i = z; m.y = y; m.fresh = fresh | tie | (m.fresh & CAND_TIE); }
+        else m.fresh |= tie;
+    }
 }
 template <int CTRL, int RM> __device__ __forceinline__ Cand dpp_step_c(Cand m)
 {
@@ -395,6 +486,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     __shared__ int s_cnt;
     __shared__ Cand s_best;
     __shared__ MinIdx s_nn;
+    __shared__ int s_rowtie;
     const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x, lane = tid & 63, wv = tid >> 6;
     const int T = blockDim.x, NW = T >> 6;
     const int64_t N = n;
@@ -451,7 +543,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                 bool skip = z < 0;
 #pragma unroll
                 for (int r = 0; r < KR; ++r) skip |= (z == ex[r]);
-                if (!skip && (m.i < 0 || v[u] < m.v || (v[u] == m.v && z < m.i))) { m.v = v[u]; m.i = z; m.y = ny_[u]; m.fresh = fr[u]; }
+                if (!skip) cand_acc(m, v[u], z, ny_[u], fr[u] & 1);
             }
         }
         return block_min_c(m, shc, NW);
@@ -492,7 +584,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     };
     // publish this workgroup's slot for the next round.  Every wave first drains its write-through stores (distance
     // matrix, bounds): whoever sees the slot may read them.
-    auto publish = [&](MinIdx q, Cand m, int nL, const MinIdx* rows) {
+    auto publish = [&](MinIdx q, Cand m, int nL, const MinIdx* rows, int row_tie = 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         ++bar;
@@ -503,6 +595,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
             STG(&sl[0], tag | (unsigned)av); STG(&sl[1], tag | (unsigned)(av >> 32)); STG(&sl[2], tag | (unsigned)m.i);
             STG(&sl[3], tag | (unsigned)m.y); STG(&sl[4], tag | (unsigned)m.fresh);
             STG(&sl[5], tag | (unsigned)nv); STG(&sl[6], tag | (unsigned)(nv >> 32)); STG(&sl[7], tag | (unsigned)q.i);
+            if (nL == 0) STG(&sl[8], tag | (unsigned)row_tie);          // rounds without refreshed rows: word 8 = "row x had a second pair at the merge height"
         }
         if (tid < nL) {
             const unsigned long long pv = (unsigned long long)__double_as_longlong(rows[tid].v);
@@ -514,6 +607,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     };
     // after a barrier: gather all slots; reduce the NN(y) partials, the refreshed rows, the global best; pick the next refresh list
     auto digest = [&](int nLprev, const int* Lprev, int yrow, bool with_nn) {
+        if (nLprev == 0) { if (tid == 0) s_rowtie = 0; __syncthreads(); if (tid < G && s_words[tid][8]) s_rowtie = 1; }
         if (tid < G) {
             Cand c; c.v = word_d(tid, 0); c.i = (int)s_words[tid][2]; c.y = (int)s_words[tid][3]; c.fresh = (int)s_words[tid][4]; s_cand[tid] = c;
             MinIdx a; a.v = word_d(tid, 5); a.i = (int)s_words[tid][7]; s_nnp[tid] = a;
@@ -565,7 +659,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                 if (idx <= G) {
                     Cand o = extra;
                     if (idx < G) o = s_cand[idx];
-                    if (o.i >= 0 && !o.fresh && o.v != INFINITY) { c[u].v = o.v; c[u].i = o.i; }
+                    if (o.i >= 0 && !(o.fresh & 1) && o.v != INFINITY) { c[u].v = o.v; c[u].i = o.i; }
                 }
             }
             // common case: at most KR stale candidates -> take them all (their order is irrelevant), no reduction needed
@@ -607,12 +701,19 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         Cand m0 = local_argmin(0, s_L[0]);
         publish(none, m0, 0, s_row);
     }
-    if (!consume(8)) return;
+    if (!consume(9)) return;
     digest(0, s_L[0], -1, false);
     par ^= 1;
     Cand best = s_best;
-    if (!(best.fresh && best.y >= 0)) pick_stale(nocand, lp);
-    int x = best.i, y = best.y; double dist = best.v; bool fresh = best.fresh != 0;
+    if (!((best.fresh & 1) && best.y >= 0)) pick_stale(nocand, lp);
+    int x = best.i, y = best.y; double dist = best.v; bool fresh = (best.fresh & 1) != 0;
+    // a merge is taken from the arg-min only when its pair is the UNIQUE closest pair; otherwise the kernel stops and
+    // run_linkage repeats the job with k_linkage_heap, which owns the reference's tie order
+    auto tie_stop = [&](int flags) -> bool {
+        if (!(flags & CAND_TIE)) return false;
+        if (g == 0 && tid == 0) sync[5] = 1;
+        return true;
+    };
 
     for (int k = 0; k < n - 1; ++k) {
         // ---- lazy validation (cl.cpp:323-339): cooperative refresh of the KR best stale candidates per round
@@ -626,17 +727,18 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
             Cand m = local_argmin(nL, L);
             publish(none, m, nL, s_row);
             STAMP2(1);
-            if (!consume(8 + 3 * nL)) return;
+            if (!consume(nL > 0 ? 8 + 3 * nL : 9)) return;
             STAMP2(2);
             digest(nL, L, -1, false);
             par ^= 1;
             best = s_best;
             STAMP2(3);
             lp ^= 1;
-            if (!(best.fresh && best.y >= 0)) pick_stale(nocand, lp);
+            if (!((best.fresh & 1) && best.y >= 0)) pick_stale(nocand, lp);
             STAMP2(4);
-            x = best.i; dist = best.v; y = best.y; fresh = best.fresh != 0;
+            x = best.i; dist = best.v; y = best.y; fresh = (best.fresh & 1) != 0;
         }
+        if (tie_stop(best.fresh)) return;
         // ---- merge (x, y) at height dist
         const int nx = size[x], ny = size[y];
         __syncthreads();
@@ -661,6 +763,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         STAMP2(5);
         MinIdx q = none;
         Cand m; m.v = INFINITY; m.i = -1; m.y = -1; m.fresh = 0;
+        int row_tie = 0;
         const int cnt = s_cnt;
         int zdummy = 0;                                   // any valid row other than x and y (n >= 3 here)
         while (zdummy == x || zdummy == y) ++zdummy;
@@ -685,6 +788,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                 if (z < 0) continue;
                 const double nd = lw_centroid(dzx[u], dzy[u], dist, nx, ny);
                 STG(&D[izy[u]], nd);
+                if (z > x && dzx[u] == dist) row_tie = 1;         // row x had a second neighbour at exactly the merge height
                 double mz = (z < n - 1) ? mdz[u] : INFINITY; int nz = nbz[u], fz = frz[u];
                 if (z < y) {
                     bool touch = false;
@@ -693,19 +797,21 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                     if (nd < mz) { nz = y; mz = nd; fz = 1; STG(&md[z], nd); STG(&nb[z], y); fresh_flag[z] = 1; }
                     else if (touch) { fz = (mz == nd); STG(&nb[z], nz); fresh_flag[z] = (unsigned char)fz; }
                 } else if (nd < q.v || (nd == q.v && z < q.i)) { q.v = nd; q.i = z; }
-                if (z < n - 1 && (m.i < 0 || mz < m.v || (mz == m.v && z < m.i))) { m.v = mz; m.i = z; m.y = nz; m.fresh = fz; }
+                if (z < n - 1) cand_acc(m, mz, z, nz, fz);
             }
         }
         STAMP2(6);
         q = block_min_t(q, sh, NW);
         m = block_min_c(m, shc, NW);
-        publish(q, m, 0, s_row);
+        row_tie = __syncthreads_or(row_tie);
+        publish(q, m, 0, s_row, row_tie);
         STAMP2(7);
-        if (!consume(8)) return;
+        if (!consume(9)) return;
         STAMP2(2);
         digest(0, s_L[lp], y, true);
         STAMP2(3);
         par ^= 1;
+        if (s_rowtie) { if (g == 0 && tid == 0) sync[5] = 1; return; }
         best = s_best;
         const MinIdx nn = s_nn;
         // row y: exact by construction when it has an active neighbour above (cl.cpp:395-404), else its old (stale) bound
@@ -718,12 +824,12 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                 cy.v = LDG(&md[y]); cy.i = y; cy.y = LDG(&nb[y]); cy.fresh = 0;
                 if (tid == 0 && (y % G) == g) fresh_flag[y] = 0;
             }
-            if (best.i < 0 || cy.v < best.v || (cy.v == best.v && y < best.i)) best = cy;
+            best = cbetter(best, cy);
         }
         lp ^= 1;
-        if (!(best.fresh && best.y >= 0)) pick_stale(cy, lp);
+        if (!((best.fresh & 1) && best.y >= 0)) pick_stale(cy, lp);
         STAMP2(4);
-        x = best.i; dist = best.v; y = best.y; fresh = best.fresh != 0;
+        x = best.i; dist = best.v; y = best.y; fresh = (best.fresh & 1) != 0;
     }
 #ifdef SD_LINKAGE_STAMPS
     if (g == 0 && tid == 0) for (int i = 0; i < 8; ++i) sync[8 + i] = (unsigned)(acc[i] / 100);   // microseconds
@@ -766,16 +872,13 @@ __global__ void k_fill_i32(int* p, int v, int64_t n, int iota)
 }
 
 // X[N][d] (rows as given; Clustering::linkage does not normalise) -> Z[N-1][4] on the device
-int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
+//   N < 1500 (or option linkage_wgs = 0): k_linkage_heap, the reference's algorithm heap included.
+//   above: k_linkage_mw on G co-resident workgroups (cooperative launch: the runtime guarantees residency or refuses).  It
+//   takes a merge from its parallel arg-min only while the closest pair is unique; at the first exact tie (duplicate
+//   embeddings), on a refused launch or on a poll timeout the distance matrix is rebuilt and k_linkage_heap does the job.
+static int linkage_prepare(sd_ctx* c, const double* d_X, int64_t N, int d, double* D, int* size, int* cid, int* nb, double* md)
 {
-    if (N < 2) return SD_OK;
     const int64_t m = N * (N - 1) / 2;
-    if (N > 0x7fffffff / 4 || (double)m * 8.0 > 230e9) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs a %.0f GB condensed matrix (limit 230 GB)", (long long)N, (double)m * 8e-9);
-    WS(c, double, D, "cl_D", m);
-    WS(c, int, size, "cl_size", N);
-    WS(c, int, cid, "cl_cid", N);
-    WS(c, int, nb, "cl_nb", N);
-    WS(c, double, md, "cl_md", N);
     const int tiles = (int)((N + PT - 1) / PT);
     {
         ProfScope ps(c, "pdist", (double)m * d * 3.0, (double)m * 8.0 + (double)N * d * 8.0);
@@ -790,44 +893,79 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         hipLaunchKernelGGL(k_row_nn, dim3((unsigned)((N - 1 + 3) / 4)), dim3(256), 0, c->stream, D, N, nb, md);
         KCHECK(c);
     }
+    return SD_OK;
+}
+
+static int linkage_heap(sd_ctx* c, int64_t N, double* D, int* size, int* cid, int* nb, double* md, double* d_Z)
+{
+    double* hval = nullptr; int* hkey = nullptr; int* hpos = nullptr;
+    if (N - 1 > HEAP_LDS) {
+        WS(c, double, hv, "cl_hval", N);
+        WS(c, int, hk, "cl_hkey", N);
+        WS(c, int, hp, "cl_hpos", N);
+        hval = hv; hkey = hk; hpos = hp;
+    }
+    ProfScope ps(c, "linkage_heap", 0, 24.0 * (double)N * (double)N);
+    hipLaunchKernelGGL(k_linkage_heap, dim3(1), dim3(LT), (size_t)((N + 31) / 32) * sizeof(unsigned), c->stream, D, (int)N, size, cid, nb, md, d_Z, hval, hkey, hpos);
+    KCHECK(c);
+    return SD_OK;
+}
+
+int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
+{
+    if (N < 2) return SD_OK;
+    const int64_t m = N * (N - 1) / 2;
+    if (N > 0x7fffffff / 4 || (double)m * 8.0 > 230e9) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs a %.0f GB condensed matrix (limit 230 GB)", (long long)N, (double)m * 8e-9);
+    WS(c, double, D, "cl_D", m);
+    WS(c, int, size, "cl_size", N);
+    WS(c, int, cid, "cl_cid", N);
+    WS(c, int, nb, "cl_nb", N);
+    WS(c, double, md, "cl_md", N);
+    int rc;
+    if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md))) return rc;
     int G = (int)c->linkage_wgs;
     if (G < 0) G = N >= 60000 ? 128 : N >= 15000 ? 64 : N >= 1500 ? 32 : 0;     // auto (measured on clustered data, profiles/r01_linkage_scaling.txt)
     if (G > c->num_cu) G = c->num_cu;
     int TH = (int)c->linkage_threads;
     if (TH <= 0) TH = N >= 15000 ? 512 : 256;          // measured: 327 vs 337 ms at N = 21 573, 4.68 vs 4.85 s at N = 172 773
     TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : 256;
-    if (G <= 1) {
+    if (G <= 1) return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
+    if ((N + G - 1) / G > 7000) G = (int)((N + 6999) / 7000);      // active-row lists live in LDS: 8 B per owned row
+    if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
+    int cap = (int)((N + G - 1) / G) + 1;
+    WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * SLOT_WORDS);
+    HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * SLOT_WORDS * sizeof(MwGran), c->stream));
+    WS(c, int, size_all, "cl_size_all", (int64_t)G * N);
+    WS(c, unsigned char, fresh_flag, "cl_fresh", N + 16);
+    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)(((int64_t)G * N + 255) / 256)), dim3(256), 0, c->stream, size_all, 1, (int64_t)G * N, 0);
+    KCHECK(c);
+    WS(c, unsigned, sync, "cl_sync", 16);
+    HIPCHK(c, hipMemsetAsync(sync, 0, 16 * sizeof(unsigned), c->stream));
+    const char* why = nullptr;
+    {
         ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
-        hipLaunchKernelGGL(k_linkage, dim3(1), dim3(LT), 0, c->stream, D, (int)N, size, cid, nb, md, d_Z);
-        KCHECK(c);
-    } else {
-        if ((N + G - 1) / G > 7000) G = (int)((N + 6999) / 7000);      // active-row lists live in LDS: 8 B per owned row
-        if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
-        int cap = (int)((N + G - 1) / G) + 1;
-        WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * SLOT_WORDS);
-        HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * SLOT_WORDS * sizeof(MwGran), c->stream));
-        WS(c, int, size_all, "cl_size_all", (int64_t)G * N);
-        WS(c, unsigned char, fresh_flag, "cl_fresh", N + 16);
-        hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)(((int64_t)G * N + 255) / 256)), dim3(256), 0, c->stream, size_all, 1, (int64_t)G * N, 0);
-        KCHECK(c);
-        WS(c, unsigned, sync, "cl_sync", 16);
-        HIPCHK(c, hipMemsetAsync(sync, 0, 16 * sizeof(unsigned), c->stream));
-        {
-            ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
-            hipLaunchKernelGGL(k_linkage_mw, dim3(G), dim3(TH), (size_t)cap * 8, c->stream, D, (int)N, size_all, cid, nb, md, fresh_flag, d_Z, gran, sync, cap);
-            KCHECK(c);
-        }
-        unsigned h[16] = {0};
+        int n_i = (int)N;
+        void* args[] = {&D, &n_i, &size_all, &cid, &nb, &md, &fresh_flag, &d_Z, &gran, &sync, &cap};
+        // cooperative launch: all G workgroups are resident together, or the launch is refused (they poll each other's slots)
+        const hipError_t le = hipLaunchCooperativeKernel((const void*)k_linkage_mw, dim3(G), dim3(TH), args, (size_t)cap * 8, c->stream);
+        if (le != hipSuccess) { (void)hipGetLastError(); why = "cooperative launch refused"; }
+    }
+    unsigned h[16] = {0};
+    if (!why) {
         HIPCHK(c, hipMemcpyAsync(h, sync, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (h[1]) SD_FAIL(c, SD_ERR_HIP, "linkage: device-scope barrier timed out (workgroups not co-resident?)");
         c->stats["linkage_retry_rounds"].flops += (double)h[2];
-        c->stats["linkage_flag_conservative"].flops += (double)h[3];
 #ifdef SD_LINKAGE_STAMPS
         fprintf(stderr, "linkage stamps (us): retry-scan %u retry-argmin %u barrier %u digest %u pick %u bookkeeping %u lw %u reductions %u\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
 #endif
+        if (h[1]) why = "slot poll timed out";
+        else if (h[5]) { why = "exact tie"; c->stats["linkage_tie_fallbacks"].launches += 1; }
     }
-    return SD_OK;
+    if (!why) return SD_OK;
+    c->stats["linkage_fallbacks"].launches += 1;
+    if (c->profile_detail) fprintf(stderr, "linkage: %s at N = %lld -> k_linkage_heap\n", why, (long long)N);
+    if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md))) return rc;
+    return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
 }
 
 // fcluster(criterion="distance"), cl.cpp:121-232 + 442-457.  Node ids grow with merge order, so the

@@ -198,13 +198,9 @@ def test_linkage_bit_exact(diarizer, N, d):
     cutoff = orc.THRESH_F32 if d > 2 else 1.1
     T_ref, Z_ref = orc.ahc(X, cutoff)
     Z = diarizer.linkage(X)
-    if d > 2:
-        assert np.array_equal(Z, Z_ref)                        # bit-identical dendrogram
-    else:
-        # the 12-point grid of cluster.cpp:8-13 is all exact ties (unit distances): merge ORDER among equal
-        # heights follows the arg-min's lowest-row rule instead of the heap; the
-        # heights and the flat clustering must still agree
-        assert np.array_equal(np.sort(Z[:, 2]), np.sort(Z_ref[:, 2])) and np.array_equal(np.sort(Z[:, 3]), np.sort(Z_ref[:, 3]))
+    # bit-identical dendrogram -- also on the 12-point grid of cluster.cpp:8-13, which is all exact ties (unit distances):
+    # the merge order among equal heights is the reference heap's (k_linkage_heap)
+    assert np.array_equal(Z, Z_ref)
     assert np.array_equal(diarizer.cluster(X, cutoff), T_ref)
 
 
@@ -225,18 +221,56 @@ def test_cooperative_linkage_bit_exact(diarizer, N, G, T):
     assert np.array_equal(Z, Z_ref)
 
 
-def test_linkage_with_exact_ties_gives_same_partition(diarizer):
-    # duplicate rows: the heap's order for exactly equal candidates is not reproduced;
-    # the flat clustering must still agree
+def _tie_sets():
     rng = np.random.default_rng(9)
     X = _blobs(rng, 200)
-    X[7] = X[3]; X[19] = X[3]; X[30] = X[11]; X[150] = X[149]
-    T_ref, _ = orc.ahc(X, orc.THRESH_F32)
-    T = diarizer.cluster(X, orc.THRESH_F32)
-    m = {}
-    for a, b in zip(T.tolist(), T_ref.tolist()):
-        assert m.setdefault(a, b) == b
-    assert len(set(m.values())) == len(m)
+    X[7] = X[3]; X[19] = X[3]; X[30] = X[11]; X[150] = X[149]               # duplicate embeddings (looped audio, digital silence)
+    yield "duplicates", X
+    g = np.stack(np.meshgrid(np.arange(8.0), np.arange(8.0), np.arange(8.0)), -1).reshape(-1, 3)   # 512 lattice points: almost every merge is a tie
+    yield "lattice", g[rng.permutation(len(g))]
+    Y = _blobs(rng, 2400)
+    Y[rng.integers(0, 2400, 300)] = Y[rng.integers(0, 2400, 300)]            # ~300 duplicated rows in a set large enough for the cooperative kernel
+    yield "big_duplicates", Y
+
+
+@pytest.mark.parametrize("G", [-1, 0, 16])
+def test_linkage_with_exact_ties_is_bit_identical(diarizer, G):
+    """exact ties are resolved by the reference's heap (clustering.cpp:28-119, 323-404), not by value: Z must still be
+    array_equal.  G = 0 forces k_linkage_heap (heap in global memory above 2048 rows), G = 16 forces the cooperative kernel,
+    which has to notice the first tie and hand the job over."""
+    for name, X in _tie_sets():
+        T_ref, Z_ref = orc.ahc(X, orc.THRESH_F32)
+        fb0 = diarizer.kernel_stats("linkage_tie_fallbacks")["launches"]
+        diarizer.set_option("linkage_wgs", G)
+        try:
+            Z = diarizer.linkage(X)
+            T = diarizer.cluster(X, orc.THRESH_F32)
+        finally:
+            diarizer.set_option("linkage_wgs", -1)
+        assert np.array_equal(Z, Z_ref), (name, G)
+        assert np.array_equal(T, T_ref), (name, G)
+        used_mw = (G == 16 and len(X) > 16) or (G == -1 and len(X) >= 1500)
+        assert (diarizer.kernel_stats("linkage_tie_fallbacks")["launches"] - fb0 == 2) == used_mw, (name, G)
+
+
+def test_heap_linkage_with_global_heap_is_bit_identical(diarizer):
+    """k_linkage_heap with its heap in global memory (N - 1 > 2048 entries), tie-free data"""
+    X = _blobs(np.random.default_rng(77), 3000)
+    _, Z_ref = orc.ahc(X, orc.THRESH_F32)
+    diarizer.set_option("linkage_wgs", 0)
+    try:
+        Z = diarizer.linkage(X)
+    finally:
+        diarizer.set_option("linkage_wgs", -1)
+    assert np.array_equal(Z, Z_ref)
+
+
+def test_tie_free_data_never_leaves_the_cooperative_kernel(diarizer):
+    fb0 = diarizer.kernel_stats("linkage_fallbacks")["launches"]
+    X = _blobs(np.random.default_rng(5), 4000)
+    _, Z_ref = orc.ahc(X, orc.THRESH_F32)
+    assert np.array_equal(diarizer.linkage(X), Z_ref)
+    assert diarizer.kernel_stats("linkage_fallbacks")["launches"] == fb0
 
 
 def test_clustering_parity(diarizer):

@@ -83,6 +83,28 @@ def test_linkage_with_duplicates_matches_reference_heap_order():
     assert np.array_equal(Z, linkage(X, "centroid", "euclidean"))
 
 
+def test_tie_heavy_sets_match_the_reference_build():
+    """the sets the GPU tie tests use (tests/test_gpu_parity.py::_tie_sets), pinned on the reference's own clustering.cpp:
+    lattice points (almost every merge is an exact tie) and duplicated rows"""
+    R = orc.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    rng = np.random.default_rng(9)
+    g = np.stack(np.meshgrid(np.arange(8.0), np.arange(8.0), np.arange(8.0)), -1).reshape(-1, 3)
+    Y = _blobs(rng, 900, d=16)
+    Y[rng.integers(0, 900, 120)] = Y[rng.integers(0, 900, 120)]
+    for X in (g[rng.permutation(len(g))], Y):
+        X = np.ascontiguousarray(X)
+        N = len(X)
+        T, Z = orc.ahc(X, orc.THRESH_F32)
+        Zr = np.zeros((N - 1, 4))
+        R.ref_linkage(X, N, X.shape[1], Zr)
+        Tr = np.zeros(N, np.int32)
+        R.ref_cluster(X, N, X.shape[1], orc.THRESH_F32, Tr)
+        assert np.array_equal(Z, Zr) and np.array_equal(T, Tr)
+        assert len(np.unique(Z[:, 2])) < N - 1                      # the set really has tied merge heights
+
+
 def test_binarize_semantics():
     rng = np.random.default_rng(1)
     seg = rng.random((7, 293, 3)).astype(np.float32)

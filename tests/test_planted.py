@@ -162,7 +162,7 @@ def test_whole_path_with_planted_scores_and_real_embeddings(diarizer, weights):
     finally:
         diarizer.set_planted(0, 0, 0, 0)
     t_ref, info = pipeline_oracle.diarize_ref(pcm, weights[2], weights[3], seg_override=scores, emb_override=emb.astype(np.float64), return_all=True)
-    assert turns == t_ref and len(turns) > 10
+    assert turns == t_ref and len(turns) >= 5        # (the random-weight ECAPA separates items by length, not by talker: few clusters)
     # embed-level: 3 whole reference batches (96 items) of partial-length items against the torch oracle
     c0 = 320                                                               # multiple of 32 chunks -> item 960 starts a batch
     sub_wav = wav[c0 * 8000:(c0 + 31) * 8000 + 80000]
