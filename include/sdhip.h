@@ -116,9 +116,8 @@ int sd_diarize(sd_ctx*, const int16_t* h_pcm, int64_t n, sd_turn** turns, int64_
 int sd_diarize_dev(sd_ctx*, const int16_t* d_pcm, int64_t n, sd_turn** turns, int64_t* n_turns);
 void sd_free_turns(sd_turn*);
 
-/* ---- multi-GPU split of the same path: ranks run infer on their
- * contiguous chunk range (multiple of 32 chunks), all-gather d_seg / d_emb with
- * RCCL (torch.distributed), then any rank finalizes. */
+/* ---- the two halves of the multi-GPU path as separate calls (a host that brings its own collective): ranks run infer on
+ * their contiguous chunk range (multiple of 32 chunks), exchange d_seg / d_emb, then any rank finalizes. */
 /* d_pcm_shard holds samples [first_sample, first_sample + shard_samples) of the n_total-sample
  * recording and must cover [chunk_lo*8000, min(n_total, (chunk_hi-1)*8000 + 80000)). */
 int sd_shard_infer_dev(sd_ctx*, const int16_t* d_pcm_shard, int64_t first_sample, int64_t shard_samples,
@@ -126,6 +125,29 @@ int sd_shard_infer_dev(sd_ctx*, const int16_t* d_pcm_shard, int64_t first_sample
                        float* d_seg /*[hi-lo][293][3]*/, float* d_emb /*[(hi-lo)*3][192]*/);
 int sd_finalize_dev(sd_ctx*, const float* d_seg, const float* d_emb, int64_t chunks, int64_t n,
                     sd_turn** turns, int64_t* n_turns);
+
+/* ---- the same path on several GPUs under the boundary (comm.cpp): one process per GPU, RCCL all-gather of scores and
+ * embeddings over xGMI on the library's stream, clustering on rank 0.  Replaces speakerDiarization() (sd.cpp:2937-3234)
+ * for long recordings; the reference has no counterpart (single device, onnx_model.cc:21-71).
+ * Bootstrap: rank 0 calls sd_comm_unique_id (needs a GPU) and the host program hands the SD_COMM_ID_BYTES bytes to every
+ * rank; then every rank calls sd_comm_init with the same id (collective, like ncclCommInitRank).  */
+#define SD_COMM_ID_BYTES 128
+int sd_comm_unique_id(void* id /*[SD_COMM_ID_BYTES]*/);
+int sd_comm_init(sd_ctx*, const void* id, int rank, int world);
+int sd_comm_destroy(sd_ctx*);
+int sd_comm_info(const sd_ctx*, int* rank, int* world /* 0 = no communicator */);
+/* host-only: chunk range [ranges[2r], ranges[2r+1]) of every rank r for an n_total-sample recording -- contiguous, each
+ * starting on a multiple of 32 chunks (= 3 reference embedding batches) -- and the slot size (chunks) of the padded
+ * all-gather.  rank0_permille = share of the chunks rank 0 infers itself (it also finalizes), -1 = equal shares; the
+ * library uses option "rank0_permille" for the same plan.  Rank r needs samples
+ * [lo*8000, min(n_total, (hi-1)*8000 + 80000)). */
+int sd_shard_plan(int64_t n_total, int world, int rank0_permille, int64_t* ranges /*[world][2]*/, int64_t* slot_chunks);
+/* collective: every rank passes the samples of its range (h_/d_pcm_shard[0] is sample first_sample of the recording).
+ * Rank 0 receives the turns; the other ranks return *n_turns = 0 as soon as their all-gather is queued. */
+int sd_diarize_sharded(sd_ctx*, const int16_t* h_pcm_shard, int64_t first_sample, int64_t shard_samples, int64_t n_total,
+                       sd_turn** turns, int64_t* n_turns);
+int sd_diarize_sharded_dev(sd_ctx*, const int16_t* d_pcm_shard, int64_t first_sample, int64_t shard_samples, int64_t n_total,
+                           sd_turn** turns, int64_t* n_turns);
 
 /* ---- planted workload (measurement / test hook, SURVEY 8d: "with synthetic weights force a deterministic activity
  * pattern for stage >= a4 (override sigmoid outputs from the schedule) so N is controlled").  With seeded random
@@ -147,8 +169,18 @@ void sd_free_pcm(int16_t*);
 int sd_read_wav_f32(const char* path, float** wav, int64_t* n, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample);
 void sd_free_wav(float*);
 int sd_diarize_f32(sd_ctx*, const float* h_wav, int64_t n, sd_turn** turns, int64_t* n_turns);
-/* RTTM file of the turns ("SPEAKER <uri> 1 <start> <dur> <NA> <NA> SPEAKER_kk <NA> <NA>"), SURVEY 8f-4 */
+/* ---- output formats (the reference prints raw cluster ids to stdout only, sd.cpp:3433-3441) */
+/* RTTM file of the turns ("SPEAKER <uri> 1 <start> <dur> <NA> <NA> SPEAKER_kk <NA> <conf|NA>") */
 int sd_write_rttm(const char* path, const char* uri, const sd_turn* turns, int64_t n_turns);
+int sd_write_rttm_ex(const char* path, const char* uri, const sd_turn* turns, int64_t n_turns, const double* conf /* or NULL */);
+/* renumber the labels in place: mode 1 (sd_relabel_turns) = pyannote.audio's SPEAKER_00.. convention (the labels that occur,
+ * sorted by their decimal string, pyannote.core Annotation.labels()); mode 0 = order of first appearance */
+int sd_relabel_turns(sd_turn* turns, int64_t n_turns);
+int sd_relabel_turns_ex(sd_turn* turns, int64_t n_turns, int mode);
+/* per-turn confidence of the turns the last sd_diarize* / sd_finalize_dev of this ctx returned (same order): mean soft score
+ * (2 - cosine distance to the cluster centroid, soft_clusters of sd.cpp:2191-2207; range 0..2) of the (chunk, local speaker)
+ * items assigned to the turn's cluster whose chunk overlaps the turn; NaN when no such item has an embedding */
+int sd_last_confidence(const sd_ctx*, double* conf, int64_t cap, int64_t* n);
 
 /* ---- a18: the reference's output line (sd.cpp:3439) */
 int sd_format_turn(const sd_turn* t, char* buf, int cap);
@@ -161,7 +193,10 @@ int sd_stage_ms(const sd_ctx*, double* ms4);
 int sd_kernel_stats(const sd_ctx*, const char* kernel, double* total_ms, int64_t* launches, double* flops, double* bytes);
 void sd_reset_stats(sd_ctx*);
 /* keys: "emb_batch_items", "seg_batch_chunks", "profile", "linkage_wgs" (-1 auto, 0 one workgroup), "linkage_threads",
- * "skip_dead_rows", "num_clusters", "min_clusters", "max_clusters", "ecapa_precision" (0 = f32 MFMA, 1 = fp16 MFMA) */
+ * "skip_dead_rows", "num_clusters", "min_clusters", "max_clusters", "ecapa_precision" (0 = f32 MFMA, 1 = fp16 MFMA),
+ * "rank0_permille" (sd_diarize_sharded: share of rank 0, -1 = equal), "virtual_world" (test mode: a communicator of ONE rank plays all W
+ * ranks of the plan in turn, slot by slot, so plan + slot assembly of a W-GPU job run on a 1-GPU box), "constrained_assignment" (1 = constrained_argmax of
+ * clustering/Clustering.py:81-94: the local speakers of a chunk go to different clusters; applies to sd_clustering* and the whole path) */
 int sd_set_option(sd_ctx*, const char* key, int64_t value);
 /* tuning hook (tools/tune_conv.py): time one conv_gemm shape on scratch data; dbg selects an ablation */
 int sd_bench_barrier(sd_ctx*, int workgroups, int iters, int dirty_doubles, double* us_per_barrier);

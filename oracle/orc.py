@@ -60,6 +60,12 @@ def lib():
     L.orc_clustering.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, C.c_float, C.c_long, c_ip, C.c_void_p, C.POINTER(C.c_long)]
     L.orc_clustering_ex.restype = C.c_int
     L.orc_clustering_ex.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, C.c_float, C.c_long, C.c_int, C.c_int, C.c_int, c_ip, C.c_void_p, C.POINTER(C.c_long)]
+    L.orc_clustering_full.restype = C.c_int
+    L.orc_clustering_full.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, C.c_float, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, c_ip, C.c_void_p,
+                                      C.POINTER(C.c_long), C.c_void_p, C.c_long]
+    L.orc_linear_sum_assignment.restype = C.c_int
+    L.orc_linear_sum_assignment.argtypes = [c_dp, C.c_int, C.c_int, C.c_int, c_ip, c_ip]
+    L.orc_constrained_argmax.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, c_ip]
     L.orc_cluster_embeddings_ex.restype = C.c_int
     L.orc_cluster_embeddings_ex.argtypes = [c_dp, C.c_long, C.c_int, C.c_float, C.c_long, C.c_int, C.c_int, C.c_int, c_ip]
     L.orc_mark_inactive.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, c_ip]
@@ -262,6 +268,37 @@ def clustering(emb, threshold=THRESH_F32, min_cluster_size=MIN_CLUSTER_SIZE, num
     K = lib().orc_clustering_ex(emb, c, S, d, threshold, min_cluster_size, num_clusters, min_clusters, max_clusters,
                                 hard, tl.ctypes.data, C.byref(nt))
     return hard, K, tl[:nt.value].copy()
+
+
+def clustering_full(emb, constrained=False, num_clusters=-1, min_clusters=-1, max_clusters=-1, threshold=THRESH_F32,
+                    min_cluster_size=MIN_CLUSTER_SIZE):
+    """like clustering(), optionally with constrained_argmax (Clustering.py:81-94); also returns soft [c][S][K]"""
+    emb = np.ascontiguousarray(emb, np.float64)
+    c, S, d = emb.shape
+    hard = np.zeros((c, S), np.int32)
+    tl = np.zeros(c * S, np.int32)
+    nt = C.c_long(0)
+    cap = c * S * 256
+    soft = np.zeros(cap, np.float64)
+    K = lib().orc_clustering_full(emb, c, S, d, threshold, min_cluster_size, num_clusters, min_clusters, max_clusters, int(constrained),
+                                  hard, tl.ctypes.data, C.byref(nt), soft.ctypes.data, cap)
+    return hard, K, soft[:c * S * max(K, 0)].reshape(c, S, max(K, 0)).copy()
+
+
+def linear_sum_assignment(cost, maximize=False):
+    cost = np.ascontiguousarray(cost, np.float64)
+    nr, nc = cost.shape
+    ri, ci = np.zeros(max(nr, nc), np.int32), np.zeros(max(nr, nc), np.int32)
+    n = lib().orc_linear_sum_assignment(cost, nr, nc, int(maximize), ri, ci)
+    return ri[:n].copy(), ci[:n].copy()
+
+
+def constrained_argmax(soft):
+    soft = np.ascontiguousarray(soft, np.float64)
+    c, S, K = soft.shape
+    hard = np.zeros((c, S), np.int32)
+    lib().orc_constrained_argmax(soft, c, S, K, hard)
+    return hard
 
 
 def cluster_embeddings_ex(X, num_clusters=-1, min_clusters=-1, max_clusters=-1, threshold=THRESH_F32, min_cluster_size=MIN_CLUSTER_SIZE):

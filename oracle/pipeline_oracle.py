@@ -7,10 +7,11 @@ from . import nn_oracle as nn
 from . import orc
 
 
-def diarize_ref(pcm, ws, we, seg_override=None, emb_override=None, return_all=False):
+def diarize_ref(pcm, ws, we, seg_override=None, emb_override=None, return_all=False, planted=None):
     """pcm int16 [n] -> list of (start, end, label) sorted by start.
     seg_override / emb_override let a test inject the GPU's network outputs so the non-neural
-    stages can be compared bit-for-bit."""
+    stages can be compared bit-for-bit.  planted = (scores, emb) mirrors sd_set_planted: both networks run (so a timing
+    includes them), then their outputs are replaced exactly as the library does it (NaN rows by rule are kept)."""
     wav = (pcm.astype(np.float32) * np.float32(1.0)) / np.float32(32768.0)      # sd.cpp:2950
     n = len(wav)
     nc, last_len = orc.num_chunks(n)
@@ -29,6 +30,8 @@ def diarize_ref(pcm, ws, we, seg_override=None, emb_override=None, return_all=Fa
             seg[full, :y.shape[0]] = y[:orc.FRAMES]
     else:
         seg = np.asarray(seg_override, np.float32)
+    if planted is not None and planted[0] is not None:
+        seg = np.asarray(planted[0], np.float32)
     binar = orc.binarize(seg)
     count, cwin, ft = orc.speaker_count(binar)
     masks = orc.select_masks(binar)
@@ -54,6 +57,10 @@ def diarize_ref(pcm, ws, we, seg_override=None, emb_override=None, return_all=Fa
             emb[b0:b1] = e
     else:
         emb = np.asarray(emb_override, np.float64)
+    if planted is not None and planted[1] is not None:
+        live = ~np.isnan(emb[:, 0])
+        emb = emb.copy()
+        emb[live] = np.asarray(planted[1], np.float64)[live]
     hard, K, _ = orc.clustering(emb.reshape(nc, 3, 192))
     hard = orc.mark_inactive(binar, hard)
     binary, start = orc.reconstruct(seg, hard, count, cwin, ft, n)

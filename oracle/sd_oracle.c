@@ -607,6 +607,9 @@ done:
 /* ------------------------------------------------------------------ */
 int orc_clustering_ex(const double *emb, long c, int S, int d, float threshold, long min_cluster_size_cfg,
                       int num_clusters, int min_clusters, int max_clusters, int *hard, int *train_labels_out, long *ntrain_out);
+int orc_clustering_full(const double *emb, long c, int S, int d, float threshold, long min_cluster_size_cfg,
+                        int num_clusters, int min_clusters, int max_clusters, int constrained, int *hard, int *train_labels_out,
+                        long *ntrain_out, double *soft_out, long soft_cap);
 int orc_clustering(const double *emb, long c, int S, int d, float threshold,
                    long min_cluster_size_cfg, int *hard, int *train_labels_out, long *ntrain_out)
 {
@@ -614,6 +617,102 @@ int orc_clustering(const double *emb, long c, int S, int d, float threshold,
 }
 int orc_clustering_ex(const double *emb, long c, int S, int d, float threshold, long min_cluster_size_cfg,
                       int num_clusters, int min_clusters, int max_clusters, int *hard, int *train_labels_out, long *ntrain_out)
+{
+    return orc_clustering_full(emb, c, S, d, threshold, min_cluster_size_cfg, num_clusters, min_clusters, max_clusters, 0,
+                               hard, train_labels_out, ntrain_out, NULL, 0);
+}
+
+/* scipy.optimize.linear_sum_assignment (minimisation, nr <= nc), the dependency clustering/Clustering.py:90 calls
+ * (third-party, version not pinned by the reference).  Restated from scipy's rectangular_lsap.cpp (scipy >= 1.6: Crouse's
+ * shortest augmenting path; `remaining` filled in reverse; ties go to an unassigned column); pinned against the scipy
+ * installed in this image by tests/test_oracle.py. */
+static void orc_lsap(int nr, int nc, const double *cost, int *col4row)
+{
+    double *u = (double *)calloc((size_t)nr, sizeof(double)), *v = (double *)calloc((size_t)nc, sizeof(double));
+    double *spc = (double *)malloc(sizeof(double) * (size_t)nc);
+    int *path = (int *)malloc(sizeof(int) * (size_t)nc), *row4col = (int *)malloc(sizeof(int) * (size_t)nc);
+    int *remaining = (int *)malloc(sizeof(int) * (size_t)nc);
+    char *SR = (char *)malloc((size_t)nr), *SC = (char *)malloc((size_t)nc);
+    for (int j = 0; j < nc; ++j) { path[j] = -1; row4col[j] = -1; }
+    for (int i = 0; i < nr; ++i) col4row[i] = -1;
+    for (int cur = 0; cur < nr; ++cur) {
+        double minVal = 0.0;
+        int num_remaining = nc;
+        for (int it = 0; it < nc; ++it) remaining[it] = nc - it - 1;
+        memset(SR, 0, (size_t)nr); memset(SC, 0, (size_t)nc);
+        for (int j = 0; j < nc; ++j) spc[j] = INFINITY;
+        int sink = -1, i = cur;
+        while (sink == -1) {
+            int index = -1; double lowest = INFINITY;
+            SR[i] = 1;
+            for (int it = 0; it < num_remaining; ++it) {
+                int j = remaining[it];
+                double r = minVal + cost[i * nc + j] - u[i] - v[j];
+                if (r < spc[j]) { path[j] = i; spc[j] = r; }
+                if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+            }
+            minVal = lowest;
+            if (index < 0) goto out;
+            int j = remaining[index];
+            if (row4col[j] == -1) sink = j; else i = row4col[j];
+            SC[j] = 1;
+            remaining[index] = remaining[--num_remaining];
+        }
+        u[cur] += minVal;
+        for (int r = 0; r < nr; ++r) if (SR[r] && r != cur) u[r] += minVal - spc[col4row[r]];
+        for (int j = 0; j < nc; ++j) if (SC[j]) v[j] -= minVal - spc[j];
+        int j = sink;
+        while (1) {
+            int r = path[j];
+            row4col[j] = r;
+            int t = col4row[r]; col4row[r] = j; j = t;
+            if (r == cur) break;
+        }
+    }
+out:
+    free(u); free(v); free(spc); free(path); free(row4col); free(remaining); free(SR); free(SC);
+}
+/* exported for the pin test: maximise or minimise an nr x nc cost matrix like scipy (transposing when nr > nc);
+ * row_ind/col_ind get min(nr, nc) pairs sorted by row */
+int orc_linear_sum_assignment(const double *cost, int nr, int nc, int maximize, int *row_ind, int *col_ind)
+{
+    int tr = nc < nr, R = tr ? nc : nr, Cc = tr ? nr : nc;
+    double *t = (double *)malloc(sizeof(double) * (size_t)nr * nc);
+    for (int i = 0; i < nr; ++i) for (int j = 0; j < nc; ++j) {
+        double x = maximize ? -cost[i * nc + j] : cost[i * nc + j];
+        if (tr) t[j * nr + i] = x; else t[i * nc + j] = x;
+    }
+    int *c4r = (int *)malloc(sizeof(int) * (size_t)R);
+    orc_lsap(R, Cc, t, c4r);
+    int n = 0;
+    if (!tr) { for (int i = 0; i < R; ++i) { row_ind[n] = i; col_ind[n] = c4r[i]; n++; } }
+    else {                                               /* rows of the transposed problem are columns: report sorted by row */
+        for (int i = 0; i < nr; ++i) for (int k = 0; k < R; ++k) if (c4r[k] == i) { row_ind[n] = i; col_ind[n] = k; n++; }
+    }
+    free(t); free(c4r);
+    return n;
+}
+
+/* constrained_argmax, clustering/Clustering.py:81-94: soft [c][S][K] (NaN allowed) -> hard [c][S] (-2 = unassigned) */
+void orc_constrained_argmax(const double *soft, long c, int S, int K, int *hard)
+{
+    double fill = INFINITY;                                        /* np.nanmin over the whole tensor, :83 */
+    for (long i = 0; i < c * S * K; ++i) if (!isnan(soft[i]) && soft[i] < fill) fill = soft[i];
+    if (fill == INFINITY) fill = 0.0;
+    double *cost = (double *)malloc(sizeof(double) * (size_t)S * K);
+    int *ri = (int *)malloc(sizeof(int) * (size_t)(S > K ? S : K)), *ci = (int *)malloc(sizeof(int) * (size_t)(S > K ? S : K));
+    for (long i = 0; i < c; ++i) {
+        for (int q = 0; q < S * K; ++q) { double x = soft[i * S * K + q]; cost[q] = isnan(x) ? fill : x; }
+        for (int s = 0; s < S; ++s) hard[i * S + s] = -2;          /* :88 */
+        int n = orc_linear_sum_assignment(cost, S, K, 1, ri, ci);  /* :90-92 */
+        for (int q = 0; q < n; ++q) hard[i * S + ri[q]] = ci[q];
+    }
+    free(cost); free(ri); free(ci);
+}
+
+int orc_clustering_full(const double *emb, long c, int S, int d, float threshold, long min_cluster_size_cfg,
+                        int num_clusters, int min_clusters, int max_clusters, int constrained, int *hard, int *train_labels_out,
+                        long *ntrain_out, double *soft_out, long soft_cap)
 {
     long M = c * S, N = 0;
     long *tidx = (long *)malloc(sizeof(long) * (size_t)M);
@@ -643,14 +742,19 @@ int orc_clustering_ex(const double *emb, long c, int S, int d, float threshold, 
         for (int q = 0; q < d; ++q) cen[k * d + q] /= (double)mc;           /* sd.cpp:2165 */
     }
     int err = 0;
+    double *softm = (double *)malloc(sizeof(double) * (size_t)M * nk);
     for (long i = 0; i < M; ++i) {
         int best = 0; double mv = -DBL_MAX;                                 /* sd.cpp:293-316 */
         for (int k = 0; k < nk; ++k) {
-            double soft = 2.0 - cos_dist(&emb[i * d], &cen[k * d], d, &err);
+            double soft = 2.0 - cos_dist(&emb[i * d], &cen[k * d], d, &err);   /* sd.cpp:2191-2207 */
+            softm[i * nk + k] = soft;
             if (soft > mv) { mv = soft; best = k; }
         }
         hard[i] = best;
     }
+    if (constrained) orc_constrained_argmax(softm, c, S, nk, hard);         /* Clustering.py:156-157 */
+    if (soft_out && (long)M * nk <= soft_cap) memcpy(soft_out, softm, sizeof(double) * (size_t)M * nk);
+    free(softm);
     free(tidx); free(X); free(lab); free(cen);
     return err ? -1 : nk;
 }

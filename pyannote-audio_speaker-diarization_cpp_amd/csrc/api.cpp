@@ -45,6 +45,7 @@ extern "C" void sd_destroy(sd_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     sd_flush_profile(c);
+    (void)sd_comm_destroy(c);
     for (void* p : c->owned) (void)hipFree(p);
     for (auto& kv : c->ws) kv.second.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -87,6 +88,9 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "linkage_threads") c->linkage_threads = v;
     else if (k == "skip_dead_rows") c->skip_dead_rows = v != 0;
     else if (k == "ecapa_precision") { if (v != 0 && v != 1) SD_FAIL(c, SD_ERR_ARG, "ecapa_precision must be 0 (f32) or 1 (f16)"); c->ecapa_precision = (int)v; }
+    else if (k == "rank0_permille") c->rank0_permille = (int)v;
+    else if (k == "virtual_world") c->virtual_world = (int)v;
+    else if (k == "constrained_assignment") c->constrained_assignment = v != 0;
     else if (k == "num_clusters") c->num_clusters = (int)v;
     else if (k == "min_clusters") c->min_clusters = (int)v;
     else if (k == "max_clusters") c->max_clusters = (int)v;
@@ -281,16 +285,45 @@ extern "C" int sd_read_wav_f32(const char* path, float** wav, int64_t* n, int32_
 }
 extern "C" void sd_free_wav(float* p) { free(p); }
 
-// ------------------------------------------------------------------ RTTM output
-// one "SPEAKER <uri> 1 <start> <duration> <NA> <NA> SPEAKER_<kk> <NA> <NA>" line per turn (pyannote's RTTM writer layout)
-extern "C" int sd_write_rttm(const char* path, const char* uri, const sd_turn* turns, int64_t n_turns)
+// ------------------------------------------------------------------ output formats
+// Relabelling.  The reference prints the raw cluster index (sd.cpp:3439).  pyannote.audio renames the clusters on the way
+// out: SpeakerDiarization.apply maps `diarization.labels()` -- the labels that occur, sorted BY THEIR STRING -- onto
+// SPEAKER_00, SPEAKER_01, ... (mode 1); mode 0 numbers the speakers in order of first appearance.
+extern "C" int sd_relabel_turns_ex(sd_turn* turns, int64_t n, int mode)
 {
-    if (!path || !turns || n_turns < 0) return SD_ERR_ARG;
+    if (n < 0 || (n > 0 && !turns) || (mode != 0 && mode != 1)) return SD_ERR_ARG;
+    std::vector<int> seen;
+    for (int64_t i = 0; i < n; ++i) if (std::find(seen.begin(), seen.end(), turns[i].label) == seen.end()) seen.push_back(turns[i].label);
+    if (mode == 1) std::sort(seen.begin(), seen.end(), [](int a, int b) { return std::to_string(a) < std::to_string(b); });
+    for (int64_t i = 0; i < n; ++i) turns[i].label = (int32_t)(std::find(seen.begin(), seen.end(), turns[i].label) - seen.begin());
+    return SD_OK;
+}
+extern "C" int sd_relabel_turns(sd_turn* turns, int64_t n) { return sd_relabel_turns_ex(turns, n, 1); }
+
+extern "C" int sd_last_confidence(const sd_ctx* c, double* conf, int64_t cap, int64_t* n)
+{
+    if (!c) return SD_ERR_ARG;
+    if (n) *n = (int64_t)c->last_conf.size();
+    if (conf) for (int64_t i = 0; i < cap && i < (int64_t)c->last_conf.size(); ++i) conf[i] = c->last_conf[(size_t)i];
+    return SD_OK;
+}
+
+// one "SPEAKER <uri> 1 <start> <duration> <NA> <NA> SPEAKER_<kk> <NA> <conf>" line per turn (pyannote's RTTM writer layout;
+// the last field is RTTM's confidence column, <NA> without conf)
+extern "C" int sd_write_rttm_ex(const char* path, const char* uri, const sd_turn* turns, int64_t n_turns, const double* conf)
+{
+    if (!path || (n_turns > 0 && !turns) || n_turns < 0) return SD_ERR_ARG;
     FILE* f = fopen(path, "w");
     if (!f) return SD_ERR_ARG;
-    for (int64_t i = 0; i < n_turns; ++i)
-        fprintf(f, "SPEAKER %s 1 %.3f %.3f <NA> <NA> SPEAKER_%02d <NA> <NA>\n", (uri && uri[0]) ? uri : "audio",
+    for (int64_t i = 0; i < n_turns; ++i) {
+        fprintf(f, "SPEAKER %s 1 %.3f %.3f <NA> <NA> SPEAKER_%02d <NA> ", (uri && uri[0]) ? uri : "audio",
                 turns[i].start, turns[i].end - turns[i].start, turns[i].label);
+        if (conf && conf[i] == conf[i]) fprintf(f, "%.4f\n", conf[i]); else fprintf(f, "<NA>\n");
+    }
     fclose(f);
     return SD_OK;
+}
+extern "C" int sd_write_rttm(const char* path, const char* uri, const sd_turn* turns, int64_t n_turns)
+{
+    return sd_write_rttm_ex(path, uri, turns, n_turns, nullptr);
 }

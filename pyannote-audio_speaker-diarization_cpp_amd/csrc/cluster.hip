@@ -1047,7 +1047,8 @@ __global__ void k_cluster_means(const double* __restrict__ X, int d, const int* 
 
 // cosine distance with the reference's sequential sums (sd.cpp:476-498); soft = 2 - d; argmax first-max-wins
 __global__ __launch_bounds__(64) void k_assign(const double* __restrict__ E, int64_t M, int d, const double* __restrict__ cen, int K,
-                                               int* __restrict__ hard, int* __restrict__ err)
+                                               int* __restrict__ hard, int* __restrict__ err, double* __restrict__ soft_out /*[M][K] or null*/,
+                                               double* __restrict__ best_out /*[M] or null*/)
 {
     extern __shared__ double soft[];
     const int64_t row = blockIdx.x;
@@ -1058,13 +1059,90 @@ __global__ __launch_bounds__(64) void k_assign(const double* __restrict__ E, int
         for (int i = 0; i < d; ++i) { dot += e[i] * cc[i]; m1 += e[i] * e[i]; m2 += cc[i] * cc[i]; }
         if (m1 == 0.0 || m2 == 0.0) { *err = 1; soft[k] = NAN; }
         else soft[k] = 2.0 - (1.0 - (dot / (sqrt(m1) * sqrt(m2))));
+        if (soft_out) soft_out[(size_t)row * K + k] = soft[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         int best = 0; double mv = -DBL_MAX;
         for (int k = 0; k < K; ++k) if (soft[k] > mv) { mv = soft[k]; best = k; }
         hard[row] = best;
+        if (best_out) best_out[row] = soft[best];                  // NaN for rows without an embedding
     }
+}
+
+// ---------------------------------------------------------------- constrained_argmax (clustering/Clustering.py:81-94)
+// hard[c] = linear_sum_assignment(soft[c] (3 x K), maximize=True): every local speaker of a chunk goes to a DIFFERENT cluster.
+// The Python delegates to scipy.optimize.linear_sum_assignment (third-party, unpinned by the reference); its published
+// algorithm -- Crouse's shortest-augmenting-path rectangular LSAP as implemented in scipy's rectangular_lsap.cpp (1.6 and
+// later): rows in order, `remaining` columns filled in reverse, ties towards an unassigned column, transpose when there are
+// fewer clusters than speakers -- is restated here step by step, because rows without an embedding become CONSTANT rows
+// (nan_to_num with the global minimum) and which optimal assignment comes out of the many equal ones is decided by exactly
+// those details.  nr <= nc <= LSAP_MAXC after the optional transpose.
+#define LSAP_MAXC 64
+__host__ __device__ inline void lsap_solve(int nr, int nc, const double* cost /*[nr][nc], minimised*/, int* col4row)
+{
+    double u[SD_SPEAKERS] = {0, 0, 0}, v[LSAP_MAXC], spc[LSAP_MAXC];
+    int path[LSAP_MAXC], row4col[LSAP_MAXC], remaining[LSAP_MAXC];
+    bool SR[SD_SPEAKERS], SC[LSAP_MAXC];
+    for (int j = 0; j < nc; ++j) { v[j] = 0.0; path[j] = -1; row4col[j] = -1; }
+    for (int i = 0; i < nr; ++i) col4row[i] = -1;
+    for (int cur = 0; cur < nr; ++cur) {
+        double minVal = 0.0;
+        int num_remaining = nc;
+        for (int it = 0; it < nc; ++it) remaining[it] = nc - it - 1;
+        for (int i = 0; i < nr; ++i) SR[i] = false;
+        for (int j = 0; j < nc; ++j) { SC[j] = false; spc[j] = INFINITY; }
+        int sink = -1, i = cur;
+        while (sink == -1) {
+            int index = -1; double lowest = INFINITY;
+            SR[i] = true;
+            for (int it = 0; it < num_remaining; ++it) {
+                const int j = remaining[it];
+                const double r = minVal + cost[i * nc + j] - u[i] - v[j];
+                if (r < spc[j]) { path[j] = i; spc[j] = r; }
+                if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+            }
+            minVal = lowest;
+            if (index < 0) return;                              // infeasible (cannot happen with finite costs)
+            const int j = remaining[index];
+            if (row4col[j] == -1) sink = j; else i = row4col[j];
+            SC[j] = true;
+            remaining[index] = remaining[--num_remaining];
+        }
+        u[cur] += minVal;
+        for (int r = 0; r < nr; ++r) if (SR[r] && r != cur) u[r] += minVal - spc[col4row[r]];
+        for (int j = 0; j < nc; ++j) if (SC[j]) v[j] -= minVal - spc[j];
+        int j = sink;
+        while (true) {
+            const int r = path[j];
+            row4col[j] = r;
+            const int t = col4row[r]; col4row[r] = j; j = t;
+            if (r == cur) break;
+        }
+    }
+}
+__host__ __device__ inline void constrained_argmax_chunk(const double* soft /*[3][K]*/, int K, double fill, int* hard3)
+{
+    double cost[SD_SPEAKERS * LSAP_MAXC];
+    int c4r[SD_SPEAKERS];
+    hard3[0] = hard3[1] = hard3[2] = -2;
+    if (K >= SD_SPEAKERS) {
+        for (int s = 0; s < SD_SPEAKERS; ++s) for (int k = 0; k < K; ++k) { const double x = soft[s * K + k]; cost[s * K + k] = -((x != x) ? fill : x); }
+        lsap_solve(SD_SPEAKERS, K, cost, c4r);
+        for (int s = 0; s < SD_SPEAKERS; ++s) hard3[s] = c4r[s] >= 0 ? c4r[s] : -2;
+    } else {                                                    // fewer clusters than speakers: scipy transposes
+        for (int k = 0; k < K; ++k) for (int s = 0; s < SD_SPEAKERS; ++s) { const double x = soft[s * K + k]; cost[k * SD_SPEAKERS + s] = -((x != x) ? fill : x); }
+        lsap_solve(K, SD_SPEAKERS, cost, c4r);
+        for (int k = 0; k < K; ++k) if (c4r[k] >= 0) hard3[c4r[k]] = k;
+    }
+}
+__global__ void k_constrained_argmax(const double* __restrict__ soft, int64_t chunks, int K, double fill, int* __restrict__ hard)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= chunks) return;
+    int h[3];
+    constrained_argmax_chunk(soft + (size_t)c * SD_SPEAKERS * K, K, fill, h);
+    hard[c * 3] = h[0]; hard[c * 3 + 1] = h[1]; hard[c * 3 + 2] = h[2];
 }
 
 static double cos_dist_host(const double* a, const double* b, int d, bool* err)      // sd.cpp:476-498
@@ -1121,9 +1199,10 @@ static void constrained_recut(const std::vector<double>& Z, int64_t N, double th
 
 // d_emb: [M][d] f64 (NaN rows = no embedding), M = chunks*3.  hard: [M]
 int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector<int>& hard, int* Kout,
-                   int num_clusters, int min_clusters, int max_clusters)
+                   int num_clusters, int min_clusters, int max_clusters, std::vector<double>* soft_best)
 {
     hard.assign((size_t)M, 0);
+    if (soft_best) soft_best->assign((size_t)M, NAN);
     if (Kout) *Kout = 1;
     if (M <= 0) return SD_OK;
     // a10: rows whose first element is not NaN (sd.cpp:2224)
@@ -1229,13 +1308,38 @@ int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector
     HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(k_cluster_means, dim3(nl), dim3(((d + 63) / 64) * 64), 0, c->stream, X, d, d_order2, d_off2, d_cen2);
     KCHECK(c);
-    hipLaunchKernelGGL(k_assign, dim3((unsigned)M), dim3(64), (size_t)nl * sizeof(double), c->stream, d_emb, M, d, d_cen2, nl, d_hard, d_err);
+    const bool constrained_assign = c->constrained_assignment && (M % SD_SPEAKERS) == 0;
+    double* d_soft = nullptr; double* d_best = nullptr;
+    if (constrained_assign || soft_best) {
+        WS(c, double, t_soft, "cl_soft", (size_t)M * nl);
+        WS(c, double, t_best, "cl_best", M);
+        d_soft = t_soft; d_best = t_best;
+    }
+    hipLaunchKernelGGL(k_assign, dim3((unsigned)M), dim3(64), (size_t)nl * sizeof(double), c->stream, d_emb, M, d, d_cen2, nl, d_hard, d_err, d_soft, d_best);
     KCHECK(c);
     int herr = 0;
     HIPCHK(c, hipMemcpyAsync(hard.data(), d_hard, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (soft_best) HIPCHK(c, hipMemcpyAsync(soft_best->data(), d_best, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (herr) SD_FAIL(c, SD_ERR_NUMERIC, "zero-magnitude embedding or centroid in assignment (reference throws, sd.cpp:493-495)");
+    if (constrained_assign) {
+        // Clustering.py:83: NaN (rows without an embedding) -> the smallest soft score of the whole recording
+        std::vector<double> hs((size_t)M * nl);
+        HIPCHK(c, hipMemcpy(hs.data(), d_soft, hs.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double fill = INFINITY;
+        for (double x : hs) if (x == x && x < fill) fill = x;
+        if (fill == INFINITY) fill = 0.0;
+        const int64_t chunks = M / SD_SPEAKERS;
+        if (nl <= LSAP_MAXC) {
+            hipLaunchKernelGGL(k_constrained_argmax, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, c->stream, d_soft, chunks, nl, fill, d_hard);
+            KCHECK(c);
+            HIPCHK(c, hipMemcpyAsync(hard.data(), d_hard, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        } else SD_FAIL(c, SD_ERR_ARG, "constrained assignment supports up to %d clusters (found %d)", LSAP_MAXC, nl);
+        if (soft_best)                                             // confidence follows the cluster actually assigned
+            for (int64_t i = 0; i < M; ++i) (*soft_best)[(size_t)i] = hard[(size_t)i] >= 0 ? hs[(size_t)i * nl + hard[(size_t)i]] : NAN;
+    }
     if (Kout) *Kout = nl;
     return SD_OK;
 }

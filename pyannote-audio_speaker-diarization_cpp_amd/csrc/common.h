@@ -107,6 +107,12 @@ struct sd_ctx {
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
     int64_t linkage_threads = 0;               // 0 auto (256, or 1024 for N >= 60000), else 256 / 512 / 1024 threads per cooperative workgroup
     int num_cu = 256;
+    bool constrained_assignment = false;        // Clustering.py:81-94 (one cluster per local speaker of a chunk)
+    std::vector<double> last_conf;               // per-turn confidence of the last finalize (sd_last_confidence)
+    void* comm = nullptr;                       // ncclComm_t (comm.cpp), null = single GPU
+    int rank = 0, world = 1;
+    int virtual_world = 0;                      // test mode of sd_diarize_sharded on one rank (comm.cpp)
+    int rank0_permille = -1;                    // share of the chunks rank 0 infers itself (it also finalizes); -1 = equal shares
     const float* planted_scores = nullptr;      // sd_set_planted: measurement / test hook
     const float* planted_emb = nullptr;
     int64_t planted_lo = 0, planted_n = 0;
@@ -166,7 +172,7 @@ int64_t closest_frame_host(double w_start, double w_step, double w_dur, double t
 int run_linkage(sd_ctx* c, const double* d_Xn, int64_t N, int d, double* d_Z);
 int run_cluster_labels(sd_ctx* c, const double* d_Xn, int64_t N, int d, double cutoff, std::vector<int>& labels1, std::vector<double>* Zout = nullptr);
 int run_clustering(sd_ctx* c, const double* d_emb /*[M][d] f64*/, int64_t M, int d, std::vector<int>& hard, int* K,
-                   int num_clusters = -1, int min_clusters = -1, int max_clusters = -1);
+                   int num_clusters = -1, int min_clusters = -1, int max_clusters = -1, std::vector<double>* soft_best = nullptr);
 void fcluster_host(const std::vector<double>& Z, int64_t n, double cutoff, std::vector<int>& T);
 // ---- reconstruct.hip
 int run_reconstruct(sd_ctx* c, const float* d_seg, const int* d_nact, const int* d_hard, const int32_t* d_count,

@@ -271,6 +271,7 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
     WS(c, float, emb_c, "emb_compact", items * SD_EMB_DIM);
     int n_active = 0;
     if ((rc = run_frontend(c, d_wav, n, d_masks, items, first_item, feats, lens, nnorm, nvalid, flags, true, &n_active, cidx))) return rc;
+    { KernelStat& ks = c->stats["items_live"]; ks.launches++; ks.flops += (double)n_active; ks.bytes += (double)items; }   // bench: live / all items
     std::vector<int> h_nvalid((size_t)(n_active > 0 ? n_active : 1));
     if (n_active > 0) {
         HIPCHK(c, hipMemcpyAsync(h_nvalid.data(), nvalid, (size_t)n_active * sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -1,36 +1,31 @@
 // main.cpp -- the `speakerDiarizer` command line, same surface as the reference's main()
-// (sd.cpp:3415-3442):   speakerDiarizer <segment model> <embedding model> <16 kHz mono 16-bit wav>
+// (sd.cpp:3415-3442):   speakerDiarizer <segment model> <embedding model> <16 kHz mono wav>
 // prints the per-stage timings and, between two 52-dash rules, one line per turn:
 //   [start -- end] --> Speaker_N
-// Model files are .sdw weight packs (tools/make_weights.py); the whole path runs on GPU 0
-// through the C ABI of libsdhip.so.
+// Model files are the reference's ONNX files or .sdw weight packs (tools/make_weights.py); the
+// whole path runs on the GPU through the C ABI of libsdhip.so.
+//
+// Extras after the three positional arguments (the reference has none):
+//   --gpus N        shard the recording over N GPUs of this node: the launcher fork()s one
+//                   process per GPU BEFORE anything touches HIP, rank 0 mints the RCCL rendezvous id and
+//                   passes it to the others through pipes created before the fork; turns are printed by rank 0
+//   --rttm FILE     also write the turns as RTTM
+//   --relabel       stdout / RTTM labels renumbered the way pyannote.audio names its output (the clusters that occur,
+//                   sorted by their string, become 0, 1, ... = SPEAKER_00, SPEAKER_01, ...); default = raw cluster ids (sd.cpp:3439)
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
+#include <vector>
+#include <csignal>
+#include <sys/wait.h>
+#include <unistd.h>
 #include "sdhip.h"
 
-int main(int argc, char* argv[])
+struct Args { const char* seg = nullptr; const char* emb = nullptr; const char* wav = nullptr; const char* rttm = nullptr; int gpus = 1; bool relabel = false; };
+
+static void print_block(sd_ctx* ctx, sd_turn* turns, int64_t nt, const Args& a)
 {
-    if (argc < 4) {
-        printf("program [segment model file] [embeding model file] [wave file]\n");   // sd.cpp:3423
-        return 0;
-    }
-    float* wav = nullptr; int64_t n = 0; int32_t sr = 0, ch = 0, bits = 0;
-    if (sd_read_wav_f32(argv[3], &wav, &n, &sr, &ch, &bits) != SD_OK) {       // 8 / 16 / 32-bit PCM like wav.h:99-122
-        fprintf(stderr, "cannot read PCM wav: %s\n", argv[3]);
-        return 1;
-    }
-    sd_ctx* ctx = sd_create(argv[1], argv[2], 0);
-    if (!ctx) {
-        fprintf(stderr, "sd_create failed: %s\n", sd_create_error());
-        return 1;
-    }
-    sd_turn* turns = nullptr; int64_t nt = 0;
-    int rc = sd_diarize_f32(ctx, wav, n, &turns, &nt);
-    if (rc != SD_OK) {
-        fprintf(stderr, "diarization failed (%d): %s\n", rc, sd_last_error(ctx));
-        return 1;
-    }
     double ms[4];
     sd_stage_ms(ctx, ms);
     printf("-----------\nSegmenations time: %lldms\n", (long long)ms[0]);      // labels of sd.cpp:3028, 3110, 3231
@@ -38,12 +33,122 @@ int main(int argc, char* argv[])
     printf("-----------\nClustering time: %lldms\n", (long long)ms[2]);
     printf("\n----Summary----\n-----------\nTime cost: %lldms\n", (long long)ms[3]);
     printf("----------------------------------------------------\n");
+    if (a.relabel) sd_relabel_turns(turns, nt);
     char line[160];
     for (int64_t i = 0; i < nt; ++i) { sd_format_turn(&turns[i], line, sizeof(line)); printf("%s\n", line); }
     printf("----------------------------------------------------\n");
-    if (argc >= 6 && std::string(argv[4]) == "--rttm") sd_write_rttm(argv[5], argv[3], turns, nt);   // optional extra: RTTM file
+    if (a.rttm) sd_write_rttm(a.rttm, a.wav, turns, nt);
+    fflush(stdout);
+}
+
+static int run_single(const Args& a)
+{
+    float* wav = nullptr; int64_t n = 0; int32_t sr = 0, ch = 0, bits = 0;
+    if (sd_read_wav_f32(a.wav, &wav, &n, &sr, &ch, &bits) != SD_OK) {         // 8 / 16 / 32-bit PCM like wav.h:99-122
+        fprintf(stderr, "cannot read PCM wav: %s\n", a.wav);
+        return 1;
+    }
+    sd_ctx* ctx = sd_create(a.seg, a.emb, 0);
+    if (!ctx) { fprintf(stderr, "sd_create failed: %s\n", sd_create_error()); return 1; }
+    sd_turn* turns = nullptr; int64_t nt = 0;
+    const int rc = sd_diarize_f32(ctx, wav, n, &turns, &nt);
+    if (rc != SD_OK) { fprintf(stderr, "diarization failed (%d): %s\n", rc, sd_last_error(ctx)); return 1; }
+    print_block(ctx, turns, nt, a);
     sd_free_turns(turns);
     sd_free_wav(wav);
     sd_destroy(ctx);
     return 0;
+}
+
+static bool read_all(int fd, void* buf, size_t n)
+{
+    size_t got = 0;
+    while (got < n) { const ssize_t r = read(fd, (char*)buf + got, n - got); if (r <= 0) return false; got += (size_t)r; }
+    return true;
+}
+
+// one rank of the sharded job; id_rd = pipe this rank reads the rendezvous id from (ranks > 0), id_wr = the pipes rank 0 writes
+static int run_rank(const Args& a, int rank, int world, int id_rd, const std::vector<int>& id_wr)
+{
+    int16_t* pcm = nullptr; int64_t n = 0; int32_t sr = 0, ch = 0;
+    if (sd_read_wav(a.wav, &pcm, &n, &sr, &ch) != SD_OK) {
+        fprintf(stderr, "rank %d: cannot read 16-bit PCM wav: %s (--gpus needs 16-bit samples)\n", rank, a.wav);
+        return 1;
+    }
+    sd_ctx* ctx = sd_create(a.seg, a.emb, rank);
+    if (!ctx) { fprintf(stderr, "rank %d: sd_create failed: %s\n", rank, sd_create_error()); return 1; }
+    unsigned char id[SD_COMM_ID_BYTES];
+    if (rank == 0) {
+        if (sd_comm_unique_id(id) != SD_OK) { fprintf(stderr, "rank 0: sd_comm_unique_id failed\n"); return 1; }
+        for (int fd : id_wr) if (write(fd, id, sizeof(id)) != (ssize_t)sizeof(id)) { fprintf(stderr, "rank 0: cannot hand the rendezvous id over\n"); return 1; }
+    } else if (!read_all(id_rd, id, sizeof(id))) { fprintf(stderr, "rank %d: no rendezvous id from rank 0\n", rank); return 1; }
+    if (sd_comm_init(ctx, id, rank, world) != SD_OK) { fprintf(stderr, "rank %d: sd_comm_init failed: %s\n", rank, sd_last_error(ctx)); return 1; }
+    std::vector<int64_t> ranges((size_t)world * 2);
+    sd_shard_plan(n, world, -1, ranges.data(), nullptr);
+    const int64_t lo = ranges[2 * (size_t)rank], hi = ranges[2 * (size_t)rank + 1];
+    int64_t s0 = lo * SD_HOP, s1 = hi > lo ? (hi - 1) * SD_HOP + SD_CHUNK : s0;
+    if (s1 > n) s1 = n;
+    if (s0 > n) s0 = n;
+    sd_turn* turns = nullptr; int64_t nt = 0;
+    const int rc = sd_diarize_sharded(ctx, pcm + s0, s0, s1 - s0, n, &turns, &nt);
+    if (rc != SD_OK) { fprintf(stderr, "rank %d: diarization failed (%d): %s\n", rank, rc, sd_last_error(ctx)); return 1; }
+    if (rank == 0) print_block(ctx, turns, nt, a);
+    sd_free_turns(turns);
+    sd_free_pcm(pcm);
+    sd_destroy(ctx);                       // (drains the stream: the all-gather of the non-zero ranks completes here)
+    return 0;
+}
+
+int main(int argc, char* argv[])
+{
+    Args a;
+    std::vector<const char*> pos;
+    for (int i = 1; i < argc; ++i) {
+        const std::string s(argv[i]);
+        if (s == "--gpus" && i + 1 < argc) a.gpus = atoi(argv[++i]);
+        else if (s == "--rttm" && i + 1 < argc) a.rttm = argv[++i];
+        else if (s == "--relabel") a.relabel = true;
+        else pos.push_back(argv[i]);
+    }
+    if (pos.size() < 3) {
+        printf("program [segment model file] [embeding model file] [wave file]\n");   // sd.cpp:3423
+        return 0;
+    }
+    a.seg = pos[0]; a.emb = pos[1]; a.wav = pos[2];
+    if (a.gpus <= 1) return run_single(a);
+
+    // ---- launcher: nothing below touches HIP in this process.  pipes[r] carries the rendezvous id from rank 0 to rank r.
+    const int world = a.gpus;
+    std::vector<int> rd((size_t)world, -1), wr((size_t)world, -1);
+    for (int r = 1; r < world; ++r) {
+        int fd[2];
+        if (pipe(fd) != 0) { perror("pipe"); return 1; }
+        rd[(size_t)r] = fd[0]; wr[(size_t)r] = fd[1];
+    }
+    fflush(stdout); fflush(stderr);
+    std::vector<pid_t> kids;
+    for (int r = 0; r < world; ++r) {
+        const pid_t pid = fork();
+        if (pid < 0) { perror("fork"); return 1; }
+        if (pid == 0) {
+            signal(SIGPIPE, SIG_IGN);           // a write to a dead rank's pipe is an error return, not a kill
+            // keep only this rank's ends: a rank that dies closes its pipes, so nobody blocks on a read forever
+            std::vector<int> mine;
+            for (int q = 1; q < world; ++q) {
+                if (r == 0) { close(rd[(size_t)q]); mine.push_back(wr[(size_t)q]); }
+                else { close(wr[(size_t)q]); if (q != r) close(rd[(size_t)q]); }
+            }
+            const int rc = run_rank(a, r, world, r > 0 ? rd[(size_t)r] : -1, mine);
+            fflush(stdout); fflush(stderr);
+            _exit(rc);
+        }
+        kids.push_back(pid);
+    }
+    for (int r = 1; r < world; ++r) { close(rd[(size_t)r]); close(wr[(size_t)r]); }
+    int worst = 0;
+    for (pid_t pid : kids) {
+        int st = 0;
+        if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) worst = 1;
+    }
+    return worst;
 }

@@ -11,6 +11,7 @@
 // Anything else (unexpected op counts, non-constant weights, external data) is reported as
 // SD_ERR_MODEL with the reason; nothing is guessed.
 #include "common.h"
+#include <algorithm>
 #include <cmath>
 
 namespace {
@@ -110,6 +111,147 @@ bool parse_graph(PB pb, OGraph& g)
     return pb.ok;
 }
 
+// ---- constant evaluation of the weight-shuffling ops an exporter leaves behind when it does not fold them
+// (torch.onnx.export with do_constant_folding=False builds the LSTM W / R / B by Slice + Concat + Unsqueeze of the PyTorch
+// parameters and the Linear weights by Transpose): a node whose inputs are all constants becomes a constant itself.
+// Only data movement is evaluated -- no arithmetic -- so the extracted weights stay the exporter's bits.
+int64_t numel(const OTensor& t) { int64_t n = 1; for (auto d : t.dims) n *= d; return n; }
+bool is_int(const OTensor& t) { return !t.i64.empty() || t.dtype == 7 || t.dtype == 6; }
+// copy a strided N-d view: out[idx] = in[sum (start_a + idx_a * step_a) * stride_a]
+void gather_nd(const OTensor& in, const std::vector<int64_t>& odims, const std::vector<int64_t>& start, const std::vector<int64_t>& step,
+               const std::vector<int64_t>& istride, OTensor& out)
+{
+    out.dims = odims; out.dtype = in.dtype;
+    const int64_t n = numel(out);
+    const bool ii = is_int(in);
+    if (ii) out.i64.resize((size_t)n); else out.f.resize((size_t)n);
+    std::vector<int64_t> idx(odims.size(), 0);
+    for (int64_t k = 0; k < n; ++k) {
+        int64_t src = 0;
+        for (size_t a = 0; a < odims.size(); ++a) src += (start[a] + idx[a] * step[a]) * istride[a];
+        if (ii) out.i64[(size_t)k] = in.i64[(size_t)src]; else out.f[(size_t)k] = in.f[(size_t)src];
+        for (int a = (int)odims.size() - 1; a >= 0; --a) { if (++idx[(size_t)a] < odims[(size_t)a]) break; idx[(size_t)a] = 0; }
+    }
+}
+std::vector<int64_t> strides_of(const std::vector<int64_t>& dims)
+{
+    std::vector<int64_t> s(dims.size(), 1);
+    for (int a = (int)dims.size() - 2; a >= 0; --a) s[(size_t)a] = s[(size_t)a + 1] * dims[(size_t)a + 1];
+    return s;
+}
+void fold_constants(OGraph& g)
+{
+    for (const ONode& n : g.nodes) {
+        if (n.out.empty() || g.init.count(n.out[0])) continue;
+        const bool known = n.op == "Slice" || n.op == "Concat" || n.op == "Unsqueeze" || n.op == "Squeeze" || n.op == "Transpose" || n.op == "Identity" ||
+                           n.op == "Reshape";
+        if (!known) continue;
+        std::vector<const OTensor*> in;
+        bool all = !n.in.empty();
+        for (auto& nm : n.in) {
+            if (nm.empty()) { in.push_back(nullptr); continue; }
+            auto it = g.init.find(nm);
+            if (it == g.init.end() || it->second.external) { all = false; break; }
+            in.push_back(&it->second);
+        }
+        if (!all || !in[0]) continue;
+        const OTensor& x = *in[0];
+        if ((int64_t)(is_int(x) ? x.i64.size() : x.f.size()) != numel(x)) continue;
+        OTensor y; y.name = n.out[0]; y.dtype = x.dtype;
+        const int R = (int)x.dims.size();
+        auto ints_of = [&](size_t k, const char* attr) -> std::vector<int64_t> {
+            if (k < in.size() && in[k]) return in[k]->i64;
+            const OAttr* a = n.attr(attr);
+            return a ? a->ints : std::vector<int64_t>();
+        };
+        if (n.op == "Identity") { y = x; y.name = n.out[0]; }
+        else if (n.op == "Unsqueeze" || n.op == "Squeeze") {
+            std::vector<int64_t> axes = ints_of(1, "axes");
+            y = x; y.name = n.out[0];
+            if (n.op == "Unsqueeze") {
+                const int Ro = R + (int)axes.size();
+                std::vector<int64_t> od((size_t)Ro, -1);
+                for (auto a : axes) { if (a < 0) a += Ro; if (a < 0 || a >= Ro) { od.clear(); break; } od[(size_t)a] = 1; }
+                if (od.empty()) continue;
+                size_t q = 0;
+                for (auto& d : od) if (d == -1) d = x.dims[q++];
+                y.dims = od;
+            } else {
+                std::vector<int64_t> od;
+                for (int a = 0; a < R; ++a) {
+                    bool drop = axes.empty() ? x.dims[(size_t)a] == 1 : false;
+                    for (auto ax : axes) if ((ax < 0 ? ax + R : ax) == a) drop = true;
+                    if (!drop) od.push_back(x.dims[(size_t)a]);
+                }
+                y.dims = od;
+            }
+        } else if (n.op == "Reshape") {
+            if (in.size() < 2 || !in[1]) continue;
+            std::vector<int64_t> od = in[1]->i64;
+            int64_t known_n = 1; int neg = -1;
+            for (size_t a = 0; a < od.size(); ++a) { if (od[a] == 0 && a < x.dims.size()) od[a] = x.dims[a]; if (od[a] == -1) neg = (int)a; else known_n *= od[a]; }
+            if (neg >= 0) { if (known_n == 0) continue; od[(size_t)neg] = numel(x) / known_n; }
+            y = x; y.name = n.out[0]; y.dims = od;
+            if (numel(y) != numel(x)) continue;
+        } else if (n.op == "Transpose") {
+            const OAttr* pa = n.attr("perm");
+            std::vector<int64_t> perm = pa ? pa->ints : std::vector<int64_t>();
+            if (perm.empty()) for (int a = R - 1; a >= 0; --a) perm.push_back(a);
+            if ((int)perm.size() != R) continue;
+            const std::vector<int64_t> xs = strides_of(x.dims);
+            std::vector<int64_t> od((size_t)R), st((size_t)R, 0), sp((size_t)R, 1), is((size_t)R);
+            for (int a = 0; a < R; ++a) { od[(size_t)a] = x.dims[(size_t)perm[(size_t)a]]; is[(size_t)a] = xs[(size_t)perm[(size_t)a]]; }
+            gather_nd(x, od, st, sp, is, y);
+        } else if (n.op == "Slice") {
+            std::vector<int64_t> starts = ints_of(1, "starts"), ends = ints_of(2, "ends"), axes = ints_of(3, "axes"), steps = ints_of(4, "steps");
+            if (starts.size() != ends.size() || starts.empty()) continue;
+            if (axes.empty()) for (size_t a = 0; a < starts.size(); ++a) axes.push_back((int64_t)a);
+            if (steps.empty()) steps.assign(starts.size(), 1);
+            std::vector<int64_t> od = x.dims, st((size_t)R, 0), sp((size_t)R, 1);
+            bool ok = true;
+            for (size_t k = 0; k < axes.size(); ++k) {
+                int64_t a = axes[k]; if (a < 0) a += R;
+                if (a < 0 || a >= R || steps[k] <= 0) { ok = false; break; }
+                const int64_t D = x.dims[(size_t)a];
+                int64_t s0 = starts[k], e0 = ends[k];
+                if (s0 < 0) s0 += D; if (e0 < 0) e0 += D;
+                s0 = std::min(std::max<int64_t>(s0, 0), D); e0 = std::min(std::max<int64_t>(e0, 0), D);
+                st[(size_t)a] = s0; sp[(size_t)a] = steps[k];
+                od[(size_t)a] = e0 > s0 ? (e0 - s0 + steps[k] - 1) / steps[k] : 0;
+            }
+            if (!ok) continue;
+            gather_nd(x, od, st, sp, strides_of(x.dims), y);
+        } else if (n.op == "Concat") {
+            const OAttr* aa = n.attr("axis");
+            int64_t axis = aa ? aa->i : 0; if (axis < 0) axis += R;
+            if (axis < 0 || axis >= R) continue;
+            bool ok = true; int64_t total = 0;
+            for (auto* t : in) {
+                if (!t || (int)t->dims.size() != R || is_int(*t) != is_int(x)) { ok = false; break; }
+                for (int a = 0; a < R; ++a) if (a != axis && t->dims[(size_t)a] != x.dims[(size_t)a]) ok = false;
+                total += t->dims[(size_t)axis];
+            }
+            if (!ok) continue;
+            y.dims = x.dims; y.dims[(size_t)axis] = total;
+            int64_t outer = 1, inner = 1;
+            for (int a = 0; a < axis; ++a) outer *= x.dims[(size_t)a];
+            for (int a = (int)axis + 1; a < R; ++a) inner *= x.dims[(size_t)a];
+            const bool ii = is_int(x);
+            if (ii) y.i64.resize((size_t)numel(y)); else y.f.resize((size_t)numel(y));
+            int64_t off = 0;
+            for (auto* t : in) {
+                const int64_t w = t->dims[(size_t)axis] * inner;
+                for (int64_t o = 0; o < outer; ++o) {
+                    if (ii) memcpy(&y.i64[(size_t)(o * total * inner + off)], &t->i64[(size_t)(o * w)], (size_t)w * 8);
+                    else memcpy(&y.f[(size_t)(o * total * inner + off)], &t->f[(size_t)(o * w)], (size_t)w * 4);
+                }
+                off += w;
+            }
+        }
+        g.init[y.name] = std::move(y);
+    }
+}
+
 int load_onnx(const char* path, OGraph& g, std::string& err)
 {
     FILE* f = fopen(path, "rb");
@@ -125,6 +267,7 @@ int load_onnx(const char* path, OGraph& g, std::string& err)
         else pb.skip(wt);
     }
     if (!pb.ok || !got) { err = std::string("not an ONNX ModelProto: ") + path; return SD_ERR_MODEL; }
+    fold_constants(g);
     return SD_OK;
 }
 

@@ -149,7 +149,7 @@ extern "C" int sd_clustering_ex(sd_ctx* c, const double* h_emb, int64_t chunks, 
     return SD_OK;
 }
 
-static int turns_out(sd_ctx* c, const std::vector<sd_turn>& v, sd_turn** turns, int64_t* n_turns)
+int turns_out(sd_ctx* c, const std::vector<sd_turn>& v, sd_turn** turns, int64_t* n_turns)
 {
     sd_turn* t = (sd_turn*)malloc(sizeof(sd_turn) * (v.size() ? v.size() : 1));
     if (!t) SD_FAIL(c, SD_ERR_ARG, "out of host memory");
@@ -188,7 +188,7 @@ extern "C" int sd_reconstruct(sd_ctx* c, const float* h_seg, const uint8_t* h_bi
 }
 
 // ------------------------------------------------------------------ sharded inference + finalize
-static int get_wav(sd_ctx* c, const int16_t* d_pcm, int64_t n, float** d_wav)
+int pcm_to_wav(sd_ctx* c, const int16_t* d_pcm, int64_t n, float** d_wav)
 {
     WS(c, float, w, "wav_f32", n + 512);
     hipLaunchKernelGGL(k_pcm_to_f32, GRID1(n), 0, c->stream, d_pcm, w, n);
@@ -197,7 +197,7 @@ static int get_wav(sd_ctx* c, const int16_t* d_pcm, int64_t n, float** d_wav)
     return SD_OK;
 }
 
-static int shard_infer(sd_ctx* c, const float* d_wav, int64_t n, int64_t lo, int64_t hi, float* d_seg, float* d_emb)
+int shard_infer(sd_ctx* c, const float* d_wav, int64_t n, int64_t lo, int64_t hi, float* d_seg, float* d_emb)
 {
     const int64_t nc = hi - lo;
     if (nc <= 0) return SD_OK;
@@ -226,7 +226,7 @@ static int shard_infer(sd_ctx* c, const float* d_wav, int64_t n, int64_t lo, int
     return SD_OK;
 }
 
-static int finalize(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t chunks, int64_t n, std::vector<sd_turn>& v)
+int finalize(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t chunks, int64_t n, std::vector<sd_turn>& v)
 {
     int rc;
     const double t0 = now_ms();
@@ -242,7 +242,8 @@ static int finalize(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t c
     hipLaunchKernelGGL(k_f32_to_f64, GRID1(M * SD_EMB_DIM), 0, c->stream, d_emb, d_e64, M * SD_EMB_DIM);
     KCHECK(c);
     std::vector<int> hard; int K = 1;
-    if ((rc = run_clustering(c, d_e64, M, SD_EMB_DIM, hard, &K, c->num_clusters, c->min_clusters, c->max_clusters))) return rc;
+    std::vector<double> soft_best;
+    if ((rc = run_clustering(c, d_e64, M, SD_EMB_DIM, hard, &K, c->num_clusters, c->min_clusters, c->max_clusters, &soft_best))) return rc;
     HIPCHK(c, hipMemcpyAsync(d_hard, hard.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_mark_inactive, GRID1(M), 0, c->stream, d_hard, d_nact, M);
     KCHECK(c);
@@ -252,6 +253,24 @@ static int finalize(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t c
     for (int h : hard) if (h > Kr) Kr = h;
     Kr += 1;                                                                  // sd.cpp:2803-2812
     if ((rc = run_reconstruct(c, d_seg, d_nact, d_hard, d_count, nf, chunks, n, Kr, v))) return rc;
+    // per-turn confidence: mean soft score (2 - cosine distance to the centroid, sd.cpp:2191-2207) of the
+    // (chunk, local speaker) items assigned to the turn's cluster whose 5 s chunk [0.5 c, 0.5 c + 5) overlaps the turn
+    { KernelStat& ks = c->stats["clusters_K"]; ks.launches++; ks.flops += (double)Kr; ks.bytes += (double)v.size(); }       // bench: K and turns per job
+    c->last_conf.assign(v.size(), NAN);
+    for (size_t t = 0; t < v.size(); ++t) {
+        int64_t c0 = (int64_t)std::floor((v[t].start - 5.0) / 0.5), c1 = (int64_t)std::ceil(v[t].end / 0.5);
+        if (c0 < 0) c0 = 0;
+        if (c1 > chunks - 1) c1 = chunks - 1;
+        double sum = 0.0; int64_t cnt = 0;
+        for (int64_t ck = c0; ck <= c1; ++ck) {
+            if (!(0.5 * (double)ck < v[t].end && 0.5 * (double)ck + 5.0 > v[t].start)) continue;
+            for (int s = 0; s < SD_SPEAKERS; ++s) {
+                const size_t i = (size_t)(ck * SD_SPEAKERS + s);
+                if (hard[i] == v[t].label && soft_best[i] == soft_best[i]) { sum += soft_best[i]; cnt++; }
+            }
+        }
+        if (cnt > 0) c->last_conf[t] = sum / (double)cnt;
+    }
     c->stage_ms[2] += now_ms() - t0;
     return SD_OK;
 }
@@ -265,9 +284,9 @@ extern "C" int sd_shard_infer_dev(sd_ctx* c, const int16_t* d_pcm_shard, int64_t
     int64_t need_hi = (chunk_hi - 1) * SD_HOP + SD_CHUNK; if (need_hi > n) need_hi = n;
     if (chunk_hi > chunk_lo && (first_sample > need_lo || first_sample + shard_samples < need_hi))
         SD_FAIL(c, SD_ERR_ARG, "shard samples [%lld,%lld) do not cover chunks [%lld,%lld)", (long long)first_sample, (long long)(first_sample + shard_samples), (long long)chunk_lo, (long long)chunk_hi);
-    WS(c, float, w, "wav_f32", shard_samples + 512);
-    hipLaunchKernelGGL(k_pcm_to_f32, GRID1(shard_samples), 0, c->stream, d_pcm_shard, w, shard_samples);
-    KCHECK(c);
+    float* w = nullptr;
+    int rc0 = pcm_to_wav(c, d_pcm_shard, shard_samples, &w);
+    if (rc0) return rc0;
     for (int i = 0; i < 4; ++i) c->stage_ms[i] = 0;
     // kernels index the recording with absolute sample positions; only the covered range is ever touched
     return shard_infer(c, w - first_sample, n, chunk_lo, chunk_hi, d_seg, d_emb);
@@ -302,7 +321,7 @@ extern "C" int sd_diarize_dev(sd_ctx* c, const int16_t* d_pcm, int64_t n, sd_tur
     if (chunks <= 0) SD_FAIL(c, SD_ERR_SHORT, "audio of %lld samples yields no chunk", (long long)n);
     for (int i = 0; i < 4; ++i) c->stage_ms[i] = 0;
     float* d_wav = nullptr;
-    int rc = get_wav(c, d_pcm, n, &d_wav);
+    int rc = pcm_to_wav(c, d_pcm, n, &d_wav);
     if (rc) return rc;
     WS(c, float, d_seg, "dz_seg", chunks * SD_FRAMES * 3);
     WS(c, float, d_emb, "dz_emb", chunks * 3 * SD_EMB_DIM);

@@ -35,8 +35,10 @@ EXPORTS = [
     "sd_clustering", "sd_clustering_ex", "sd_reconstruct", "sd_diarize", "sd_diarize_dev", "sd_free_turns", "sd_shard_infer_dev",
     "sd_finalize_dev", "sd_read_wav", "sd_free_pcm", "sd_format_turn", "sd_stage_ms", "sd_kernel_stats",
     "sd_reset_stats", "sd_set_option", "sd_bench_conv", "sd_bench_barrier", "sd_convert_onnx", "sd_convert_error", "sd_read_wav_f32", "sd_free_wav", "sd_diarize_f32",
-    "sd_write_rttm", "sd_set_planted",
+    "sd_write_rttm", "sd_set_planted", "sd_comm_unique_id", "sd_comm_init", "sd_comm_destroy", "sd_comm_info", "sd_shard_plan",
+    "sd_diarize_sharded", "sd_diarize_sharded_dev", "sd_write_rttm_ex", "sd_relabel_turns", "sd_relabel_turns_ex", "sd_last_confidence",
 ]
+COMM_ID_BYTES = 128
 
 
 def lib():
@@ -82,6 +84,17 @@ def lib():
     L.sd_diarize_f32.argtypes = [vp, vp, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
     L.sd_write_rttm.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Turn), i64]
     L.sd_set_planted.argtypes = [vp, vp, vp, i64, i64]
+    L.sd_comm_unique_id.argtypes = [vp]
+    L.sd_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.sd_comm_destroy.argtypes = [vp]
+    L.sd_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.sd_shard_plan.argtypes = [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    L.sd_diarize_sharded.argtypes = [vp, vp, i64, i64, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
+    L.sd_diarize_sharded_dev.argtypes = [vp, vp, i64, i64, i64, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
+    L.sd_write_rttm_ex.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Turn), i64, C.POINTER(dbl)]
+    L.sd_relabel_turns.argtypes = [C.POINTER(Turn), i64]
+    L.sd_relabel_turns_ex.argtypes = [C.POINTER(Turn), i64, C.c_int]
+    L.sd_last_confidence.argtypes = [vp, C.POINTER(dbl), i64, C.POINTER(i64)]
     L.sd_format_turn.argtypes = [C.POINTER(Turn), C.c_char_p, C.c_int]
     L.sd_stage_ms.argtypes = [vp, C.POINTER(dbl)]
     L.sd_kernel_stats.argtypes = [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
@@ -101,29 +114,29 @@ def num_chunks(n):
     return int(c), int(ll.value)
 
 
+def shard_plan(n_total, world, rank0_permille=-1):
+    """sd_shard_plan: (slot size in chunks of the padded all-gather, [(lo, hi)] by rank) -- contiguous chunk ranges, each
+    starting on a multiple of 32 chunks (= 96 items = 3 reference embedding batches)"""
+    arr = (C.c_int64 * (2 * world))()
+    per = C.c_int64(0)
+    rc = lib().sd_shard_plan(n_total, world, rank0_permille, arr, C.byref(per))
+    if rc:
+        raise SdError(rc, "sd_shard_plan: bad argument")
+    return int(per.value), [(int(arr[2 * r]), int(arr[2 * r + 1])) for r in range(world)]
+
+
 def plan_shards(n_total, world):
-    """contiguous chunk ranges per rank, aligned to 32 chunks (= 96 items = 3 reference embedding
-    batches) so every rank forms exactly the reference's batches.  Returns (per, [(lo, hi)])"""
-    C, _ = num_chunks(n_total)
-    per = -(-C // world)
-    per = -(-per // 32) * 32
-    return per, [(min(C, r * per), min(C, (r + 1) * per)) for r in range(world)]
+    """equal shares"""
+    return shard_plan(n_total, world, -1)
 
 
 def plan_ranks(n_total, world, rank0_fraction=None):
     """chunk range of every rank when rank 0, which also finalizes (count / clustering / reconstruction), is given a
     smaller share of the chunks: rank0_fraction of all chunks (0 = none), the other ranks split the rest evenly.
-    None = equal shares (plan_shards).  Every shard starts on a multiple of 32 chunks.
-    Returns (per, [(lo, hi)] by rank): per = slot size of the padded all-gather, rank r's shard sits in slot r."""
+    None = equal shares.  Returns (per, [(lo, hi)] by rank): per = slot size of the padded all-gather."""
     if rank0_fraction is None or world == 1:
-        return plan_shards(n_total, world)
-    C, _ = num_chunks(n_total)
-    c0 = min(C, int(round(C * max(0.0, min(1.0, rank0_fraction)) / 32.0)) * 32)
-    rest = C - c0
-    per_r = -(-rest // (world - 1))
-    per_r = -(-per_r // 32) * 32
-    ranges = [(0, c0)] + [(min(C, c0 + r * per_r), min(C, c0 + (r + 1) * per_r)) for r in range(world - 1)]
-    return max(c0, per_r, 32), ranges
+        return shard_plan(n_total, world, -1)
+    return shard_plan(n_total, world, int(round(1000.0 * max(0.0, min(1.0, rank0_fraction)))))
 
 
 def gather_pieces(per, ranges):
@@ -181,13 +194,39 @@ def read_wav_f32(path):
     return arr[:n.value], sr.value, ch.value, bits.value
 
 
-def write_rttm(path, uri, turns):
+def _turn_array(turns):
     arr = (Turn * max(len(turns), 1))()
     for i, t in enumerate(turns):
         arr[i] = Turn(t[0], t[1], t[2], 0)
-    rc = lib().sd_write_rttm(path.encode(), uri.encode(), arr, len(turns))
+    return arr
+
+
+def write_rttm(path, uri, turns, conf=None):
+    arr = _turn_array(turns)
+    if conf is None:
+        rc = lib().sd_write_rttm(path.encode(), uri.encode(), arr, len(turns))
+    else:
+        cc = (C.c_double * max(len(turns), 1))(*[float(x) for x in conf])
+        rc = lib().sd_write_rttm_ex(path.encode(), uri.encode(), arr, len(turns), cc)
     if rc:
         raise SdError(rc, "cannot write " + path)
+
+
+def relabel_turns(turns, mode="pyannote"):
+    """'pyannote': labels that occur, sorted by their string, -> 0, 1, ... (SPEAKER_00 ...); 'first': order of first appearance"""
+    arr = _turn_array(turns)
+    rc = lib().sd_relabel_turns_ex(arr, len(turns), 1 if mode == "pyannote" else 0)
+    if rc:
+        raise SdError(rc, "sd_relabel_turns_ex: bad argument")
+    return [(arr[i].start, arr[i].end, int(arr[i].label)) for i in range(len(turns))]
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().sd_comm_unique_id(buf)
+    if rc:
+        raise SdError(rc, "sd_comm_unique_id failed (RCCL needs a GPU)")
+    return buf.raw
 
 
 class Diarizer:
@@ -302,7 +341,8 @@ class Diarizer:
 
     def _turns(self, p, n):
         out = [(p[i].start, p[i].end, int(p[i].label)) for i in range(n.value)]
-        lib().sd_free_turns(p)
+        if p:
+            lib().sd_free_turns(p)
         return out
 
     # ---- whole path
@@ -329,6 +369,39 @@ class Diarizer:
     def shard_infer_dev(self, d_pcm_shard_ptr, first_sample, shard_samples, n_total, chunk_lo, chunk_hi, d_seg_ptr, d_emb_ptr):
         self._chk(lib().sd_shard_infer_dev(self._h, C.c_void_p(d_pcm_shard_ptr), first_sample, shard_samples, n_total,
                                            chunk_lo, chunk_hi, C.c_void_p(d_seg_ptr), C.c_void_p(d_emb_ptr)))
+
+    def comm_init(self, id_bytes, rank, world):
+        assert len(id_bytes) == COMM_ID_BYTES
+        self._chk(lib().sd_comm_init(self._h, C.c_char_p(id_bytes), rank, world))
+
+    def comm_destroy(self):
+        lib().sd_comm_destroy(self._h)
+
+    def comm_info(self):
+        r, w = C.c_int(0), C.c_int(0)
+        lib().sd_comm_info(self._h, C.byref(r), C.byref(w))
+        return r.value, w.value
+
+    def diarize_sharded_dev(self, d_pcm_shard_ptr, first_sample, shard_samples, n_total):
+        """collective over the ctx's RCCL communicator; turns on rank 0, [] elsewhere"""
+        p = C.POINTER(Turn)()
+        n = C.c_int64(0)
+        self._chk(lib().sd_diarize_sharded_dev(self._h, C.c_void_p(d_pcm_shard_ptr or None), first_sample, shard_samples, n_total, C.byref(p), C.byref(n)))
+        return self._turns(p, n)
+
+    def diarize_sharded(self, pcm_shard, first_sample, n_total):
+        pcm_shard = np.ascontiguousarray(pcm_shard, np.int16)
+        p = C.POINTER(Turn)()
+        n = C.c_int64(0)
+        self._chk(lib().sd_diarize_sharded(self._h, _ptr(pcm_shard), first_sample, len(pcm_shard), n_total, C.byref(p), C.byref(n)))
+        return self._turns(p, n)
+
+    def last_confidence(self):
+        n = C.c_int64(0)
+        self._chk(lib().sd_last_confidence(self._h, None, 0, C.byref(n)))
+        buf = (C.c_double * max(n.value, 1))()
+        self._chk(lib().sd_last_confidence(self._h, buf, n.value, C.byref(n)))
+        return np.array(buf[:n.value], np.float64)
 
     def finalize_dev(self, d_seg_ptr, d_emb_ptr, chunks, n_samples):
         p = C.POINTER(Turn)()

@@ -177,3 +177,183 @@ def test_gpu_diarize_f32_equals_int16_path_and_cli_rttm(diarizer, weights, tmp_p
     assert out.returncode == 0, out.stderr
     turns = diarizer.diarize(pcm)
     assert len(rttm.read_text().splitlines()) == len(turns)
+
+
+# ------------------------------------------------------------------ f4: relabelling, confidence, RTTM confidence column
+def test_relabel_conventions():
+    turns = [(0.5, 2.0, 10), (1.0, 3.0, 2), (3.5, 4.0, 2), (4.0, 9.0, 0), (9.5, 10.0, 10)]
+    # pyannote: Annotation.labels() sorts the labels that occur by their STRING ("0" < "10" < "2") -> SPEAKER_00, 01, 02
+    assert [t[2] for t in sdhip.relabel_turns(turns, "pyannote")] == [1, 2, 2, 0, 1]
+    assert [t[2] for t in sdhip.relabel_turns(turns, "first")] == [0, 1, 1, 2, 0]
+    assert sdhip.relabel_turns([], "first") == []
+    r = sdhip.relabel_turns(turns, "first")
+    assert [(a[0], a[1]) for a in r] == [(a[0], a[1]) for a in turns]
+
+
+def test_rttm_confidence_column(tmp_path):
+    turns = [(5.222812345, 17.74406789, 3), (17.8116, 25.2197, 0)]
+    p = tmp_path / "c.rttm"
+    sdhip.write_rttm(str(p), "rec", turns, conf=[1.87654321, float("nan")])
+    lines = p.read_text().splitlines()
+    assert lines[0] == "SPEAKER rec 1 5.223 12.521 <NA> <NA> SPEAKER_03 <NA> 1.8765"
+    assert lines[1].endswith("SPEAKER_00 <NA> <NA>")
+
+
+def test_cli_multi_gpu_launcher_fails_cleanly_without_devices(golden_dir):
+    """speakerDiarizer --gpus 2: the launcher forks one process per GPU before anything touches HIP and hands the RCCL
+    rendezvous id over through pipes.  Without (enough) GPUs every rank must say why and the launcher must return 1
+    promptly -- no rank may block on a pipe whose writer died."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pyannote-audio_speaker-diarization_cpp_amd", "speakerDiarizer")
+    out = subprocess.run([exe, "--gpus", "2", "/nonexistent/seg.onnx", "/nonexistent/emb.onnx", os.path.join(golden_dir, "multi-speaker_1min.wav")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 1
+    assert "rank 0" in out.stderr and "rank 1" in out.stderr and "Speaker_" not in out.stdout
+
+
+# ------------------------------------------------------------------ f3: constrained_argmax (Clustering.py:81-94)
+def test_oracle_linear_sum_assignment_is_scipys():
+    """the dependency behind constrained_argmax is scipy.optimize.linear_sum_assignment; the oracle restates its algorithm
+    (rectangular_lsap.cpp) and must pick the same one of several optimal assignments: ties, constant rows (NaN rows after
+    nan_to_num), fewer clusters than speakers (transposed problem)"""
+    from scipy.optimize import linear_sum_assignment as lsa
+    rng = np.random.default_rng(0)
+    for trial in range(2000):
+        nc = int(rng.integers(1, 9))
+        mode = trial % 4
+        if mode == 0:
+            cost = rng.standard_normal((3, nc))
+        elif mode == 1:
+            cost = rng.integers(0, 3, (3, nc)).astype(float)
+        elif mode == 2:
+            cost = rng.standard_normal((3, nc))
+            cost[rng.integers(0, 3)] = cost.min()
+            if rng.random() < 0.5:
+                cost[rng.integers(0, 3)] = cost.min()
+        else:
+            cost = np.zeros((3, nc))
+        for mx in (True, False):
+            r1, c1 = lsa(cost, maximize=mx)
+            r2, c2 = orc.linear_sum_assignment(cost, mx)
+            assert np.array_equal(r1, r2) and np.array_equal(c1, c2), (trial, mx)
+
+
+def _py_constrained_argmax(soft):
+    from scipy.optimize import linear_sum_assignment as lsa
+    s = np.nan_to_num(soft, nan=np.nanmin(soft))                            # Clustering.py:83
+    hard = -2 * np.ones(s.shape[:2], np.int32)
+    for c, cost in enumerate(s):
+        for a, b in zip(*lsa(cost, maximize=True)):
+            hard[c, a] = b
+    return hard
+
+
+def _planted_emb(c, k, pnan, seed, s=0.5):
+    rng = np.random.default_rng(seed)
+    cen = rng.standard_normal((k, 192)) * 2
+    emb = (cen[rng.integers(0, k, (c, 3))] + s * rng.standard_normal((c, 3, 192))).astype(np.float32).astype(np.float64)
+    emb[rng.random((c, 3)) < pnan] = np.nan
+    return emb
+
+
+@pytest.mark.parametrize("c,k,pnan", [(200, 5, 0.3), (150, 2, 0.2), (90, 3, 0.0), (120, 8, 0.5)])
+def test_oracle_constrained_assignment_follows_python_spec(c, k, pnan):
+    emb = _planted_emb(c, k, pnan, seed=c + k)
+    hard, K, soft = orc.clustering_full(emb, constrained=True)
+    assert K == k and np.array_equal(hard, _py_constrained_argmax(soft))
+    per_chunk_distinct = all(len({x for x in row if x >= 0}) == sum(x >= 0 for x in row) for row in hard.tolist())
+    assert per_chunk_distinct and ((hard == -2).any() == (k < 3))
+    h0, K0, _ = orc.clustering(emb)
+    assert not np.array_equal(h0, hard)                                     # the plain argmax does put two local speakers in one cluster
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,k,pnan", [(200, 5, 0.3), (150, 2, 0.2), (90, 3, 0.0), (120, 8, 0.5)])
+def test_gpu_constrained_assignment_matches_oracle(diarizer, c, k, pnan):
+    emb = _planted_emb(c, k, pnan, seed=c + k)
+    diarizer.set_option("constrained_assignment", 1)
+    try:
+        h, K = diarizer.clustering(emb)
+    finally:
+        diarizer.set_option("constrained_assignment", 0)
+    h_ref, K_ref, _ = orc.clustering_full(emb, constrained=True)
+    assert K == K_ref and np.array_equal(h, h_ref)
+    assert np.array_equal(diarizer.clustering(emb)[0], orc.clustering(emb)[0])       # and the default is back
+
+
+@pytest.mark.gpu
+def test_gpu_confidence_and_relabelled_rttm(diarizer, tmp_path):
+    """per-turn confidence = mean soft score (sd.cpp:2191-2207) of the items of the turn's cluster whose chunk overlaps it"""
+    import torch
+    import synth
+    sec = 300.0
+    pcm = synth.make_pcm(sec, 21)
+    n = len(pcm)
+    nc = synth.num_chunks(n)
+    scores, assign = synth.planted_scores(synth.with_duets(synth.schedule(sec, 21)), n, 0, nc)
+    emb = synth.planted_embeddings(assign, outlier_every=97)
+    from test_planted import nan_rule
+    binar, _, _, bad = nan_rule(scores)
+    emb[bad] = np.nan
+    dev = torch.device("cuda", 0)
+    d_seg, d_emb = torch.from_numpy(scores).to(dev), torch.from_numpy(emb).to(dev)
+    torch.cuda.synchronize()
+    turns = diarizer.finalize_dev(d_seg.data_ptr(), d_emb.data_ptr(), nc, n)
+    conf = diarizer.last_confidence()
+    assert len(conf) == len(turns) > 20
+    hard, K, soft = orc.clustering_full(emb.astype(np.float64).reshape(nc, 3, 192))
+    hard = orc.mark_inactive(binar, hard)
+    exp = np.full(len(turns), np.nan)
+    for t, (s, e, k) in enumerate(turns):
+        vals = [soft[c, sp, k] for c in range(nc) for sp in range(3)
+                if hard[c, sp] == k and 0.5 * c < e and 0.5 * c + 5.0 > s and not np.isnan(soft[c, sp, k])]
+        if vals:
+            exp[t] = np.mean(vals)
+    assert np.isfinite(exp).all() and (exp > 1.0).all()
+    np.testing.assert_allclose(conf, exp, rtol=1e-12, atol=0)
+    p = tmp_path / "r.rttm"
+    rel = sdhip.relabel_turns(turns, "first")
+    sdhip.write_rttm(str(p), "rec", rel, conf=conf)
+    lines = p.read_text().splitlines()
+    assert len(lines) == len(turns) and lines[0].split()[7] == "SPEAKER_00" and float(lines[0].split()[9]) == round(conf[0], 4)
+
+
+# ------------------------------------------------------------------ 8e under the boundary: RCCL communicator inside libsdhip
+@pytest.mark.gpu
+def test_sharded_entry_point_through_rccl_world_of_one(diarizer):
+    """sd_comm_unique_id / sd_comm_init / sd_diarize_sharded_dev on one rank: the RCCL all-gather runs on the library's
+    stream and the result equals sd_diarize_dev (the N-rank form cannot run on a 1-GPU box: RCCL refuses two ranks on one device)"""
+    import torch
+    import synth
+    pcm = synth.make_pcm(60.0, seed=12)
+    n = len(pcm)
+    dev = torch.device("cuda", 0)
+    d_pcm = torch.from_numpy(pcm).to(dev)
+    torch.cuda.synchronize()
+    whole = diarizer.diarize_dev(d_pcm.data_ptr(), n)
+    assert diarizer.comm_info() == (0, 0)
+    diarizer.comm_init(sdhip.comm_unique_id(), 0, 1)
+    try:
+        assert diarizer.comm_info() == (0, 1)
+        assert diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 0, n, n) == whole
+        assert diarizer.diarize_sharded(pcm, 0, n) == whole
+        assert diarizer.kernel_stats("rccl_all_gather")["launches"] >= 2
+        # the plan and slot assembly of 2- / 3- / 8-rank jobs (equal shares, reduced and zero rank-0 share), played by this one rank
+        for W, pm in [(2, -1), (3, 100), (3, 0), (8, 30)]:
+            diarizer.set_option("virtual_world", W)
+            diarizer.set_option("rank0_permille", pm)
+            try:
+                assert diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 0, n, n) == whole, (W, pm)
+            finally:
+                diarizer.set_option("virtual_world", 0)
+                diarizer.set_option("rank0_permille", -1)
+        with pytest.raises(sdhip.SdError):
+            diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 8000, n - 8000, n)       # samples do not cover the rank's chunks
+    finally:
+        diarizer.comm_destroy()
+    assert diarizer.comm_info() == (0, 0)
+    with pytest.raises(sdhip.SdError):
+        diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 0, n, n)                     # no communicator
