@@ -149,11 +149,15 @@ extern "C" int sd_frontend(sd_ctx* c, const float* h_wav, int64_t n, const float
     if (!h_wav || !h_masks || n <= 0 || items <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_frontend: bad argument");
     DTMP(c, dw, n * sizeof(float)); DTMP(c, dm, items * SD_FRAMES * sizeof(float));
     DTMP(c, df, items * SD_TP * SD_FEAT_LD * sizeof(float)); DTMP(c, dl, items * sizeof(float));
-    DTMP(c, dn, items * sizeof(int)); DTMP(c, dv, items * sizeof(int)); DTMP(c, dg, items * sizeof(int));
+    DTMP(c, dn, items * sizeof(int)); DTMP(c, dv, items * sizeof(int)); DTMP(c, dg, items * sizeof(int)); DTMP(c, dr, (items + 1) * sizeof(int));
     HIPCHK(c, hipMemcpy(dw.p, h_wav, n * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dm.p, h_masks, items * SD_FRAMES * sizeof(float), hipMemcpyHostToDevice));
-    int rc = run_frontend(c, (const float*)dw.p, n, (const float*)dm.p, items, 0, (float*)df.p, (float*)dl.p, (int*)dn.p, (int*)dv.p, (int*)dg.p);
+    std::vector<int> ro((size_t)items + 1);
+    for (int64_t i = 0; i <= items; ++i) ro[(size_t)i] = (int)(i * SD_TP);                  // every frame of every item (reference layout)
+    HIPCHK(c, hipMemcpy(dr.p, ro.data(), ro.size() * sizeof(int), hipMemcpyHostToDevice));
+    int rc = frontend_prepare(c, (const float*)dm.p, items, 0, (float*)dl.p, (int*)dn.p, (int*)dv.p, (int*)dg.p, false, nullptr, nullptr);
     if (rc) return rc;
+    if ((rc = frontend_features(c, (const float*)dw.p, n, 0, items, false, (const int*)dn.p, (const int*)dr.p, (float*)df.p))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (h_feats) {
         std::vector<float> tmp((size_t)items * SD_TP * SD_FEAT_LD);
@@ -170,21 +174,34 @@ extern "C" int sd_ecapa(sd_ctx* c, const float* h_feats, const float* h_lens, in
 {
     ENTER(c);
     if (!h_feats || !h_lens || !h_emb || items <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_ecapa: bad argument");
-    std::vector<float> tmp((size_t)items * SD_TP * SD_FEAT_LD, 0.0f);
-    std::vector<int> nv(items), fl(items, 0);
+    std::vector<int> nv((size_t)items), rowoff;
     for (int64_t i = 0; i < items; ++i) {
-        for (int t = 0; t < SD_T; ++t)
-            memcpy(&tmp[((size_t)i * SD_TP + t) * SD_FEAT_LD], h_feats + ((size_t)i * SD_T + t) * SD_NMELS, SD_NMELS * sizeof(float));
         float lt = h_lens[i] * (float)SD_T;
         int v = (int)ceilf(lt); if (v > SD_T) v = SD_T; if (v < 1) v = 1;
-        nv[i] = v;
+        nv[(size_t)i] = v;
     }
-    DTMP(c, df, tmp.size() * sizeof(float)); DTMP(c, dv, items * sizeof(int)); DTMP(c, dg, items * sizeof(int)); DTMP(c, de, items * SD_EMB_DIM * sizeof(float));
+    DTMP(c, dv, items * sizeof(int)); DTMP(c, dr, (items + 1) * sizeof(int)); DTMP(c, de, items * SD_EMB_DIM * sizeof(float));
+    int rc = ecapa_row_plan(c, nv.data(), items, rowoff, (int*)dr.p);
+    if (rc) return rc;
+    const int64_t rows = rowoff[(size_t)items];
+    std::vector<float> tmp((size_t)rows * SD_FEAT_LD, 0.0f);                                 // compact rows: the frames each item needs
+    for (int64_t i = 0; i < items; ++i)
+        for (int t = 0; t < rowoff[(size_t)i + 1] - rowoff[(size_t)i]; ++t)
+            memcpy(&tmp[((size_t)rowoff[(size_t)i] + t) * SD_FEAT_LD], h_feats + ((size_t)i * SD_T + t) * SD_NMELS, SD_NMELS * sizeof(float));
+    DTMP(c, df, tmp.size() * sizeof(float));
     HIPCHK(c, hipMemcpy(df.p, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dv.p, nv.data(), items * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dg.p, fl.data(), items * sizeof(int), hipMemcpyHostToDevice));
-    int rc = run_ecapa(c, (const float*)df.p, (const int*)dv.p, (const int*)dg.p, items, (float*)de.p, c->skip_dead_rows ? nv.data() : nullptr);
-    if (rc) return rc;
+    int64_t nb = (c->emb_batch_items / 96) * 96; if (nb < 96) nb = 96;
+    const int64_t cap_rows = nb * SD_TP;
+    for (int64_t a0 = 0; a0 < items;) {
+        int64_t a1 = a0;
+        while (a1 < items && a1 - a0 < ROWTAB_MAX_ITEMS && rowoff[(size_t)a1 + 1] - rowoff[(size_t)a0] <= cap_rows) ++a1;
+        if (a1 == a0) a1 = a0 + 1;
+        const int base = rowoff[(size_t)a0];
+        if ((rc = run_ecapa(c, (const float*)df.p + (size_t)base * SD_FEAT_LD, (const int*)dv.p + a0, (const int*)dr.p + a0, base, a1 - a0,
+                            rowoff[(size_t)a1] - base, (float*)de.p + (size_t)a0 * SD_EMB_DIM))) return rc;
+        a0 = a1;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(h_emb, de.p, items * SD_EMB_DIM * sizeof(float), hipMemcpyDeviceToHost));
     return SD_OK;

@@ -56,11 +56,17 @@ struct ConvArgs {
     int act1, act2;        // act1: 0 none 1 relu 2 leaky(0.01); act2 (after BN): 0 none 1 tanh 2 sigmoid
     int m_tiles, n_tiles;
     int sched;             // persistent-schedule variant (set by the launcher)
-    const int* mlist;      // optional per-XCD list of the row panels to compute: mlist[xcd * mlist_ld + j]
-    const int* mcount;     // [8] number of listed panels per XCD (rows of skipped panels are left untouched)
-    int mlist_ld;
-    double rows_listed;    // valid rows covered by the listed panels (FLOP accounting)
+    // compact row space (ECAPA): the buffers hold, item after item, only the frames that can influence a valid output
+    // (need_i = min(501, nvalid_i + receptive field) rows of item i).  rowtab[g] of compact row g:
+    //   .x = first compact row of g's item,  .y = frame t | (need - 1) << 10 | item << 20
+    // Input and output share the row space (TpIn / TpOut / T unused); a tap that reaches beyond the item's last stored frame
+    // reads that last frame instead (it can only feed frames that are themselves beyond nvalid).  null = dense mapping.
+    const int2* rowtab;
 };
+#define ROWTAB_T(y) ((y) & 1023)
+#define ROWTAB_LAST(y) (((y) >> 10) & 1023)
+#define ROWTAB_ITEM(y) ((int)((unsigned)(y) >> 20))
+#define ROWTAB_MAX_ITEMS 4095
 
 struct EcapaWeights {
     bool loaded = false;
@@ -153,12 +159,14 @@ int load_model_any(const char* path, int kind, Pack& out, std::string& err);   /
 int build_ecapa_weights(sd_ctx* c, const Pack& p);
 int build_seg_weights(sd_ctx* c, const Pack& p);
 // ---- frontend.hip
-int run_frontend(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item,
-                 float* d_feats /*[items][512][96]*/, float* d_wav_lens, int* d_nnorm, int* d_nvalid, int* d_flags,
-                 bool compact = false, int* h_n_active = nullptr, int* d_cidx = nullptr);
+int frontend_prepare(sd_ctx* c, const float* d_masks, int64_t items, int64_t first_item, float* d_wav_lens, int* d_nnorm, int* d_nvalid,
+                     int* d_flags, bool compact, int* h_n_active, int* d_cidx);
+int frontend_features(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_item, int64_t run_items, bool compact, const int* d_nnorm,
+                      const int* d_rowoff, float* d_feats /*[rowoff[run_items]][96]*/);
 // ---- ecapa.hip
-int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_flags, int64_t items, float* d_emb,
-              const int* h_nvalid = nullptr);
+int ecapa_need_rows(int nvalid, bool skip_dead_rows);
+int ecapa_row_plan(sd_ctx* c, const int* h_nvalid, int64_t n, std::vector<int>& rowoff, int* d_rowoff /*[n + 1]*/);
+int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, int64_t items, int64_t rows, float* d_emb);
 int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item, float* d_emb);
 // ---- pyannet.hip
 int run_segment(sd_ctx* c, const float* d_wav, int64_t n, int64_t chunk_lo, int64_t chunk_hi, float* d_seg);

@@ -22,8 +22,7 @@
 //
 // Persistent schedule: the grid is 2 workgroups per CU; the workgroups whose id is
 // equal mod 8 (one XCD under round-robin dispatch, a speed assumption only) walk
-// PM x PN super-blocks of tiles together (row panels m = xcd + 8j or the j-th entry
-// of the XCD's panel list).  The K-step pipeline runs straight across tile
+// PM x PN super-blocks of tiles together (row panels m = xcd + 8j).  The K-step pipeline runs straight across tile
 // boundaries: the first loads of tile i+1 are in flight while tile i's accumulators
 // go through the epilogue, so short-K layers (Res2Net K=384, ASP K=128) do not pay
 // a load-latency bubble per tile.
@@ -56,9 +55,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 
     const int w = blockIdx.x, G = gridDim.x;                 // G is a multiple of 8
     const int xcd = w & 7, wl = w >> 3, wpx = G >> 3;
-    // row panels owned by this XCD: m = xcd + 8 j, or the j-th entry of its panel list (time rows that cannot
-    // influence any valid output frame are not listed, see run_ecapa)
-    const int mx = a.mlist ? a.mcount[xcd] : ((a.m_tiles - xcd + 7) >> 3);
+    // row panels owned by this XCD: m = xcd + 8 j
+    const int mx = (a.m_tiles - xcd + 7) >> 3;
     // Super-block schedule: the wpx workgroups of an XCD work at the same time on a PM x PN block of tiles
     // (workgroup wl owns position (wl / PN, wl % PN) of every block).  They advance through K roughly in step,
     // so each A and W K-slice is pulled into the XCD's L2 once per block and shared by PN resp. PM workgroups
@@ -96,9 +94,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     // All global reads are buffer loads: a per-tile resource descriptor in SGPRs, a per-lane byte offset that only
     // changes with the tap, and the K position as the instruction's scalar offset -- moving to the next K-step is
     // one scalar add instead of twelve 64-bit vector pointer increments on the MFMA issue path.
-    int rrel[4], tt[4];                 // per part: item offset (rows) relative to the tile's first item, clamped frame
+    int rrel[4], tt[4], nd[4];          // per part: item offset (rows) relative to the tile's first item, clamped frame, last stored frame
     unsigned voA[4], voX[HAS_X2 ? 4 : 1], voB[4];
-    const size_t in_rows = (size_t)((a.M + a.TpOut - 1) / a.TpOut) * a.TpIn;
+    const bool RT = a.rowtab != nullptr;                     // compact row space (see ConvArgs)
+    const size_t in_rows = RT ? (size_t)a.M : (size_t)((a.M + a.TpOut - 1) / a.TpOut) * a.TpIn;
+    // row-table entries of the tile the load stream visits NEXT: fetched one tile ahead, so a tile switch never waits for them
+    int2 pre[4]; int pre_base = 0;
+    auto prefetch_tab = [&](int sb) {
+        int j, nt;
+        (void)sb_valid(sb, j, nt);
+        const int m0 = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * BM);
+        pre_base = a.rowtab[m0 < a.M ? m0 : a.M - 1].x;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { int g = m0 + r0 + 32 * p; if (g > a.M - 1) g = a.M - 1; pre[p] = a.rowtab[g]; }
+    };
     auto make_rsrc = [&](const float* base, size_t bytes) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
     };
@@ -117,22 +126,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     auto set_tile = [&](int sb) {
         int j, nt;
         (void)sb_valid(sb, j, nt);
-        m0l = __builtin_amdgcn_readfirstlane((a.mlist ? a.mlist[xcd * a.mlist_ld + j] : (xcd + 8 * j)) * BM);   // wave-uniform: keeps the descriptors in SGPRs
+        m0l = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * BM);   // wave-uniform: keeps the descriptors in SGPRs
         n0l = __builtin_amdgcn_readfirstlane(nt * BN);
-        const int b0 = m0l / a.TpOut;
-        const size_t row0 = (size_t)b0 * a.TpIn;
+        size_t row0;
+        if (RT) {
+            const int base = __builtin_amdgcn_readfirstlane(pre_base);
+            row0 = (size_t)base;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { rrel[p] = pre[p].x - base; tt[p] = ROWTAB_T(pre[p].y); nd[p] = ROWTAB_LAST(pre[p].y); }
+        } else {
+            const int b0 = m0l / a.TpOut;
+            row0 = (size_t)b0 * a.TpIn;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                int g = m0l + r0 + 32 * p;
+                if (g > a.M - 1) g = a.M - 1;
+                const int b = g / a.TpOut;
+                int t = g - b * a.TpOut;
+                if (t > a.T - 1) t = a.T - 1;
+                rrel[p] = (b - b0) * a.TpIn;
+                tt[p] = t; nd[p] = 0;
+            }
+        }
         rA = make_rsrc(a.X + row0 * a.x_ld, (in_rows - row0) * a.x_ld * sizeof(float));
         if (HAS_X2) rX = make_rsrc(a.X2 + row0 * a.x2_ld, (in_rows - row0) * a.x2_ld * sizeof(float));
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int g = m0l + r0 + 32 * p;
-            if (g > a.M - 1) g = a.M - 1;
-            const int b = g / a.TpOut;
-            int t = g - b * a.TpOut;
-            if (t > a.T - 1) t = a.T - 1;
-            rrel[p] = (b - b0) * a.TpIn;
-            tt[p] = t;
-        }
     };
     auto set_tap = [&](int kk) {          // per-lane offsets of tap kk (reflect / valid row map)
 #pragma unroll
@@ -143,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                 if (qr < 0) qr = -qr;
                 if (qr >= a.Tin) qr = 2 * (a.Tin - 1) - qr;
                 if (qr < 0) qr = 0;
+                if (RT && qr > nd[p]) qr = nd[p];
             } else {
                 qr = tt[p] + kk * a.dil;
                 if (qr > a.Tin - 1) qr = a.Tin - 1;
@@ -159,7 +177,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         if (++l_kk == a.KT) {
             l_kk = 0;
             const int nq = next_sb(l_q);
-            if (nq < sb_end) { l_q = nq; set_tile(l_q); }               // else: stay on the last tile (dummy loads)
+            if (nq < sb_end) {                                           // else: stay on the last tile (dummy loads)
+                l_q = nq; set_tile(l_q);
+                if (RT) { const int nq2 = next_sb(l_q); if (nq2 < sb_end) prefetch_tab(nq2); }
+            }
         }
         set_tap(l_kk);
     };
@@ -243,7 +264,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     };
 
     // prologue: stage step 0 of the first tile
+    if (RT) prefetch_tab(l_q);
     set_tile(l_q);
+    if (RT) { const int nq2 = next_sb(l_q); if (nq2 < sb_end) prefetch_tab(nq2); }
     set_tap(0);
     int m0c = m0l, n0c = n0l;
 #pragma unroll
@@ -322,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                 if (a.scale) { cs_[j] = a.scale[cc]; ch_[j] = a.shift[cc]; }
             }
             const float slope = (a.act1 == 1) ? 0.0f : ((a.act1 == 2) ? 0.01f : 1.0f);
-            const int b0 = m0c / a.TpOut, t0 = m0c - b0 * a.TpOut;      // wave-uniform
+            const int b0 = RT ? 0 : m0c / a.TpOut, t0 = RT ? 0 : m0c - b0 * a.TpOut;      // wave-uniform
             const bool fast_rows = a.TpOut >= BM;
             const bool wide = ((a.Cout | a.y_ld) & 3) == 0 && a.R == nullptr;
             const int lq = lane & 3;
@@ -338,9 +361,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                         for (int e = 0; e < 4; ++e) {
                             const int row = wr * 64 + i * 32 + e + 8 * gq + 4 * lh;
                             int b, t;
-                            if (fast_rows) { t = t0 + row; b = b0; if (t >= a.TpOut) { t -= a.TpOut; b += 1; } }
+                            if (RT) { t = 0; b = 0; if (IB) { const int g = m0c + row; b = ROWTAB_ITEM(a.rowtab[g < a.M ? g : a.M - 1].y); } }
+                            else if (fast_rows) { t = t0 + row; b = b0; if (t >= a.TpOut) { t -= a.TpOut; b += 1; } }
                             else { const int g = m0c + row; b = g / a.TpOut; t = g - b * a.TpOut; }
-                            const bool live = t < a.T;
+                            const bool live = RT || t < a.T;
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
                                 float v = acc[i][j][4 * gq + e] + cb_[j];
@@ -484,7 +508,7 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     if (a.w_ld <= 0) a.w_ld = a.Cin;
     if (a.Cin % BK != 0) SD_FAIL(c, SD_ERR_ARG, "conv_gemm(%s): Cin=%d not a multiple of %d", tag, a.Cin, BK);
     if (a.M <= 0) return SD_OK;
-    if (a.KT == 1 && a.M <= 2048 && a.TpIn == a.M && a.TpOut == a.M && a.T == a.M && a.Tin == a.M && !a.X2 && !a.item_bias && !a.R && !a.mlist &&
+    if (a.KT == 1 && a.M <= 2048 && a.TpIn == a.M && a.TpOut == a.M && a.T == a.M && a.Tin == a.M && !a.X2 && !a.item_bias && !a.R && !a.rowtab &&
         (a.x_ld & 3) == 0 && (a.w_ld & 3) == 0) {
         const int cinr = a.cin_real > 0 ? a.cin_real : a.Cin;
         ProfScope ps(c, c->profile_detail ? std::string("skinny_gemm:") + tag : std::string("skinny_gemm"), 2.0 * a.M * a.Cout * cinr,
@@ -498,8 +522,8 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     a.sched = SD_CONV_SCHED_DEFAULT;
     const int grid = conv_grid(c, a);
     // algorithmic work: valid rows only (T of every TpOut), un-padded input channels
-    const double rows = a.mlist ? a.rows_listed
-                                : (double)(a.M / a.TpOut) * a.T + (double)((a.M % a.TpOut) < a.T ? (a.M % a.TpOut) : a.T);
+    const double rows = a.rowtab ? (double)a.M
+                                 : (double)(a.M / a.TpOut) * a.T + (double)((a.M % a.TpOut) < a.T ? (a.M % a.TpOut) : a.T);
     const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
     const double flops = 2.0 * rows * a.Cout * cin * a.KT;
     const double bytes = 4.0 * (rows * cin * (a.X2 ? 2 : 1) + rows * a.Cout + (double)a.Cout * cin * a.KT);

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void k_stft_mel(
     int64_t first_item, const float* __restrict__ window, const double* __restrict__ twc, const double* __restrict__ twns,
     const float* __restrict__ mel_w, const int* __restrict__ mel_lo, const int* __restrict__ mel_cnt,
     const int* __restrict__ mel_off, int mel_nnz, float* __restrict__ db, float* __restrict__ item_max,
-    const int* __restrict__ alist /* active-item list or null: outputs are indexed by the compact position */)
+    const int* __restrict__ alist /* active-item list or null: outputs are indexed by the compact position */,
+    const int* __restrict__ rowoff /* [slots + 1]: frames at or beyond rowoff[slot + 1] - rowoff[slot] are not needed (ecapa.hip) */)
 {
     __shared__ double tc[400], ts[400];
     __shared__ float sig[SIG_LDS];
@@ -156,6 +157,9 @@ __global__ __launch_bounds__(256) void k_stft_mel(
     __shared__ int mlo[SD_NMELS], mcnt[SD_NMELS], moff[SD_NMELS];
 
     const int slot = blockIdx.y, t0 = blockIdx.x * FT;
+    // frames the network never reads are all-zero signal (every frame with content lies below nvalid + 2): they can neither
+    // raise the item's maximum nor enter the mean, so whole tiles of them are skipped
+    if (t0 >= rowoff[slot + 1] - rowoff[slot]) return;
     const int item = alist ? alist[slot] : slot;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t gitem = first_item + item;
@@ -210,8 +214,9 @@ __global__ __launch_bounds__(256) void k_stft_mel(
 }
 
 // ---------------------------------------------------------------- k_fbank_norm
+// feats: compact rows (see ecapa.hip): item's frame t goes to row rowoff[item] + t, t < rowoff[item + 1] - rowoff[item]
 __global__ __launch_bounds__(256) void k_fbank_norm(const float* __restrict__ db, const float* __restrict__ item_max,
-                                                    const int* __restrict__ nnorm, float* __restrict__ feats)
+                                                    const int* __restrict__ nnorm, const int* __restrict__ rowoff, float* __restrict__ feats)
 {
     __shared__ float part[3][SD_NMELS];
     __shared__ float mean[SD_NMELS];
@@ -228,11 +233,12 @@ __global__ __launch_bounds__(256) void k_fbank_norm(const float* __restrict__ db
     __syncthreads();
     if (tid < SD_NMELS) mean[tid] = (part[0][tid] + part[1][tid] + part[2][tid]) / (float)nn;
     __syncthreads();
-    float* dst = feats + (size_t)item * SD_TP * SD_FEAT_LD;
-    for (int idx = tid; idx < SD_TP * SD_FEAT_LD; idx += 256) {
+    const int r0 = rowoff[item], need = rowoff[item + 1] - r0;
+    float* dst = feats + (size_t)r0 * SD_FEAT_LD;
+    for (int idx = tid; idx < need * SD_FEAT_LD; idx += 256) {
         const int t = idx / SD_FEAT_LD, c = idx - t * SD_FEAT_LD;
         float v = 0.0f;
-        if (t < SD_T && c < SD_NMELS) v = fmaxf(src[t * SD_NMELS + c], floor_db) - mean[c];
+        if (c < SD_NMELS) v = fmaxf(src[t * SD_NMELS + c], floor_db) - mean[c];
         dst[idx] = v;
     }
 }
@@ -275,11 +281,11 @@ __global__ void k_fill_f32(float* p, float v, int64_t n)
     if (i < n) p[i] = v;
 }
 
-// compact = true: only items whose embedding is not NaN by rule are processed; feats / nvalid_c are indexed by the
-// compact position, *h_n_active receives their number, d_cidx[item] = compact position or -1.
-int run_frontend(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item,
-                 float* d_feats, float* d_wav_lens, int* d_nnorm, int* d_nvalid, int* d_flags,
-                 bool compact, int* h_n_active, int* d_cidx)
+// Phase A: mask prefix tables, wav_lens / nnorm / nvalid / too-short flags.  compact = true: items whose embedding is NaN by
+// rule are dropped -- *h_n_active receives the number of live items, d_nnorm / d_nvalid are indexed by the compact position,
+// d_cidx[item] = compact position or -1.  The prefix tables, sample counts and the active list stay in workspaces for phase B.
+int frontend_prepare(sd_ctx* c, const float* d_masks, int64_t items, int64_t first_item, float* d_wav_lens, int* d_nnorm, int* d_nvalid,
+                     int* d_flags, bool compact, int* h_n_active, int* d_cidx)
 {
     if (!c->ew.loaded) SD_FAIL(c, SD_ERR_MODEL, "embedding model not loaded");
     if (h_n_active) *h_n_active = (int)items;
@@ -288,46 +294,53 @@ int run_frontend(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks,
     if (c->ew.mel_nnz > MEL_MAX_NNZ) SD_FAIL(c, SD_ERR_MODEL, "mel filterbank too dense (%d non-zeros)", c->ew.mel_nnz);
     WS(c, int, d_prefix, "fe_prefix", items * 296);
     WS(c, int, d_counts, "fe_counts", items);
-    WS(c, float, d_db, "fe_db", items * SD_T * SD_NMELS);
-    WS(c, float, d_max, "fe_max", items);
-    const EcapaWeights& E = c->ew;
     hipLaunchKernelGGL(k_mask_prefix, dim3((unsigned)items), dim3(512), 0, c->stream, d_masks, d_prefix, d_counts, (int)items);
     KCHECK(c);
-    int* nnorm_all = d_nnorm; int* nvalid_all = d_nvalid;
-    int* alist = nullptr;
-    int64_t run_items = items;
     if (compact) {
         WS(c, int, t_nnorm, "fe_nnorm_all", items);
         WS(c, int, t_nvalid, "fe_nvalid_all", items);
         WS(c, int, t_alist, "fe_alist", items);
         WS(c, int, t_nact, "fe_nact", 4);
-        nnorm_all = t_nnorm; nvalid_all = t_nvalid; alist = t_alist;
-        hipLaunchKernelGGL(k_wav_lens, dim3((unsigned)((items + 31) / 32)), dim3(64), 0, c->stream, d_counts, (int)items, d_wav_lens, nnorm_all, nvalid_all, d_flags);
+        hipLaunchKernelGGL(k_wav_lens, dim3((unsigned)((items + 31) / 32)), dim3(64), 0, c->stream, d_counts, (int)items, d_wav_lens, t_nnorm, t_nvalid, d_flags);
         KCHECK(c);
-        hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, c->stream, d_flags, (int)items, alist, d_cidx, nnorm_all, nvalid_all, d_nnorm, d_nvalid, t_nact);
+        hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, c->stream, d_flags, (int)items, t_alist, d_cidx, t_nnorm, t_nvalid, d_nnorm, d_nvalid, t_nact);
         KCHECK(c);
         int na = 0;
         HIPCHK(c, hipMemcpyAsync(&na, t_nact, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        run_items = na;
         if (h_n_active) *h_n_active = na;
-        if (na == 0) return SD_OK;
     } else {
         hipLaunchKernelGGL(k_wav_lens, dim3((unsigned)((items + 31) / 32)), dim3(64), 0, c->stream, d_counts, (int)items, d_wav_lens, d_nnorm, d_nvalid, d_flags);
         KCHECK(c);
     }
+    return SD_OK;
+}
+
+// Phase B: compaction gather + STFT + mel + dB, then top-dB clamp and mean normalisation into the compact feature rows
+// d_feats [rowoff[run_items]][96] (item's frame t at row d_rowoff[item] + t; frames beyond an item's rows are not computed).
+int frontend_features(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_item, int64_t run_items, bool compact, const int* d_nnorm,
+                      const int* d_rowoff, float* d_feats)
+{
+    if (run_items <= 0) return SD_OK;
+    const EcapaWeights& E = c->ew;
+    const int* d_prefix = c->ws["fe_prefix"].as<int>();
+    const int* d_counts = c->ws["fe_counts"].as<int>();
+    const int* alist = compact ? c->ws["fe_alist"].as<int>() : nullptr;
+    if (!d_prefix || !d_counts || (compact && !alist)) SD_FAIL(c, SD_ERR_ARG, "frontend_features before frontend_prepare");
+    WS(c, float, d_db, "fe_db", run_items * SD_T * SD_NMELS);
+    WS(c, float, d_max, "fe_max", run_items);
     hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((run_items + 255) / 256)), dim3(256), 0, c->stream, d_max, -INFINITY, run_items);
     KCHECK(c);
     {
         // algorithmic bytes per item: 80000*4 + 293*4 read, 501*80*4 written
         ProfScope ps(c, "stft_mel", (double)run_items * (SD_TP * 208.0 * 204 * 2 * 2 + SD_T * 201.0 * 80 * 2), (double)run_items * (321172.0 + 160320.0));
         hipLaunchKernelGGL(k_stft_mel, dim3((SD_T + FT - 1) / FT, (unsigned)run_items), dim3(256), 0, c->stream, d_wav, n, d_prefix, d_counts,
-                           first_item, E.window, E.tw_cos, E.tw_nsin, E.mel_w, E.mel_lo, E.mel_cnt, E.mel_off, E.mel_nnz, d_db, d_max, alist);
+                           first_item, E.window, E.tw_cos, E.tw_nsin, E.mel_w, E.mel_lo, E.mel_cnt, E.mel_off, E.mel_nnz, d_db, d_max, alist, d_rowoff);
         KCHECK(c);
     }
     {
         ProfScope ps(c, "fbank_norm", 0, (double)run_items * (160320.0 + SD_TP * SD_FEAT_LD * 4.0));
-        hipLaunchKernelGGL(k_fbank_norm, dim3((unsigned)run_items), dim3(256), 0, c->stream, d_db, d_max, d_nnorm, d_feats);
+        hipLaunchKernelGGL(k_fbank_norm, dim3((unsigned)run_items), dim3(256), 0, c->stream, d_db, d_max, d_nnorm, d_rowoff, d_feats);
         KCHECK(c);
     }
     return SD_OK;
