@@ -243,6 +243,171 @@ __global__ __launch_bounds__(256) void k_fbank_norm(const float* __restrict__ db
     }
 }
 
+// ---------------------------------------------------------------- k_stft_fbank : the whole front end of one item in one workgroup
+// gather (inverse of the reference's stream compaction) -> fp64 STFT as a mixed-radix FFT -> power -> mel -> dB, then -- same
+// workgroup, second phase -- top-dB clamp with the item's maximum, mean over the first nnorm frames, compact feature rows.
+//
+// 400-point real DFT of a windowed frame, 400 = 16 x 25 (decimation in time over the residue r = n mod 16):
+//   Y_r[k1]      = sum_{m<25} xw[16 m + r] W25^{m k1}              k1 = 0..12   (real input: Y_r[25-k1] = conj Y_r[k1])
+//   X[k1+25 k2]  = sum_{r<16} (W400^{r k1} Y_r[k1]) W16^{r k2}      k2 = 0..15
+// For k1 = 1..12 the 16 outputs are the bins k1 + 25 k2 (k2 <= 7) and, conjugated, 400 - (k1 + 25 k2) (k2 >= 8); k1 = 0 gives the
+// bins 25 k2, k2 <= 8: all 201 bins, each once.  ~15 kFLOP per frame instead of 170 kFLOP for the DFT-as-GEMM it replaces.
+//   stage A: lane = (frame f of 4, residue r): 25 samples from LDS (consecutive lanes = consecutive samples), window in fp64,
+//            straight-line 25-point real DFT (300 FMAs), twiddle, 13 complex values to LDS
+//   stage B: lane = (frame f of 4, k1 of 13): 16 complex values from LDS, radix-4 x 4 FFT in registers, power (f32, as the
+//            reference casts the STFT to f32 before the ONNX graph squares it) to LDS
+// 16 frames per tile (4 per wave).  One persistent workgroup walks the tiles of an item, then the items blockIdx.x, + gridDim.x, ...
+// The dB values of the item in flight go to a per-workgroup scratch (160 KB, re-used item after item: it stays in L2 / the
+// Infinity Cache and is never re-read by another kernel).
+#include "dft25_gen.h"
+#define SIGP 3072                          // padded LDS signal: sample s of the tile sits at s + 16 (s / 160)
+#define MEL_LDS_NNZ 512
+#define YK 17                              // stage A -> B exchange: Y[frame][k1][r], k1 stride padded to 17 complex (bank spread)
+__global__ __launch_bounds__(256, 2) void k_stft_fbank(
+    const float* __restrict__ wav, int64_t n, const int* __restrict__ prefix, const int* __restrict__ counts, int64_t first_item,
+    const float* __restrict__ window, const double* __restrict__ twc, const double* __restrict__ twns,
+    const float* __restrict__ mel_w, const int* __restrict__ mel_lo, const int* __restrict__ mel_cnt, const int* __restrict__ mel_off,
+    int mel_nnz, const int* __restrict__ alist, const int* __restrict__ rowoff, const int* __restrict__ nnorm, int run_items,
+    float* __restrict__ scratch /*[gridDim.x][501][80]*/, float* __restrict__ feats)
+{
+    __shared__ __attribute__((aligned(16))) double2 Y[16 * 13 * YK];
+    __shared__ __attribute__((aligned(16))) float sigpw[16 * PW_LD > SIGP ? 16 * PW_LD : SIGP];    // signal tile, then the power spectra of the tile
+    __shared__ int pre[296];
+    __shared__ int mlo[SD_NMELS], mcnt[SD_NMELS], moff[SD_NMELS];
+    __shared__ float part[3][SD_NMELS], mean[SD_NMELS];
+    __shared__ float s_wmax[4];
+    __shared__ float win[400];
+    __shared__ float mw[MEL_LDS_NNZ];                          // mel weights (402 non-zeros for the 80 x 201 triangular bank)
+    float* const sig = sigpw;
+    float* const pw = sigpw;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < SD_NMELS) { mlo[tid] = mel_lo[tid]; mcnt[tid] = mel_cnt[tid]; moff[tid] = mel_off[tid]; }
+    for (int k = tid; k < mel_nnz && k < MEL_LDS_NNZ; k += 256) mw[k] = mel_w[k];
+    const bool mel_lds = mel_nnz <= MEL_LDS_NNZ;
+    // per-lane constants of stage A: the window at this lane's 25 samples and the twiddles W400^(r k1)
+    const int fA = lane >> 4, r = lane & 15;
+    for (int k = tid; k < 400; k += 256) win[k] = window[k];
+    double tcr[13], tsr[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) { const int j = (r * k) % 400; tcr[k] = twc[j]; tsr[k] = twns[j]; }
+    const int fB = lane / 13, k1 = lane - 13 * fB;                 // stage B role (lanes 52..63 idle)
+    float* const db = scratch + (size_t)blockIdx.x * SD_T * SD_NMELS;
+
+    for (int slot = blockIdx.x; slot < run_items; slot += gridDim.x) {
+        const int item = alist ? alist[slot] : slot;
+        const int64_t gitem = first_item + item;
+        const int64_t chunk_start = (gitem / SD_SPEAKERS) * (int64_t)SD_HOP;     // crop(), sd.cpp:1643
+        const int cnt = counts[item];
+        const int row0 = rowoff[slot], need = rowoff[slot + 1] - row0;
+        __syncthreads();                                       // previous item's phase 2 is done with pre / mean / db
+        for (int k = tid; k < 296; k += 256) pre[k] = prefix[(size_t)item * 296 + k];
+        float vmax = -INFINITY;
+        for (int t0 = 0; t0 < need; t0 += 16) {
+            __syncthreads();                                   // pre is loaded; the previous tile's mel pass is done with pw
+            // ---- gather the compacted samples [160 t0 - 200, +2800): each thread a run of 11 consecutive ones
+            {
+                const int mstart = 160 * t0 - 200;
+                const int s0 = tid * 11;
+                int f = -1, fend = 0, fbeg = 0, fsrc = 0;     // current mask frame: compacted range [fbeg, fend), first source sample
+                int src[11];                                  // source sample relative to the chunk start, -1 = zero
+                const int64_t room = n - chunk_start;
+#pragma unroll
+                for (int q = 0; q < 11; ++q) {                // addresses first ...
+                    const int m = mstart + s0 + q;
+                    src[q] = -1;
+                    if (s0 + q < 2800 && m >= 0 && m < cnt) {
+                        if (f < 0 || m >= fend) {             // smallest f with pre[f+1] > m (binary search once per run, then walk)
+                            int lo = 0, hi = SD_FRAMES - 1;
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pre[mid + 1] > m) hi = mid; else lo = mid + 1; }
+                            f = lo; fbeg = pre[f]; fend = pre[f + 1]; fsrc = frame_start(f);
+                        }
+                        const int sp = fsrc + (m - fbeg);
+                        if ((int64_t)sp < room) src[q] = sp;
+                    }
+                }
+                float v[11];
+#pragma unroll
+                for (int q = 0; q < 11; ++q) v[q] = src[q] >= 0 ? wav[chunk_start + src[q]] : 0.0f;      // ... then all loads in flight together
+#pragma unroll
+                for (int q = 0; q < 11; ++q) { const int sidx = s0 + q; if (sidx < 2800) sig[sidx + 16 * (sidx / 160)] = v[q]; }
+            }
+            __syncthreads();
+            // ---- stage A
+            const int flA = 4 * w + fA;
+            if (t0 + 4 * w < SD_T) {
+                double x[25], yr[13], yi[13];
+                const float* sp = sig + 176 * flA + r;
+#pragma unroll
+                for (int m = 0; m < 25; ++m) x[m] = (double)sp[16 * m + 16 * (m / 10)] * (double)win[16 * m + r];
+                dft25_real(x, yr, yi);
+                double2* yo = Y + (size_t)flA * 13 * YK + r;
+#pragma unroll
+                for (int k = 0; k < 13; ++k) yo[k * YK] = make_double2(yr[k] * tcr[k] - yi[k] * tsr[k], yr[k] * tsr[k] + yi[k] * tcr[k]);
+            }
+            __syncthreads();
+            // ---- stage B (pw aliases sig: every wave is past its stage A reads)
+            if (lane < 52 && t0 + 4 * w < SD_T) {
+                const int flB = 4 * w + fB;
+                double vr[16], vi[16];
+                const double2* yi_ = Y + ((size_t)flB * 13 + k1) * YK;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { const double2 v = yi_[q]; vr[q] = v.x; vi[q] = v.y; }
+                fft16(vr, vi);
+                float* po = pw + flB * PW_LD;
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) {
+                    if (k1 == 0 && k2 > 8) continue;
+                    const int k = k1 + 25 * k2;
+                    const float fr = (float)vr[k2], fi = (float)vi[k2];            // STFT cast to f32 (sd.cpp:2031)
+                    po[k <= 200 ? k : 400 - k] = __fadd_rn(__fmul_rn(fr, fr), __fmul_rn(fi, fi));
+                }
+            }
+            __syncthreads();
+            // ---- mel filterbank + dB for the tile's frames
+            for (int o = tid; o < 16 * SD_NMELS; o += 256) {
+                const int fr = o / SD_NMELS, m = o - fr * SD_NMELS;
+                const int t = t0 + fr;
+                if (t >= SD_T) continue;
+                const float* pp = &pw[fr * PW_LD + mlo[m]];
+                float acc = 0.0f;
+                const int c = mcnt[m];
+                if (mel_lds) { const float* qq = &mw[moff[m]]; for (int b = 0; b < c; ++b) acc = fmaf(pp[b], qq[b], acc); }
+                else { const float* qq = &mel_w[moff[m]]; for (int b = 0; b < c; ++b) acc = fmaf(pp[b], qq[b], acc); }
+                const float v = 10.0f * log10f(fmaxf(acc, 1e-10f));
+                db[(size_t)t * SD_NMELS + m] = v;
+                vmax = fmaxf(vmax, v);
+            }
+        }
+        // ---- phase 2: the item's maximum (frames beyond `need` are all-zero signal: -100 dB, never the maximum), clamp, mean, write
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0) s_wmax[w] = vmax;
+        __syncthreads();
+        const float floor_db = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3])) - 80.0f;       // top_db = 80
+        const int nn = nnorm[slot];
+        if (tid < 240) {
+            const int c = tid % SD_NMELS, g = tid / SD_NMELS;
+            float sum = 0.0f;
+            int t = g;
+            for (; t + 9 < nn; t += 12) {                       // 4 loads in flight; the sum keeps its order
+                const float v0 = db[(size_t)t * SD_NMELS + c], v1 = db[(size_t)(t + 3) * SD_NMELS + c], v2 = db[(size_t)(t + 6) * SD_NMELS + c], v3 = db[(size_t)(t + 9) * SD_NMELS + c];
+                sum += fmaxf(v0, floor_db); sum += fmaxf(v1, floor_db); sum += fmaxf(v2, floor_db); sum += fmaxf(v3, floor_db);
+            }
+            for (; t < nn; t += 3) sum += fmaxf(db[(size_t)t * SD_NMELS + c], floor_db);
+            part[g][c] = sum;
+        }
+        __syncthreads();
+        if (tid < SD_NMELS) mean[tid] = (part[0][tid] + part[1][tid] + part[2][tid]) / (float)nn;
+        __syncthreads();
+        float* dst = feats + (size_t)row0 * SD_FEAT_LD;
+        for (int idx = tid; idx < need * SD_FEAT_LD; idx += 256) {
+            const int t = idx / SD_FEAT_LD, c = idx - t * SD_FEAT_LD;
+            float v = 0.0f;
+            if (c < SD_NMELS) v = fmaxf(db[(size_t)t * SD_NMELS + c], floor_db) - mean[c];
+            dst[idx] = v;
+        }
+    }
+}
+
 // items whose output row is NaN anyway (too short / whole batch too short, sd.cpp:2479-2549) are dropped
 // before the STFT and the network: alist[a] = item, cidx[item] = a or -1, compacted nnorm / nvalid
 __global__ __launch_bounds__(1024) void k_compact_active(const int* __restrict__ flags, int items, int* __restrict__ alist, int* __restrict__ cidx,
@@ -327,20 +492,14 @@ int frontend_features(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_it
     const int* d_counts = c->ws["fe_counts"].as<int>();
     const int* alist = compact ? c->ws["fe_alist"].as<int>() : nullptr;
     if (!d_prefix || !d_counts || (compact && !alist)) SD_FAIL(c, SD_ERR_ARG, "frontend_features before frontend_prepare");
-    WS(c, float, d_db, "fe_db", run_items * SD_T * SD_NMELS);
-    WS(c, float, d_max, "fe_max", run_items);
-    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((run_items + 255) / 256)), dim3(256), 0, c->stream, d_max, -INFINITY, run_items);
-    KCHECK(c);
+    int grid = 2 * c->num_cu;
+    if (grid > run_items) grid = (int)run_items;
+    WS(c, float, d_scratch, "fe_db", (size_t)grid * SD_T * SD_NMELS);
     {
-        // algorithmic bytes per item: 80000*4 + 293*4 read, 501*80*4 written
-        ProfScope ps(c, "stft_mel", (double)run_items * (SD_TP * 208.0 * 204 * 2 * 2 + SD_T * 201.0 * 80 * 2), (double)run_items * (321172.0 + 160320.0));
-        hipLaunchKernelGGL(k_stft_mel, dim3((SD_T + FT - 1) / FT, (unsigned)run_items), dim3(256), 0, c->stream, d_wav, n, d_prefix, d_counts,
-                           first_item, E.window, E.tw_cos, E.tw_nsin, E.mel_w, E.mel_lo, E.mel_cnt, E.mel_off, E.mel_nnz, d_db, d_max, alist, d_rowoff);
-        KCHECK(c);
-    }
-    {
-        ProfScope ps(c, "fbank_norm", 0, (double)run_items * (160320.0 + SD_TP * SD_FEAT_LD * 4.0));
-        hipLaunchKernelGGL(k_fbank_norm, dim3((unsigned)run_items), dim3(256), 0, c->stream, d_db, d_max, d_nnorm, d_rowoff, d_feats);
+        // algorithmic bytes per item: 80000*4 + 293*4 read, 501*80*4 written; ~15 kFLOP fp64 per frame (FFT) + 16 kFLOP mel
+        ProfScope ps(c, "stft_mel", (double)run_items * SD_T * (15000.0 + 201.0 * 80 * 2), (double)run_items * (321172.0 + 160320.0));
+        hipLaunchKernelGGL(k_stft_fbank, dim3(grid), dim3(256), 0, c->stream, d_wav, n, d_prefix, d_counts, first_item, E.window, E.tw_cos, E.tw_nsin,
+                           E.mel_w, E.mel_lo, E.mel_cnt, E.mel_off, E.mel_nnz, alist, d_rowoff, d_nnorm, (int)run_items, d_scratch, d_feats);
         KCHECK(c);
     }
     return SD_OK;
