@@ -39,6 +39,7 @@ struct ConvLayer {
     float* scale = nullptr;   // folded BatchNorm (applied after act1) or null
     float* shift = nullptr;
     int Cin = 0, CinPad = 0, Cout = 0, KT = 1, dil = 1;
+    int CinPad16 = 0;         // row length of W16 (multiple of 64)
 };
 
 struct ConvArgs {
@@ -62,6 +63,7 @@ struct ConvArgs {
     // Input and output share the row space (TpIn / TpOut / T unused); a tap that reaches beyond the item's last stored frame
     // reads that last frame instead (it can only feed frames that are themselves beyond nvalid).  null = dense mapping.
     const int2* rowtab;
+    int prec;              // 0 = f32 (X, X2, W, Y are float), 1 = fp16 end to end (X, X2, W16, Y are _Float16; option ecapa_precision)
 };
 #define ROWTAB_T(y) ((y) & 1023)
 #define ROWTAB_LAST(y) (((y) >> 10) & 1023)

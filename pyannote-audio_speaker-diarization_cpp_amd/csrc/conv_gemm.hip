@@ -40,13 +40,13 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte a
 
 // DBG (micro-benchmark ablations only, never used by the pipeline): 1 = no epilogue stores,
 // 2 = no global loads inside the K loop, 3 = no LDS restaging / barrier inside the K loop
-// F16 (BASELINE.json configs[4], option "ecapa_precision" = 1): the same kernel with v_mfma_f32_32x32x16_f16 -- weights
-// come from an fp16 copy, activations stay f32 in HBM and are rounded to fp16 (RNE) on their way into LDS, accumulation
-// and the whole epilogue stay f32.  16x less MFMA time per K-step: that variant is bound by the load / LDS path.
+// F16 (BASELINE.json configs[4], option "ecapa_precision" = 1): fp16 end to end.  X, X2, W16 and Y hold _Float16 (leading
+// dimensions in elements), a K-step is 64 halves -- the same 128 bytes per row as 32 floats, so the load stream, the LDS tile
+// (144-byte rows) and the K-step pipeline are byte for byte the f32 ones -- and the MFMA is v_mfma_f32_32x32x16_f16 (f32
+// accumulation, f32 epilogue arithmetic, one rounding to fp16 at the store).  16x less MFMA time per K-step than f32.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#define LDH 40            // fp16 LDS row: 32 halves + 8 pad = 80 B (ds_read_b128 of 8 consecutive rows hits 8 distinct 4-bank groups)
 template <bool HAS_X2, int DBG, bool F16>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 {
@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     const int c4 = tid & 7, r0 = tid >> 3;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int kcs = a.Cin / BK;
+    constexpr int ES = F16 ? 2 : 4;     // bytes per element of X / X2 / W / Y
+    constexpr int BKE = 128 / ES;       // elements per K-step: 128 bytes per row either way
+    const int kcs = a.Cin / BKE;
     const int S = a.KT * kcs;
     const int half = a.KT / 2;
 
@@ -108,14 +110,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 #pragma unroll
         for (int p = 0; p < 4; ++p) { int g = m0 + r0 + 32 * p; if (g > a.M - 1) g = a.M - 1; pre[p] = a.rowtab[g]; }
     };
-    auto make_rsrc = [&](const float* base, size_t bytes) {
+    auto make_rsrc = [&](const void* base, size_t bytes) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
     };
     __amdgpu_buffer_rsrc_t rA = make_rsrc(a.X, 0), rX = make_rsrc(a.X, 0);
-    constexpr int WB = F16 ? 2 : 4;     // bytes per weight element
-    const __amdgpu_buffer_rsrc_t rB = make_rsrc(F16 ? (const float*)a.W16 : a.W, (size_t)a.KT * a.Cout * a.w_ld * WB);
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(F16 ? a.W16 : (const void*)a.W, (size_t)a.KT * a.Cout * a.w_ld * ES);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)(((r0 + 32 * p) * a.w_ld + c4 * 4) * WB);
+    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)((r0 + 32 * p) * a.w_ld * ES + c4 * 16);
     int l_q = q0, l_kk = 0, l_kc = 0, m0l = 0, n0l = 0;
     // K always runs 0 .. Cin-1 in the same order for every tile: a row's result does not depend on where its tile sits
     // in the schedule (sharded and unsharded runs, full and dead-row-skipping runs stay bit-identical).  [Tried and
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                 tt[p] = t; nd[p] = 0;
             }
         }
-        rA = make_rsrc(a.X + row0 * a.x_ld, (in_rows - row0) * a.x_ld * sizeof(float));
-        if (HAS_X2) rX = make_rsrc(a.X2 + row0 * a.x2_ld, (in_rows - row0) * a.x2_ld * sizeof(float));
+        rA = make_rsrc((const char*)a.X + row0 * a.x_ld * ES, (in_rows - row0) * a.x_ld * ES);
+        if (HAS_X2) rX = make_rsrc((const char*)a.X2 + row0 * a.x2_ld * ES, (in_rows - row0) * a.x2_ld * ES);
     };
     auto set_tap = [&](int kk) {          // per-lane offsets of tap kk (reflect / valid row map)
 #pragma unroll
@@ -166,13 +167,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                 if (qr > a.Tin - 1) qr = a.Tin - 1;
             }
             const unsigned row = (unsigned)(rrel[p] + qr);
-            voA[p] = (row * (unsigned)a.x_ld + c4 * 4) * (unsigned)sizeof(float);
-            if (HAS_X2) voX[p] = (row * (unsigned)a.x2_ld + c4 * 4) * (unsigned)sizeof(float);
+            voA[p] = row * (unsigned)a.x_ld * ES + c4 * 16;
+            if (HAS_X2) voX[p] = row * (unsigned)a.x2_ld * ES + c4 * 16;
         }
-        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * WB);
+        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * ES);
     };
     auto advance = [&]() {                // move the load stream to the next K-step
-        if (++l_kc < kcs) { sK += BK * sizeof(float); return; }
+        if (++l_kc < kcs) { sK += 128; return; }
         l_kc = 0; sK = 0;
         if (++l_kk == a.KT) {
             l_kk = 0;
@@ -185,32 +186,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         set_tap(l_kk);
     };
 
-    f4u ra[4], rb[F16 ? 1 : 4], rx[HAS_X2 ? 4 : 1];
-    u32x2 rbh[F16 ? 4 : 1];
+    f4u ra[4], rb[4], rx[HAS_X2 ? 4 : 1];
     auto gload_part = [&](int p) {
         ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p], sK, 0));
         if (HAS_X2) rx[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rX, voX[p], sK, 0));
-        if constexpr (F16) rbh[p] = __builtin_amdgcn_raw_buffer_load_b64(rB, voB[p], sB + (sK >> 1), 0);
-        else rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sB + sK, 0));
+        rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sB + sK, 0));
     };
-    _Float16* const Ah = (_Float16*)&As[0][0];       // fp16 view of the same LDS: 2 buffers of BM x LDH halves each
-    _Float16* const Bh = (_Float16*)&Bs[0][0];
     auto lstore = [&](int buf) {
-        if constexpr (F16) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (HAS_X2) ra[p] += rx[p];
-                const half4 h = {(_Float16)ra[p][0], (_Float16)ra[p][1], (_Float16)ra[p][2], (_Float16)ra[p][3]};
-                *(half4*)&Ah[buf * BM * LDH + (r0 + 32 * p) * LDH + c4 * 4] = h;
-                *(u32x2*)&Bh[buf * BN * LDH + (r0 + 32 * p) * LDH + c4 * 4] = rbh[p];
+        for (int p = 0; p < 4; ++p) {
+            if (HAS_X2) {                            // the add waits for the loads: keep it next to the LDS store
+                if constexpr (F16) ra[p] = __builtin_bit_cast(f4u, __builtin_bit_cast(half8, ra[p]) + __builtin_bit_cast(half8, rx[p]));
+                else ra[p] += rx[p];
             }
-        } else {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (HAS_X2) ra[p] += rx[p];          // the add waits for the loads: keep it next to the LDS store
-                *(float4*)&As[buf][(r0 + 32 * p) * LDP + c4 * 4] = make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]);
-                *(float4*)&Bs[buf][(r0 + 32 * p) * LDP + c4 * 4] = make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]);
-            }
+            *(float4*)&As[buf][(r0 + 32 * p) * LDP + c4 * 4] = make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]);
+            *(float4*)&Bs[buf][(r0 + 32 * p) * LDP + c4 * 4] = make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]);
         }
     };
 
@@ -248,19 +238,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         }
     };
 
-    // fp16 variant of one K-step: 2 k-blocks of 16, 8 MFMAs; lane (li, lh) holds k = 16 kb + 8 lh .. +7 of row li
-    auto step16 = [&](int buf) {
-        const _Float16* Ab = Ah + buf * BM * LDH + (wr * 64 + li) * LDH + lh * 8;
-        const _Float16* Bb = Bh + buf * BN * LDH + (wc * 64 + li) * LDH + lh * 8;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const half8 a0 = *(const half8*)(Ab + kb * 16), a1 = *(const half8*)(Ab + 32 * LDH + kb * 16);
-            const half8 b0 = *(const half8*)(Bb + kb * 16), b1 = *(const half8*)(Bb + 32 * LDH + kb * 16);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
-        }
+    // fp16: one K-step = 4 k-blocks of 16 halves, 16 MFMAs; lane (li, lh) holds k = 16 kb + 8 lh .. +7 of row li.
+    // LDS rows are the f32 tile's 144-byte rows (LDP floats): 64 halves + 8 halves of padding.
+    half8 ha[2][2], hb[2][2];
+    auto hfrag = [&](int buf, int kb, int fbuf) {
+        const float* Ab = &As[buf][(wr * 64 + li) * LDP + lh * 4 + kb * 8];
+        const float* Bb = &Bs[buf][(wc * 64 + li) * LDP + lh * 4 + kb * 8];
+        ha[fbuf][0] = __builtin_bit_cast(half8, *(const float4*)Ab);
+        ha[fbuf][1] = __builtin_bit_cast(half8, *(const float4*)(Ab + 32 * LDP));
+        hb[fbuf][0] = __builtin_bit_cast(half8, *(const float4*)Bb);
+        hb[fbuf][1] = __builtin_bit_cast(half8, *(const float4*)(Bb + 32 * LDP));
+    };
+    auto hmma = [&](int fbuf) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fbuf][0], hb[fbuf][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fbuf][0], hb[fbuf][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fbuf][1], hb[fbuf][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fbuf][1], hb[fbuf][1], acc[1][1], 0, 0, 0);
     };
 
     // prologue: stage step 0 of the first tile
@@ -274,16 +267,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     lstore(0);
     __syncthreads();
     advance();
-    if constexpr (!F16) lfrag(0, 0, 0);
+    if constexpr (F16) hfrag(0, 0, 0); else lfrag(0, 0, 0);
 
     int q = q0, s = 0, buf = 0;
     while (true) {
         const int cb = (DBG == 3) ? 0 : buf;
         if constexpr (F16) {
+            // same shape as the f32 step: fragments of k-block kb+1 are read while the MFMAs of kb run, the next step's
+            // global loads are issued early, restaged to the other LDS buffer during k-block 2, one barrier per step
+            hfrag(buf, 1, 1);
             gload_part(0); gload_part(1); gload_part(2); gload_part(3);
-            step16(buf);
+            hmma(0);
+            __builtin_amdgcn_sched_barrier(0);
+            hfrag(buf, 2, 0);
+            hmma(1);
+            __builtin_amdgcn_sched_barrier(0);
+            hfrag(buf, 3, 1);
+            hmma(0);
             lstore(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
+            hfrag(buf ^ 1, 0, 0);
+            hmma(1);
+            __builtin_amdgcn_sched_barrier(0);
         } else {
         // one K step.  On entry fragment set 0 holds K-group 0 of this step.  Inside each scheduling region the
         // memory instructions are interleaved one by one with the MFMAs (sched_group_barrier: 0x008 MFMA, 0x020 VMEM
@@ -395,7 +401,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                                 const int co = n0c + wc * 64 + j * 32 + (li & ~3);
                                 if (g < a.M && co < a.Cout) {
                                     if (DBG == 1) { if (x[j][0] == 12345.678f) a.Y[0] = x[j][1]; }
-                                    else *(float4*)(a.Y + (size_t)g * a.y_ld + co) = make_float4(x[j][0], x[j][1], x[j][2], x[j][3]);
+                                    else if constexpr (F16) {
+                                        const half4 hv = {(_Float16)x[j][0], (_Float16)x[j][1], (_Float16)x[j][2], (_Float16)x[j][3]};
+                                        *(half4*)((_Float16*)a.Y + (size_t)g * a.y_ld + co) = hv;
+                                    } else *(float4*)(a.Y + (size_t)g * a.y_ld + co) = make_float4(x[j][0], x[j][1], x[j][2], x[j][3]);
                                 }
                             }
                         } else {
@@ -407,7 +416,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                                     if (g >= a.M || cco[j] >= a.Cout) continue;
                                     float v = x[j][e];
                                     if (a.R) v += a.R[(size_t)g * a.r_ld + cco[j]];
-                                    a.Y[(size_t)g * a.y_ld + cco[j]] = v;
+                                    if constexpr (F16) ((_Float16*)a.Y)[(size_t)g * a.y_ld + cco[j]] = (_Float16)v;
+                                    else a.Y[(size_t)g * a.y_ld + cco[j]] = v;
                                 }
                             }
                         }
@@ -506,9 +516,11 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
 {
     ConvArgs a = in;
     if (a.w_ld <= 0) a.w_ld = a.Cin;
-    if (a.Cin % BK != 0) SD_FAIL(c, SD_ERR_ARG, "conv_gemm(%s): Cin=%d not a multiple of %d", tag, a.Cin, BK);
+    const bool f16 = a.prec == 1;
+    if (f16 && !a.W16) SD_FAIL(c, SD_ERR_ARG, "conv_gemm(%s): fp16 mode without fp16 weights", tag);
+    if (a.Cin % (f16 ? 64 : BK) != 0) SD_FAIL(c, SD_ERR_ARG, "conv_gemm(%s): Cin=%d not a multiple of %d", tag, a.Cin, f16 ? 64 : BK);
     if (a.M <= 0) return SD_OK;
-    if (a.KT == 1 && a.M <= 2048 && a.TpIn == a.M && a.TpOut == a.M && a.T == a.M && a.Tin == a.M && !a.X2 && !a.item_bias && !a.R && !a.rowtab &&
+    if (a.prec == 0 && a.KT == 1 && a.M <= 2048 && a.TpIn == a.M && a.TpOut == a.M && a.T == a.M && a.Tin == a.M && !a.X2 && !a.item_bias && !a.R && !a.rowtab &&
         (a.x_ld & 3) == 0 && (a.w_ld & 3) == 0) {
         const int cinr = a.cin_real > 0 ? a.cin_real : a.Cin;
         ProfScope ps(c, c->profile_detail ? std::string("skinny_gemm:") + tag : std::string("skinny_gemm"), 2.0 * a.M * a.Cout * cinr,
@@ -526,9 +538,8 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
                                  : (double)(a.M / a.TpOut) * a.T + (double)((a.M % a.TpOut) < a.T ? (a.M % a.TpOut) : a.T);
     const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
     const double flops = 2.0 * rows * a.Cout * cin * a.KT;
-    const double bytes = 4.0 * (rows * cin * (a.X2 ? 2 : 1) + rows * a.Cout + (double)a.Cout * cin * a.KT);
+    const double bytes = (f16 ? 2.0 : 4.0) * (rows * cin * (a.X2 ? 2 : 1) + rows * a.Cout + (double)a.Cout * cin * a.KT);
     ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
-    const bool f16 = c->ecapa_precision == 1 && a.W16 != nullptr;
     if (f16) {
         if (a.X2) hipLaunchKernelGGL((k_conv_gemm<true, 0, true>), dim3(grid), dim3(256), 0, c->stream, a);
         else hipLaunchKernelGGL((k_conv_gemm<false, 0, true>), dim3(grid), dim3(256), 0, c->stream, a);

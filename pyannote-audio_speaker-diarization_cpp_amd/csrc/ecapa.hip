@@ -13,23 +13,36 @@
 #include <algorithm>
 
 // masked mean over the first nvalid[item] frames  -> out[item][C]   (SEBlock, lengths given)
-__global__ void k_masked_mean(const float* __restrict__ x, int ld, const int* __restrict__ nvalid, const int* __restrict__ rowoff, int row_base,
+template <class T> __global__ void k_masked_mean(const T* __restrict__ x, int ld, const int* __restrict__ nvalid, const int* __restrict__ rowoff, int row_base,
                               float* __restrict__ out, int C)
 {
     const int item = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= C) return;
     const int nv = nvalid[item];
-    const float* p = x + (size_t)(rowoff[item] - row_base) * ld + ch;
+    const T* p = x + (size_t)(rowoff[item] - row_base) * ld + ch;
     float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     int t = 0;
-    for (; t + 3 < nv; t += 4) { s0 += p[(size_t)t * ld]; s1 += p[(size_t)(t + 1) * ld]; s2 += p[(size_t)(t + 2) * ld]; s3 += p[(size_t)(t + 3) * ld]; }
-    for (; t < nv; ++t) s0 += p[(size_t)t * ld];
+    for (; t + 3 < nv; t += 4) { s0 += (float)p[(size_t)t * ld]; s1 += (float)p[(size_t)(t + 1) * ld]; s2 += (float)p[(size_t)(t + 2) * ld]; s3 += (float)p[(size_t)(t + 3) * ld]; }
+    for (; t < nv; ++t) s0 += (float)p[(size_t)t * ld];
     out[(size_t)item * C + ch] = ((s0 + s1) + (s2 + s3)) / (float)nv;
 }
 
 // y = gate[item][c] * t2 + residual   (SERes2NetBlock tail), float4 over channels
-__global__ void k_se_apply(const float* __restrict__ t2, const float* __restrict__ gate, const float* __restrict__ res, int res_ld,
-                           float* __restrict__ y, int y_ld, int C, int64_t rows, const int2* __restrict__ rowtab)
+template <class T> struct Vec4;
+template <> struct Vec4<float> { typedef float4 type; };
+template <> struct Vec4<_Float16> { typedef _Float16 type __attribute__((ext_vector_type(4))); };
+template <class T> __device__ __forceinline__ float4 ld4(const T* p)
+{
+    if constexpr (sizeof(T) == 4) return *(const float4*)p;
+    else { const typename Vec4<_Float16>::type h = *(const typename Vec4<_Float16>::type*)p; return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
+}
+template <class T> __device__ __forceinline__ void st4(T* p, float4 v)
+{
+    if constexpr (sizeof(T) == 4) *(float4*)p = v;
+    else { typename Vec4<_Float16>::type h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; *(typename Vec4<_Float16>::type*)p = h; }
+}
+template <class T> __global__ void k_se_apply(const T* __restrict__ t2, const float* __restrict__ gate, const T* __restrict__ res, int res_ld,
+                           T* __restrict__ y, int y_ld, int C, int64_t rows, const int2* __restrict__ rowtab)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int c4n = C / 4;
@@ -37,59 +50,59 @@ __global__ void k_se_apply(const float* __restrict__ t2, const float* __restrict
     const int64_t row = idx / c4n;
     const int c = (int)(idx - row * c4n) * 4;
     const int64_t item = ROWTAB_ITEM(rowtab[row].y);
-    const float4 a = *(const float4*)(t2 + row * C + c);
+    const float4 a = ld4(t2 + row * C + c);
     const float4 g = *(const float4*)(gate + item * C + c);
-    const float4 r = *(const float4*)(res + row * res_ld + c);
+    const float4 r = ld4(res + row * res_ld + c);
     float4 o;
     o.x = g.x * a.x + r.x; o.y = g.y * a.y + r.y; o.z = g.z * a.z + r.z; o.w = g.w * a.w + r.w;
-    *(float4*)(y + row * y_ld + c) = o;
+    st4(y + row * y_ld + c, o);
 }
 
 // copy a channel slice [rows][w] between strided buffers (Res2Net first sub-band is identity)
-__global__ void k_copy_slice(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld, int w, int64_t rows)
+template <class T> __global__ void k_copy_slice(const T* __restrict__ src, int src_ld, T* __restrict__ dst, int dst_ld, int w, int64_t rows)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int w4 = w / 4;
     if (idx >= rows * w4) return;
     const int64_t row = idx / w4;
     const int c = (int)(idx - row * w4) * 4;
-    *(float4*)(dst + row * dst_ld + c) = *(const float4*)(src + row * src_ld + c);
+    *(typename Vec4<T>::type*)(dst + row * dst_ld + c) = *(const typename Vec4<T>::type*)(src + row * src_ld + c);
 }
 
 // ASP global-context statistics: mean / std over valid frames -> ms[item][2C]
 // one pass (Welford) with 4 rows in flight per thread: the tensor is read once
-__global__ void k_asp_stats(const float* __restrict__ x, int ld, const int* __restrict__ nvalid, const int* __restrict__ rowoff, int row_base,
+template <class T> __global__ void k_asp_stats(const T* __restrict__ x, int ld, const int* __restrict__ nvalid, const int* __restrict__ rowoff, int row_base,
                             float* __restrict__ ms, int C)
 {
     const int item = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= C) return;
     const int nv = nvalid[item];
-    const float* p = x + (size_t)(rowoff[item] - row_base) * ld + ch;
+    const T* p = x + (size_t)(rowoff[item] - row_base) * ld + ch;
     float mean = 0.0f, m2 = 0.0f;
     int t = 0;
     for (; t + 3 < nv; t += 4) {
-        const float v0 = p[(size_t)t * ld], v1 = p[(size_t)(t + 1) * ld], v2 = p[(size_t)(t + 2) * ld], v3 = p[(size_t)(t + 3) * ld];
+        const float v0 = (float)p[(size_t)t * ld], v1 = (float)p[(size_t)(t + 1) * ld], v2 = (float)p[(size_t)(t + 2) * ld], v3 = (float)p[(size_t)(t + 3) * ld];
         float d;
         d = v0 - mean; mean += d / (float)(t + 1); m2 += d * (v0 - mean);
         d = v1 - mean; mean += d / (float)(t + 2); m2 += d * (v1 - mean);
         d = v2 - mean; mean += d / (float)(t + 3); m2 += d * (v2 - mean);
         d = v3 - mean; mean += d / (float)(t + 4); m2 += d * (v3 - mean);
     }
-    for (; t < nv; ++t) { const float v = p[(size_t)t * ld]; const float d = v - mean; mean += d / (float)(t + 1); m2 += d * (v - mean); }
+    for (; t < nv; ++t) { const float v = (float)p[(size_t)t * ld]; const float d = v - mean; mean += d / (float)(t + 1); m2 += d * (v - mean); }
     ms[(size_t)item * 2 * C + ch] = mean;
     ms[(size_t)item * 2 * C + C + ch] = sqrtf(fmaxf(m2 / (float)nv, 1e-12f));
 }
 
 // attentive statistics pooling: masked softmax over time of the logits, weighted mean/std of x.
 // One pass over both tensors: online softmax (running max, rescaled weights) + weighted Welford update.
-__global__ void k_asp_pool(const float* __restrict__ x, const float* __restrict__ logit, int ld, const int* __restrict__ nvalid,
+template <class T> __global__ void k_asp_pool(const T* __restrict__ x, const T* __restrict__ logit, int ld, const int* __restrict__ nvalid,
                            const int* __restrict__ rowoff, int row_base, float* __restrict__ pooled, int C)
 {
     const int item = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= C) return;
     const int nv = nvalid[item];
-    const float* px = x + (size_t)(rowoff[item] - row_base) * ld + ch;
-    const float* pl = logit + (size_t)(rowoff[item] - row_base) * ld + ch;
+    const T* px = x + (size_t)(rowoff[item] - row_base) * ld + ch;
+    const T* pl = logit + (size_t)(rowoff[item] - row_base) * ld + ch;
     float mx = -INFINITY, W = 0.0f, mean = 0.0f, m2 = 0.0f;
     auto step = [&](float l, float v) {
         if (l > mx) { const float s = expf(mx - l); W *= s; m2 *= s; mx = l; }      // expf(-inf) = 0 on the first frame
@@ -101,11 +114,11 @@ __global__ void k_asp_pool(const float* __restrict__ x, const float* __restrict_
     };
     int t = 0;
     for (; t + 3 < nv; t += 4) {
-        const float l0 = pl[(size_t)t * ld], l1 = pl[(size_t)(t + 1) * ld], l2 = pl[(size_t)(t + 2) * ld], l3 = pl[(size_t)(t + 3) * ld];
-        const float v0 = px[(size_t)t * ld], v1 = px[(size_t)(t + 1) * ld], v2 = px[(size_t)(t + 2) * ld], v3 = px[(size_t)(t + 3) * ld];
+        const float l0 = (float)pl[(size_t)t * ld], l1 = (float)pl[(size_t)(t + 1) * ld], l2 = (float)pl[(size_t)(t + 2) * ld], l3 = (float)pl[(size_t)(t + 3) * ld];
+        const float v0 = (float)px[(size_t)t * ld], v1 = (float)px[(size_t)(t + 1) * ld], v2 = (float)px[(size_t)(t + 2) * ld], v3 = (float)px[(size_t)(t + 3) * ld];
         step(l0, v0); step(l1, v1); step(l2, v2); step(l3, v3);
     }
-    for (; t < nv; ++t) step(pl[(size_t)t * ld], px[(size_t)t * ld]);
+    for (; t < nv; ++t) step((float)pl[(size_t)t * ld], (float)px[(size_t)t * ld]);
     pooled[(size_t)item * 2 * C + ch] = mean;
     pooled[(size_t)item * 2 * C + C + ch] = sqrtf(fmaxf(m2 / W, 1e-12f));
 }
@@ -128,17 +141,28 @@ __global__ void k_build_rowtab(const int* __restrict__ rowoff, int row_base, int
     for (int t = threadIdx.x; t < need; t += blockDim.x) rowtab[r0 + t] = make_int2(r0, t | ((need - 1) << 10) | (item << 20));
 }
 
-static ConvArgs conv_args(const ConvLayer& L, const float* X, int x_ld, float* Y, int y_ld, int64_t M, bool per_item)
+// fp16 feature rows for the fp16 mode: [rows][96] f32 -> [rows][128] halves (block0's K-step is 64 halves)
+__global__ void k_feats_to_half(const float* __restrict__ f, _Float16* __restrict__ h, int64_t rows)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * 128) return;
+    const int64_t row = idx >> 7; const int c = (int)(idx & 127);
+    h[idx] = (_Float16)(c < SD_FEAT_LD ? f[row * SD_FEAT_LD + c] : 0.0f);
+}
+
+// prec 0: f32 MFMA, float buffers.  prec 1 (ecapa_precision): fp16 MFMA, _Float16 buffers (X / Y leading dimensions in elements)
+static ConvArgs conv_args(const ConvLayer& L, const void* X, int x_ld, void* Y, int y_ld, int64_t M, bool per_item, int prec = 0)
 {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.X = X; a.x_ld = x_ld; a.Y = Y; a.y_ld = y_ld; a.W = L.W; a.W16 = L.W16;
+    a.X = (const float*)X; a.x_ld = x_ld; a.Y = (float*)Y; a.y_ld = y_ld; a.W = L.W; a.W16 = L.W16;
     a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.M = (int)M;
     if (per_item) { a.TpIn = a.TpOut = SD_TP; a.Tin = a.T = SD_T; }
     else { a.TpIn = a.TpOut = (int)M; a.Tin = a.T = (int)M; }
-    a.Cin = L.CinPad; a.cin_real = L.Cin; a.Cout = L.Cout; a.KT = L.KT; a.dil = L.dil;
-    a.pad_mode = 0;
+    a.Cin = prec ? L.CinPad16 : L.CinPad; a.cin_real = L.Cin; a.Cout = L.Cout; a.KT = L.KT; a.dil = L.dil;
+    a.w_ld = a.Cin;
+    a.pad_mode = 0; a.prec = prec;
     return a;
 }
 
@@ -156,8 +180,10 @@ int ecapa_need_rows(int nvalid, bool skip_dead_rows)
 
 // d_feats: compact rows [rows][96] of `items` items; d_rowoff[items + 1] (first compact row of every item, in a row space that
 // starts at row_base for this batch); d_nvalid[items]
-int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, int64_t items, int64_t rows, float* d_emb)
+template <class T>
+static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, int64_t items, int64_t rows, float* d_emb)
 {
+    constexpr int P = sizeof(T) == 2 ? 1 : 0;                  // conv_gemm precision of the per-frame layers
     const EcapaWeights& E = c->ew;
     if (!E.loaded) SD_FAIL(c, SD_ERR_MODEL, "embedding model not loaded");
     if (items <= 0) return SD_OK;
@@ -165,13 +191,13 @@ int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d
     const int C = E.C, C3 = 3 * C;
     const int64_t M = rows;
     if (M > 0x7fffffff / 2) SD_FAIL(c, SD_ERR_ARG, "ecapa batch too large");
-    WS(c, float, x0, "ec_x0", M * C);
-    WS(c, float, t1, "ec_t1", M * C);
-    WS(c, float, rr, "ec_r", M * C);
-    WS(c, float, t2, "ec_t2", M * C);
-    WS(c, float, cat, "ec_cat", M * C3);
-    WS(c, float, mfa, "ec_mfa", M * C3);
-    WS(c, float, hid, "ec_hid", M * 128);
+    WS(c, T, x0, "ec_x0", M * C);
+    WS(c, T, t1, "ec_t1", M * C);
+    WS(c, T, rr, "ec_r", M * C);
+    WS(c, T, t2, "ec_t2", M * C);
+    WS(c, T, cat, "ec_cat", M * C3);
+    WS(c, T, mfa, "ec_mfa", M * C3);
+    WS(c, T, hid, "ec_hid", M * 128);
     WS(c, float, se_s, "ec_se_s", items * C);
     WS(c, float, se_h, "ec_se_h", items * 128);
     WS(c, float, se_g, "ec_se_g", items * C);
@@ -186,57 +212,70 @@ int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d
 #define WITH_LIST(a) do { (a).rowtab = rowtab; } while (0)
 
     // blocks[0]: TDNNBlock(80 -> C, k5)
-    { ConvArgs a = conv_args(E.block0, d_feats, SD_FEAT_LD, x0, C, M, true); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "block0"))) return rc; }
+    const void* f_in = d_feats; int f_ld = SD_FEAT_LD;
+    if (P) {
+        WS(c, _Float16, fh, "ec_feats16", M * 128);
+        hipLaunchKernelGGL(k_feats_to_half, GRID1(M * 128), 0, st, d_feats, fh, M);
+        KCHECK(c);
+        f_in = fh; f_ld = 128;
+    }
+    { ConvArgs a = conv_args(E.block0, f_in, f_ld, x0, C, M, true, P); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "block0"))) return rc; }
 
     for (int b = 0; b < 3; ++b) {
         const auto& B = E.blk[b];
-        const float* xin = (b == 0) ? x0 : cat + (size_t)(b - 1) * C;
+        const T* xin = (b == 0) ? x0 : cat + (size_t)(b - 1) * C;
         const int xin_ld = (b == 0) ? C : C3;
-        { ConvArgs a = conv_args(B.tdnn1, xin, xin_ld, t1, C, M, true); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "tdnn1"))) return rc; }
+        { ConvArgs a = conv_args(B.tdnn1, xin, xin_ld, t1, C, M, true, P); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "tdnn1"))) return rc; }
         const int S = C / 8;
-        hipLaunchKernelGGL(k_copy_slice, GRID1(M * (S / 4)), 0, st, t1, C, rr, C, S, M);
+        hipLaunchKernelGGL(k_copy_slice<T>, GRID1(M * (S / 4)), 0, st, t1, C, rr, C, S, M);
         KCHECK(c);
         for (int i = 1; i < 8; ++i) {
-            ConvArgs a = conv_args(B.res[i - 1], t1 + i * S, C, rr + i * S, C, M, true);
+            ConvArgs a = conv_args(B.res[i - 1], t1 + i * S, C, rr + i * S, C, M, true, P);
             a.act1 = 1;
-            if (i >= 2) { a.X2 = rr + (i - 1) * S; a.x2_ld = C; }
+            if (i >= 2) { a.X2 = (const float*)(rr + (i - 1) * S); a.x2_ld = C; }
             WITH_LIST(a);
             if ((rc = launch_conv_gemm(c, a, "res2net"))) return rc;
         }
-        { ConvArgs a = conv_args(B.tdnn2, rr, C, t2, C, M, true); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "tdnn2"))) return rc; }
+        { ConvArgs a = conv_args(B.tdnn2, rr, C, t2, C, M, true, P); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "tdnn2"))) return rc; }
         {
             ProfScope ps(c, "se_mean", 0, (double)M * C * 4.0);
-            hipLaunchKernelGGL(k_masked_mean, dim3((C + 255) / 256, (unsigned)items), dim3(256), 0, st, t2, C, d_nvalid, d_rowoff, row_base, se_s, C);
+            hipLaunchKernelGGL(k_masked_mean<T>, dim3((C + 255) / 256, (unsigned)items), dim3(256), 0, st, t2, C, d_nvalid, d_rowoff, row_base, se_s, C);
             KCHECK(c);
         }
         { ConvArgs a = conv_args(B.se1, se_s, C, se_h, 128, items, false); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "se1"))) return rc; }
         { ConvArgs a = conv_args(B.se2, se_h, 128, se_g, C, items, false); a.act2 = 2; if ((rc = launch_conv_gemm(c, a, "se2"))) return rc; }
         {
             ProfScope ps(c, "se_apply", 0, (double)M * C * 12.0);
-            hipLaunchKernelGGL(k_se_apply, GRID1(M * (C / 4)), 0, st, t2, se_g, xin, xin_ld, cat + (size_t)b * C, C3, C, M, rowtab);
+            hipLaunchKernelGGL(k_se_apply<T>, GRID1(M * (C / 4)), 0, st, t2, se_g, xin, xin_ld, cat + (size_t)b * C, C3, C, M, rowtab);
             KCHECK(c);
         }
     }
     // mfa: TDNNBlock(3C -> 3C, k1) over cat(x1,x2,x3)
-    { ConvArgs a = conv_args(E.mfa, cat, C3, mfa, C3, M, true); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
+    { ConvArgs a = conv_args(E.mfa, cat, C3, mfa, C3, M, true, P); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
     // ASP with global context: cat[x, mean, std] @ W == x @ Wx + (mean,std) @ Wms  (per-item bias)
     {
         ProfScope ps(c, "asp_stats", 0, (double)M * C3 * 4.0);
-        hipLaunchKernelGGL(k_asp_stats, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, C3, d_nvalid, d_rowoff, row_base, ms, C3);
+        hipLaunchKernelGGL(k_asp_stats<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, C3, d_nvalid, d_rowoff, row_base, ms, C3);
         KCHECK(c);
     }
     { ConvArgs a = conv_args(E.asp_tdnn_ms, ms, 2 * C3, ib, 128, items, false); if ((rc = launch_conv_gemm(c, a, "asp_ms"))) return rc; }
-    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, C3, hid, 128, M, true); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
-    float* logits = cat;   // cat is dead after mfa
-    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, M, true); WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
+    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, C3, hid, 128, M, true, P); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
+    T* logits = cat;   // cat is dead after mfa
+    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, M, true, P); WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
     {
         ProfScope ps(c, "asp_pool", 0, (double)M * C3 * 8.0);
-        hipLaunchKernelGGL(k_asp_pool, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, C3, d_nvalid, d_rowoff, row_base, pooled, C3);
+        hipLaunchKernelGGL(k_asp_pool<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, C3, d_nvalid, d_rowoff, row_base, pooled, C3);
         KCHECK(c);
     }
     // asp_bn folded into fc
     { ConvArgs a = conv_args(E.fc, pooled, 2 * C3, d_emb, SD_EMB_DIM, items, false); if ((rc = launch_conv_gemm(c, a, "fc"))) return rc; }
     return SD_OK;
+}
+
+int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, int64_t items, int64_t rows, float* d_emb)
+{
+    if (c->ecapa_precision == 1) return run_ecapa_t<_Float16>(c, d_feats, d_nvalid, d_rowoff, row_base, items, rows, d_emb);
+    return run_ecapa_t<float>(c, d_feats, d_nvalid, d_rowoff, row_base, items, rows, d_emb);
 }
 
 // host side of the compact row plan: need / rowoff of `n` items from their nvalid (uploaded to d_rowoff[n + 1])

@@ -94,9 +94,12 @@ static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const s
     L.W = upload(c, hw);
     if (!L.W) return SD_ERR_HIP;
     L.W16 = nullptr;
-    if (want16) {                          // fp16 copy, round to nearest even
-        std::vector<_Float16> h16(hw.size());
-        for (size_t i = 0; i < hw.size(); ++i) h16[i] = (_Float16)hw[i];
+    L.CinPad16 = (cin + 63) / 64 * 64;
+    if (want16) {                          // fp16 copy (round to nearest even), rows padded to a multiple of 64 input channels
+        std::vector<_Float16> h16((size_t)K * Cout * L.CinPad16, (_Float16)0.0f);
+        for (int k = 0; k < K; ++k)
+            for (int o = 0; o < Cout; ++o)
+                for (int i = 0; i < cin; ++i) h16[((size_t)k * Cout + o) * L.CinPad16 + i] = (_Float16)hw[((size_t)k * Cout + o) * CinPad + i];
         L.W16 = upload(c, h16);
         if (!L.W16) return SD_ERR_HIP;
     }
