@@ -358,6 +358,9 @@ __global__ __launch_bounds__(LT) void k_linkage_heap(double* D, int n, int* size
 //      slots itself, so all take the same decision without a broadcast.
 // A stale candidate (cl.cpp:329-338) costs one extra round (see the kernel's own header below).
 // Used from N = 1500 up, where one CU's memory pipeline is the bottleneck.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_linkage_mw's fence-free slot exchange (sc1 write-through stores, sc1 loads, 8-byte tagged granules) is written for gfx950 only"
+#endif
 #define MWT 256
 #define MWT_MAX 1024
 // arg-min candidate that carries its neighbour and its flags along through the reductions.

@@ -135,10 +135,13 @@ extern "C" int sd_diarize_sharded_dev(sd_ctx* c, const int16_t* d_pcm_shard, int
                     (long long)(first_sample + shard_samples), (long long)mylo, (long long)myhi);
         float* w = nullptr;
         if ((rc = pcm_to_wav(c, d_pcm_shard, shard_samples, &w))) return rc;
-        // kernels index the recording with absolute sample positions; only the covered range is ever touched
-        if (!virt) { if ((rc = shard_infer(c, w - first_sample, n, mylo, myhi, s_seg, s_emb))) return rc; }
-        else for (int r = 0; r < W; ++r)
-            if (hi[(size_t)r] > lo[(size_t)r] && (rc = shard_infer(c, w - first_sample, n, lo[(size_t)r], hi[(size_t)r], g_seg + (size_t)r * seg_slot, g_emb + (size_t)r * emb_slot))) return rc;
+        c->wav_origin = first_sample;             // kernels index the recording with absolute sample positions
+        rc = SD_OK;
+        if (!virt) rc = shard_infer(c, w, n, mylo, myhi, s_seg, s_emb);
+        else for (int r = 0; r < W && !rc; ++r)
+            if (hi[(size_t)r] > lo[(size_t)r]) rc = shard_infer(c, w, n, lo[(size_t)r], hi[(size_t)r], g_seg + (size_t)r * seg_slot, g_emb + (size_t)r * emb_slot);
+        c->wav_origin = 0;
+        if (rc) return rc;
     }
     if (!virt) {
         ProfScope ps(c, "rccl_all_gather", 0, (double)(seg_slot + emb_slot) * sizeof(float) * c->world);

@@ -117,6 +117,7 @@ struct sd_ctx {
     int num_cu = 256;
     bool constrained_assignment = false;        // Clustering.py:81-94 (one cluster per local speaker of a chunk)
     std::vector<double> last_conf;               // per-turn confidence of the last finalize (sd_last_confidence)
+    int64_t wav_origin = 0;                     // recording position of d_wav[0] for the current call (sharded entry points hold a slice)
     void* comm = nullptr;                       // ncclComm_t (comm.cpp), null = single GPU
     int rank = 0, world = 1;
     int virtual_world = 0;                      // test mode of sd_diarize_sharded on one rank (comm.cpp)

@@ -5,23 +5,17 @@
 //
 // The reference materialises imask[80000], the compacted signal[80000] and the
 // [501][201][2] STFT tensor per item on the host; here an item never leaves the chip
-// between the waveform read and the [501][80] log-mel write:
-//   k_mask_prefix : per item, exclusive scan of the 293 mask frames' sample counts
-//   k_wav_lens    : per reference batch of 32 items: max_len, wav_len, too-short flags
-//   k_stft_mel    : per (item, 64-frame tile): gather the compacted samples into LDS
-//                   (inverse of the compaction via the prefix table), 400-point real
-//                   DFT as fp64 MFMA (v_mfma_f64_16x16x4_f64, even/odd folded to K = 204,
-//                   twiddles from a 400-entry LDS table), power in fp32, sparse mel, dB,
-//                   per-item max (atomic)
-//   k_fbank_norm  : top-dB clamp, mean over the first round(len*501) frames, subtract,
-//                   write channels-last [501][96] rows for the MFMA convs
+// between the waveform read and the log-mel feature rows:
+//   k_mask_prefix  : per item, exclusive scan of the 293 mask frames' sample counts
+//   k_wav_lens     : per reference batch of 32 items: max_len, wav_len, too-short flags
+//   k_compact_active : items that are NaN by the reference's rule are dropped before any arithmetic
+//   k_stft_fbank   : one persistent workgroup per item: gather the compacted samples into LDS
+//                    (inverse of the compaction via the prefix table), 400-point real DFT in fp64
+//                    as a 16 x 25 mixed-radix FFT, power in fp32, sparse mel, dB, item maximum,
+//                    then top-dB clamp, mean over the first round(len*501) frames, and the
+//                    channels-last [96] feature rows of the frames the network needs (ecapa.hip)
 #include "common.h"
 
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-#define FT 16                         // STFT frames per workgroup: one MFMA row tile; the 4 waves split the 13 bin tiles
-#define SIG_LEN ((FT - 1) * 160 + 400)  // 2800 samples feed FT frames
-#define SIG_LDS (SIG_LEN + 2 * (SIG_LEN / 160) + 8)
 #define PW_LD 209
 #define MEL_MAX_NNZ 1536
 
@@ -81,168 +75,6 @@ __global__ void k_wav_lens(const int* __restrict__ counts, int items, float* __r
     flags[item] = (all_nan || too_short) ? 1 : 0;
 }
 
-__device__ __forceinline__ void atomic_max_float(float* addr, float v)
-{
-    if (v >= 0.0f) atomicMax((int*)addr, __float_as_int(v));
-    else atomicMin((unsigned int*)addr, __float_as_uint(v));
-}
-
-template <int NT>
-__device__ __forceinline__ void dft_tiles(const float* sig, const float* win, const double* tc, const double* ts,
-                                          float* pw, int w, int lane, int tile0)
-{
-    const int i = lane & 15, kq = lane >> 4;
-    const int fl = i;                      // every wave works on the workgroup's 16 frames, on its own bin tiles
-    const int sbase = 162 * fl;            // padded LDS position of the frame's first sample
-    f64x4 re[NT], im[NT];
-    int idx[NT], inc[NT];
-#pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        re[b] = (f64x4){0, 0, 0, 0};
-        im[b] = (f64x4){0, 0, 0, 0};
-        const int j = (tile0 + b) * 16 + i;
-        idx[b] = (kq * j) % 400;
-        inc[b] = (4 * j) % 400;
-    }
-    // Real-input symmetry halves the contraction: with xw[n] = x[n] w[n],
-    //   Re X[k] =  sum_{n=0..200} e[n] cos(2 pi k n / 400),  e[n] = xw[n] + xw[400-n]  (e[0] = xw[0], e[200] = xw[200])
-    //   Im X[k] = -sum_{n=1..199} o[n] sin(2 pi k n / 400),  o[n] = xw[n] - xw[400-n]
-    // 51 K-steps of 4 instead of 100 (indices 201..203 contribute zeros).
-    for (int s = 0; s < 51; ++s) {
-        const int nn = 4 * s + kq;
-        const int nc = nn <= 200 ? nn : 200;
-        const int nm = 400 - nc;                               // mirror index (400 for nc == 0: not used)
-        const double a0 = (double)sig[sbase + nc + 2 * (nc / 160)] * (double)win[nc];
-        const int nmc = nm < 400 ? nm : 399;
-        const double a1 = (double)sig[sbase + nmc + 2 * (nmc / 160)] * (double)win[nmc];
-        const bool mid = (nn >= 1) && (nn <= 199);
-        const double e = (nn > 200) ? 0.0 : (mid ? a0 + a1 : a0);
-        const double o = mid ? a0 - a1 : 0.0;
-#pragma unroll
-        for (int b = 0; b < NT; ++b) {
-            const double cv = tc[idx[b]], sv = ts[idx[b]];
-            re[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(e, cv, re[b], 0, 0, 0);
-            im[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(o, sv, im[b], 0, 0, 0);
-            idx[b] += inc[b];
-            if (idx[b] >= 400) idx[b] -= 400;
-        }
-    }
-    // C layout (f64 16x16x4): col = lane&15 (bin), row = (lane>>4) + 4*r (frame)
-#pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        const int bin = (tile0 + b) * 16 + i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float fr = (float)re[b][r], fi = (float)im[b][r];        // STFT cast to f32 (sd.cpp:2031)
-            pw[(kq + 4 * r) * PW_LD + bin] = __fadd_rn(__fmul_rn(fr, fr), __fmul_rn(fi, fi));
-        }
-    }
-}
-
-// ---------------------------------------------------------------- k_stft_mel
-__global__ __launch_bounds__(256) void k_stft_mel(
-    const float* __restrict__ wav, int64_t n, const int* __restrict__ prefix, const int* __restrict__ counts,
-    int64_t first_item, const float* __restrict__ window, const double* __restrict__ twc, const double* __restrict__ twns,
-    const float* __restrict__ mel_w, const int* __restrict__ mel_lo, const int* __restrict__ mel_cnt,
-    const int* __restrict__ mel_off, int mel_nnz, float* __restrict__ db, float* __restrict__ item_max,
-    const int* __restrict__ alist /* active-item list or null: outputs are indexed by the compact position */,
-    const int* __restrict__ rowoff /* [slots + 1]: frames at or beyond rowoff[slot + 1] - rowoff[slot] are not needed (ecapa.hip) */)
-{
-    __shared__ double tc[400], ts[400];
-    __shared__ float sig[SIG_LDS];
-    __shared__ float win[400];
-    __shared__ float pw[16 * PW_LD];
-    __shared__ float mw[MEL_MAX_NNZ];
-    __shared__ int pre[296];
-    __shared__ int mlo[SD_NMELS], mcnt[SD_NMELS], moff[SD_NMELS];
-
-    const int slot = blockIdx.y, t0 = blockIdx.x * FT;
-    // frames the network never reads are all-zero signal (every frame with content lies below nvalid + 2): they can neither
-    // raise the item's maximum nor enter the mean, so whole tiles of them are skipped
-    if (t0 >= rowoff[slot + 1] - rowoff[slot]) return;
-    const int item = alist ? alist[slot] : slot;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t gitem = first_item + item;
-    const int64_t chunk_start = (gitem / SD_SPEAKERS) * (int64_t)SD_HOP;     // crop(), sd.cpp:1643
-    const int cnt = counts[item];
-
-    for (int k = tid; k < 400; k += 256) { tc[k] = twc[k]; ts[k] = twns[k]; win[k] = window[k]; }
-    for (int k = tid; k < 296; k += 256) pre[k] = prefix[(size_t)item * 296 + k];
-    for (int k = tid; k < mel_nnz; k += 256) mw[k] = mel_w[k];
-    if (tid < SD_NMELS) { mlo[tid] = mel_lo[tid]; mcnt[tid] = mel_cnt[tid]; moff[tid] = mel_off[tid]; }
-    __syncthreads();
-
-    // gather the compacted signal samples m in [160*t0-200, +SIG_LEN) (zeros outside [0,cnt))
-    const int mstart = 160 * t0 - 200;
-    for (int mm = tid; mm < SIG_LEN; mm += 256) {
-        const int m = mstart + mm;
-        float v = 0.0f;
-        if (m >= 0 && m < cnt) {
-            // smallest f with pre[f+1] > m  (f is an active mask frame containing compacted sample m)
-            int lo = 0, hi = SD_FRAMES - 1;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pre[mid + 1] > m) hi = mid; else lo = mid + 1; }
-            const int64_t s = chunk_start + frame_start(lo) + (m - pre[lo]);
-            if (s < n) v = wav[s];
-        }
-        sig[mm + 2 * (mm / 160)] = v;
-    }
-    __syncthreads();
-
-    // 13 bin tiles of 16: wave 0 takes tiles 0-3, waves 1-3 three each (4 waves per 16 frames keep 3 workgroups = 12 waves
-    // resident per CU; with 64 frames per workgroup the LDS footprint allowed one wave per SIMD)
-    if (w == 0) dft_tiles<4>(sig, win, tc, ts, pw, w, lane, 0);
-    else dft_tiles<3>(sig, win, tc, ts, pw, w, lane, 1 + 3 * w);
-    __syncthreads();
-
-    float vmax = -INFINITY;
-    for (int o = tid; o < 16 * SD_NMELS; o += 256) {
-        const int fr = o / SD_NMELS, m = o - fr * SD_NMELS;
-        const float* p = &pw[fr * PW_LD + mlo[m]];
-        const float* q = &mw[moff[m]];
-        float acc = 0.0f;
-        const int c = mcnt[m];
-        for (int b = 0; b < c; ++b) acc = fmaf(p[b], q[b], acc);
-        const float v = 10.0f * log10f(fmaxf(acc, 1e-10f));
-        const int t = t0 + fr;
-        if (t < SD_T) {
-            db[((size_t)slot * SD_T + t) * SD_NMELS + m] = v;
-            vmax = fmaxf(vmax, v);
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if (lane == 0 && vmax > -INFINITY) atomic_max_float(&item_max[slot], vmax);
-}
-
-// ---------------------------------------------------------------- k_fbank_norm
-// feats: compact rows (see ecapa.hip): item's frame t goes to row rowoff[item] + t, t < rowoff[item + 1] - rowoff[item]
-__global__ __launch_bounds__(256) void k_fbank_norm(const float* __restrict__ db, const float* __restrict__ item_max,
-                                                    const int* __restrict__ nnorm, const int* __restrict__ rowoff, float* __restrict__ feats)
-{
-    __shared__ float part[3][SD_NMELS];
-    __shared__ float mean[SD_NMELS];
-    const int item = blockIdx.x, tid = threadIdx.x;
-    const float floor_db = item_max[item] - 80.0f;                           // top_db = 80
-    const int nn = nnorm[item];
-    const float* src = db + (size_t)item * SD_T * SD_NMELS;
-    if (tid < 240) {
-        const int c = tid % SD_NMELS, g = tid / SD_NMELS;
-        float s = 0.0f;
-        for (int t = g; t < nn; t += 3) s += fmaxf(src[t * SD_NMELS + c], floor_db);
-        part[g][c] = s;
-    }
-    __syncthreads();
-    if (tid < SD_NMELS) mean[tid] = (part[0][tid] + part[1][tid] + part[2][tid]) / (float)nn;
-    __syncthreads();
-    const int r0 = rowoff[item], need = rowoff[item + 1] - r0;
-    float* dst = feats + (size_t)r0 * SD_FEAT_LD;
-    for (int idx = tid; idx < need * SD_FEAT_LD; idx += 256) {
-        const int t = idx / SD_FEAT_LD, c = idx - t * SD_FEAT_LD;
-        float v = 0.0f;
-        if (c < SD_NMELS) v = fmaxf(src[t * SD_NMELS + c], floor_db) - mean[c];
-        dst[idx] = v;
-    }
-}
-
 // ---------------------------------------------------------------- k_stft_fbank : the whole front end of one item in one workgroup
 // gather (inverse of the reference's stream compaction) -> fp64 STFT as a mixed-radix FFT -> power -> mel -> dB, then -- same
 // workgroup, second phase -- top-dB clamp with the item's maximum, mean over the first nnorm frames, compact feature rows.
@@ -264,7 +96,7 @@ __global__ __launch_bounds__(256) void k_fbank_norm(const float* __restrict__ db
 #define MEL_LDS_NNZ 512
 #define YK 17                              // stage A -> B exchange: Y[frame][k1][r], k1 stride padded to 17 complex (bank spread)
 __global__ __launch_bounds__(256, 2) void k_stft_fbank(
-    const float* __restrict__ wav, int64_t n, const int* __restrict__ prefix, const int* __restrict__ counts, int64_t first_item,
+    const float* __restrict__ wav /* wav[0] = sample `origin` of the recording */, int64_t origin, int64_t n, const int* __restrict__ prefix, const int* __restrict__ counts, int64_t first_item,
     const float* __restrict__ window, const double* __restrict__ twc, const double* __restrict__ twns,
     const float* __restrict__ mel_w, const int* __restrict__ mel_lo, const int* __restrict__ mel_cnt, const int* __restrict__ mel_off,
     int mel_nnz, const int* __restrict__ alist, const int* __restrict__ rowoff, const int* __restrict__ nnorm, int run_items,
@@ -327,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_fbank(
                 }
                 float v[11];
 #pragma unroll
-                for (int q = 0; q < 11; ++q) v[q] = src[q] >= 0 ? wav[chunk_start + src[q]] : 0.0f;      // ... then all loads in flight together
+                for (int q = 0; q < 11; ++q) v[q] = src[q] >= 0 ? wav[chunk_start - origin + src[q]] : 0.0f;      // ... then all loads in flight together
 #pragma unroll
                 for (int q = 0; q < 11; ++q) { const int sidx = s0 + q; if (sidx < 2800) sig[sidx + 16 * (sidx / 160)] = v[q]; }
             }
@@ -440,12 +272,6 @@ __global__ __launch_bounds__(1024) void k_compact_active(const int* __restrict__
     if (tid == 0) *n_active = base;
 }
 
-__global__ void k_fill_f32(float* p, float v, int64_t n)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 // Phase A: mask prefix tables, wav_lens / nnorm / nvalid / too-short flags.  compact = true: items whose embedding is NaN by
 // rule are dropped -- *h_n_active receives the number of live items, d_nnorm / d_nvalid are indexed by the compact position,
 // d_cidx[item] = compact position or -1.  The prefix tables, sample counts and the active list stay in workspaces for phase B.
@@ -498,7 +324,7 @@ int frontend_features(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_it
     {
         // algorithmic bytes per item: 80000*4 + 293*4 read, 501*80*4 written; ~15 kFLOP fp64 per frame (FFT) + 16 kFLOP mel
         ProfScope ps(c, "stft_mel", (double)run_items * SD_T * (15000.0 + 201.0 * 80 * 2), (double)run_items * (321172.0 + 160320.0));
-        hipLaunchKernelGGL(k_stft_fbank, dim3(grid), dim3(256), 0, c->stream, d_wav, n, d_prefix, d_counts, first_item, E.window, E.tw_cos, E.tw_nsin,
+        hipLaunchKernelGGL(k_stft_fbank, dim3(grid), dim3(256), 0, c->stream, d_wav, c->wav_origin, n, d_prefix, d_counts, first_item, E.window, E.tw_cos, E.tw_nsin,
                            E.mel_w, E.mel_lo, E.mel_cnt, E.mel_off, E.mel_nnz, alist, d_rowoff, d_nnorm, (int)run_items, d_scratch, d_feats);
         KCHECK(c);
     }

@@ -288,8 +288,10 @@ extern "C" int sd_shard_infer_dev(sd_ctx* c, const int16_t* d_pcm_shard, int64_t
     int rc0 = pcm_to_wav(c, d_pcm_shard, shard_samples, &w);
     if (rc0) return rc0;
     for (int i = 0; i < 4; ++i) c->stage_ms[i] = 0;
-    // kernels index the recording with absolute sample positions; only the covered range is ever touched
-    return shard_infer(c, w - first_sample, n, chunk_lo, chunk_hi, d_seg, d_emb);
+    c->wav_origin = first_sample;                 // kernels index the recording with absolute sample positions
+    const int rc = shard_infer(c, w, n, chunk_lo, chunk_hi, d_seg, d_emb);
+    c->wav_origin = 0;
+    return rc;
 }
 
 extern "C" int sd_finalize_dev(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t chunks, int64_t n, sd_turn** turns, int64_t* n_turns)

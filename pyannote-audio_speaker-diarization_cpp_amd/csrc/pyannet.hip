@@ -20,12 +20,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------- k_chunk_norm
 // xn[chunk][j] = (x - mean) / sqrt(var + 1e-5) * w + b  for j < L, 0 beyond
-__global__ __launch_bounds__(256) void k_chunk_norm(const float* __restrict__ wav, int64_t n, int64_t first_chunk, int L,
+__global__ __launch_bounds__(256) void k_chunk_norm(const float* __restrict__ wav, int64_t origin, int64_t first_chunk, int L,
                                                     float w, float b, float* __restrict__ xn)
 {
     __shared__ float red[256];
     const int ck = blockIdx.x, tid = threadIdx.x;
-    const int64_t base = (first_chunk + ck) * (int64_t)SD_HOP;
+    const int64_t base = (first_chunk + ck) * (int64_t)SD_HOP - origin;          // wav[0] is sample `origin` of the recording
     const float* x = wav + base;
     float s = 0.0f;
     for (int j = tid; j < L; j += 256) s += x[j];
@@ -258,7 +258,7 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
     WS(c, float, y0, "sg_y0", CB * F * 128);
     WS(c, float, y1, "sg_y1", CB * F * 128);
     int rc;
-    hipLaunchKernelGGL(k_chunk_norm, dim3((unsigned)CB), dim3(256), 0, st, d_wav, n, first_chunk, L, S.wn_w, S.wn_b, xn);
+    hipLaunchKernelGGL(k_chunk_norm, dim3((unsigned)CB), dim3(256), 0, st, d_wav, c->wav_origin, first_chunk, L, S.wn_w, S.wn_b, xn);
     KCHECK(c);
     {   // conv0: rows = output positions, row r reads xn[10 r .. 10 r + 256)
         ConvArgs a; memset(&a, 0, sizeof(a));

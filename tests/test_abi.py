@@ -74,3 +74,33 @@ def test_synth_is_deterministic_and_prefix_consistent():
     assert np.array_equal(a, synth.make_pcm(30.0, seed=5))
     assert np.array_equal(a[:100000], synth.make_pcm(30.0, seed=5, limit=100000))
     assert a.dtype == np.int16 and len(a) == 480000 and np.abs(a).max() > 5000
+
+
+def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
+    """include/sdhip.h is the drop-in boundary: it must compile as C99 (no C++-isms), and a C program linked against
+    libsdhip.so must be able to call the host-only entry points"""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "sdhip.h"
+int main(void) {
+    int64_t last = 0, ranges[4], per = 0;
+    int64_t c = sd_num_chunks(944000, &last);
+    sd_turn t[3] = {{5.222812345, 17.74406789, 10, 0}, {18.0, 19.0, 2, 0}, {20.0, 21.0, 10, 0}};
+    char buf[128];
+    sd_format_turn(&t[0], buf, (int)sizeof buf);
+    if (sd_shard_plan(57600000, 2, -1, ranges, &per) != SD_OK) return 2;
+    if (sd_relabel_turns_ex(t, 3, 0) != SD_OK) return 3;
+    printf("%lld %lld|%s|%lld %lld %lld %lld %lld|%d %d %d|%d\n", (long long)c, (long long)last, buf, (long long)per, (long long)ranges[0],
+           (long long)ranges[1], (long long)ranges[2], (long long)ranges[3], t[0].label, t[1].label, t[2].label, SD_COMM_ID_BYTES);
+    return 0;
+}
+''')
+    pkg = os.path.join(ROOT, "pyannote-audio_speaker-diarization_cpp_amd")
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", pkg, "-lsdhip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "109 80000|[5.22281 -- 17.7441] --> Speaker_10|3616 0 3616 3616 7191|0 1 0|128"
