@@ -268,6 +268,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     __syncthreads();
     advance();
     if constexpr (F16) hfrag(0, 0, 0); else lfrag(0, 0, 0);
+    if constexpr (F16) {
+        // the two workgroups of a CU tend to run in lockstep (same tile length): both sit in their VALU-bound epilogues
+        // together and both K loops fight for the MFMA pipe together.  Starting every second workgroup of an XCD half a
+        // tile late lets one workgroup's epilogue overlap the other's MFMAs (a 16-MFMA K-step is only ~512 cycles here).
+        if (a.sched == 3 && (wl & 1)) for (int i_ = 0; i_ < S * 4; ++i_) __builtin_amdgcn_s_sleep(1);
+    }
 
     int q = q0, s = 0, buf = 0;
     while (true) {
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                                 float v = acc[i][j][4 * gq + e] + cb_[j];
                                 acc[i][j][4 * gq + e] = 0.0f;
                                 if (IB) v += a.item_bias[(size_t)b * a.ib_ld + (cco[j] < a.Cout ? cco[j] : a.Cout - 1)];
-                                v = v > 0.0f ? v : v * slope;
+                                v = fmaxf(v, v * slope);                  // slope in [0, 1]: relu (0), leaky (0.01), identity (1)
                                 v = v * cs_[j] + ch_[j];
                                 if (A2 == 1) v = tanhf(v);
                                 else if (A2 == 2) v = 1.0f / (1.0f + expf(-v));

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdhip.so")
+LIB_PATH = os.environ.get("SDHIP_LIB") or os.path.join(_HERE, "libsdhip.so")      # (SDHIP_LIB: instrumented builds of the tuning tools)
 
 CHUNK, HOP, FRAMES, SPEAKERS, EMB_DIM, EMB_BATCH = 80000, 8000, 293, 3, 192, 32
 T_FRAMES, N_MELS = 501, 80
