@@ -927,10 +927,10 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     int rc;
     if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md))) return rc;
     int G = (int)c->linkage_wgs;
-    if (G < 0) G = N >= 60000 ? 128 : N >= 15000 ? 64 : N >= 1500 ? 32 : 0;     // auto (measured on clustered data, profiles/r01_linkage_scaling.txt)
+    if (G < 0) G = N >= 60000 ? 128 : N >= 8000 ? 64 : N >= 1500 ? 32 : 0;      // auto (measured on clustered data, profiles/r01_linkage_scaling.txt, r02_linkage_stamps.txt)
     if (G > c->num_cu) G = c->num_cu;
     int TH = (int)c->linkage_threads;
-    if (TH <= 0) TH = N >= 15000 ? 512 : 256;          // measured: 327 vs 337 ms at N = 21 573, 4.68 vs 4.85 s at N = 172 773
+    if (TH <= 0) TH = N >= 8000 ? 512 : 256;           // measured: 188 vs 195 ms at N = 12 602, 327 vs 337 ms at N = 21 573, 4.68 vs 4.85 s at N = 172 773
     TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : 256;
     if (G <= 1) return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
     if ((N + G - 1) / G > 7000) G = (int)((N + 6999) / 7000);      // active-row lists live in LDS: 8 B per owned row
