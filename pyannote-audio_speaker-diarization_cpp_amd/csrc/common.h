@@ -60,9 +60,12 @@ struct ConvArgs {
     // compact row space (ECAPA): the buffers hold, item after item, only the frames that can influence a valid output
     // (need_i = min(501, nvalid_i + receptive field) rows of item i).  rowtab[g] of compact row g:
     //   .x = first compact row of g's item,  .y = frame t | (need - 1) << 10 | item << 20
-    // Input and output share the row space (TpIn / TpOut / T unused); a tap that reaches beyond the item's last stored frame
-    // reads that last frame instead (it can only feed frames that are themselves beyond nvalid).  null = dense mapping.
+    // g enumerates the OUTPUT rows; .x and the "last stored frame" refer to the INPUT buffer, which may live in a wider row
+    // space of `in_rows` rows (0 = the same space, M rows): the 1x1 MFA layer reads the rows with their receptive-field margin
+    // and writes only the frames < nvalid.  TpIn / TpOut / T are unused; a tap that reaches beyond the item's last stored
+    // frame reads that last frame instead (it can only feed frames that are themselves beyond nvalid).  null = dense mapping.
     const int2* rowtab;
+    int in_rows;
     int prec;              // 0 = f32 (X, X2, W, Y are float), 1 = fp16 end to end (X, X2, W16, Y are _Float16; option ecapa_precision)
 };
 #define ROWTAB_T(y) ((y) & 1023)
@@ -168,8 +171,9 @@ int frontend_features(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_it
                       const int* d_rowoff, float* d_feats /*[rowoff[run_items]][96]*/);
 // ---- ecapa.hip
 int ecapa_need_rows(int nvalid, bool skip_dead_rows);
-int ecapa_row_plan(sd_ctx* c, const int* h_nvalid, int64_t n, std::vector<int>& rowoff, int* d_rowoff /*[n + 1]*/);
-int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, int64_t items, int64_t rows, float* d_emb);
+int ecapa_row_plan(sd_ctx* c, const int* h_nvalid, int64_t n, std::vector<int>& rowoff, std::vector<int>& rowoffN, int* d_rowoff /*[2][n + 1]: wide, narrow*/);
+int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, const int* d_rowoffN, int row_baseN,
+              int64_t items, int64_t rows, int64_t rowsN, float* d_emb);
 int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item, float* d_emb);
 // ---- pyannet.hip
 int run_segment(sd_ctx* c, const float* d_wav, int64_t n, int64_t chunk_lo, int64_t chunk_hi, float* d_seg);

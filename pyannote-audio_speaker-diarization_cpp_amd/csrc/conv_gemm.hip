@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     int rrel[4], tt[4], nd[4];          // per part: item offset (rows) relative to the tile's first item, clamped frame, last stored frame
     unsigned voA[4], voX[HAS_X2 ? 4 : 1], voB[4];
     const bool RT = a.rowtab != nullptr;                     // compact row space (see ConvArgs)
-    const size_t in_rows = RT ? (size_t)a.M : (size_t)((a.M + a.TpOut - 1) / a.TpOut) * a.TpIn;
+    const size_t in_rows = RT ? (size_t)(a.in_rows > 0 ? a.in_rows : a.M) : (size_t)((a.M + a.TpOut - 1) / a.TpOut) * a.TpIn;
     // row-table entries of the tile the load stream visits NEXT: fetched one tile ahead, so a tile switch never waits for them
     int2 pre[4]; int pre_base = 0;
     auto prefetch_tab = [&](int sb) {

@@ -133,12 +133,14 @@ __global__ void k_scatter_emb(const float* __restrict__ emb_c, const int* __rest
     emb[idx] = (a >= 0) ? emb_c[(size_t)a * SD_EMB_DIM + (idx - item * SD_EMB_DIM)] : __int_as_float(0x7fc00000);
 }
 
-// rowtab[g] of every compact row of the batch (see ConvArgs): one workgroup per item
-__global__ void k_build_rowtab(const int* __restrict__ rowoff, int row_base, int2* __restrict__ rowtab)
+// rowtab[g] of every row g of the OUTPUT space of the batch (see ConvArgs): first row / last stored frame of the item in the
+// INPUT space; one workgroup per item
+__global__ void k_build_rowtab(const int* __restrict__ rowoff_out, int base_out, const int* __restrict__ rowoff_in, int base_in, int2* __restrict__ rowtab)
 {
     const int item = blockIdx.x;
-    const int r0 = rowoff[item] - row_base, need = rowoff[item + 1] - rowoff[item];
-    for (int t = threadIdx.x; t < need; t += blockDim.x) rowtab[r0 + t] = make_int2(r0, t | ((need - 1) << 10) | (item << 20));
+    const int r0 = rowoff_out[item] - base_out, n_out = rowoff_out[item + 1] - rowoff_out[item];
+    const int i0 = rowoff_in[item] - base_in, n_in = rowoff_in[item + 1] - rowoff_in[item];
+    for (int t = threadIdx.x; t < n_out; t += blockDim.x) rowtab[r0 + t] = make_int2(i0, t | ((n_in - 1) << 10) | (item << 20));
 }
 
 // fp16 feature rows for the fp16 mode: [rows][96] f32 -> [rows][128] halves (block0's K-step is 64 halves)
@@ -179,9 +181,13 @@ int ecapa_need_rows(int nvalid, bool skip_dead_rows)
 }
 
 // d_feats: compact rows [rows][96] of `items` items; d_rowoff[items + 1] (first compact row of every item, in a row space that
-// starts at row_base for this batch); d_nvalid[items]
+// starts at row_base for this batch); d_nvalid[items].  Two row spaces: the WIDE one (need_i = nvalid_i + receptive-field margin)
+// carries block0 and the three SE-Res2Net blocks; MFA is a 1x1 layer whose output is only ever read at frames < nvalid (ASP
+// statistics and pooling), so it reads wide rows and writes the NARROW space (nvalid_i rows per item, d_rowoffN / row_baseN /
+// rowsN), in which the ASP layers then run: 17 % fewer rows for half of the network's FLOPs on the planted hour.
 template <class T>
-static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, int64_t items, int64_t rows, float* d_emb)
+static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, const int* d_rowoffN, int row_baseN,
+                       int64_t items, int64_t rows, int64_t rowsN, float* d_emb)
 {
     constexpr int P = sizeof(T) == 2 ? 1 : 0;                  // conv_gemm precision of the per-frame layers
     const EcapaWeights& E = c->ew;
@@ -196,8 +202,9 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, con
     WS(c, T, rr, "ec_r", M * C);
     WS(c, T, t2, "ec_t2", M * C);
     WS(c, T, cat, "ec_cat", M * C3);
-    WS(c, T, mfa, "ec_mfa", M * C3);
-    WS(c, T, hid, "ec_hid", M * 128);
+    const int64_t MN = rowsN;
+    WS(c, T, mfa, "ec_mfa", MN * C3);
+    WS(c, T, hid, "ec_hid", MN * 128);
     WS(c, float, se_s, "ec_se_s", items * C);
     WS(c, float, se_h, "ec_se_h", items * 128);
     WS(c, float, se_g, "ec_se_g", items * C);
@@ -205,9 +212,13 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, con
     WS(c, float, ib, "ec_ib", items * 128);
     WS(c, float, pooled, "ec_pooled", items * 2 * C3);
     WS(c, int2, rowtab, "ec_rowtab", M + 128);
+    WS(c, int2, rowtab_nw, "ec_rowtab_nw", MN + 128);          // narrow rows -> wide input (MFA)
+    WS(c, int2, rowtab_n, "ec_rowtab_n", MN + 128);            // narrow -> narrow (ASP layers)
     int rc;
     hipStream_t st = c->stream;
-    hipLaunchKernelGGL(k_build_rowtab, dim3((unsigned)items), dim3(256), 0, st, d_rowoff, row_base, rowtab);
+    hipLaunchKernelGGL(k_build_rowtab, dim3((unsigned)items), dim3(256), 0, st, d_rowoff, row_base, d_rowoff, row_base, rowtab);
+    hipLaunchKernelGGL(k_build_rowtab, dim3((unsigned)items), dim3(256), 0, st, d_rowoffN, row_baseN, d_rowoff, row_base, rowtab_nw);
+    hipLaunchKernelGGL(k_build_rowtab, dim3((unsigned)items), dim3(256), 0, st, d_rowoffN, row_baseN, d_rowoffN, row_baseN, rowtab_n);
     KCHECK(c);
 #define WITH_LIST(a) do { (a).rowtab = rowtab; } while (0)
 
@@ -251,20 +262,20 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, con
         }
     }
     // mfa: TDNNBlock(3C -> 3C, k1) over cat(x1,x2,x3)
-    { ConvArgs a = conv_args(E.mfa, cat, C3, mfa, C3, M, true, P); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
+    { ConvArgs a = conv_args(E.mfa, cat, C3, mfa, C3, MN, true, P); a.act1 = 1; a.rowtab = rowtab_nw; a.in_rows = (int)M; if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
     // ASP with global context: cat[x, mean, std] @ W == x @ Wx + (mean,std) @ Wms  (per-item bias)
     {
-        ProfScope ps(c, "asp_stats", 0, (double)M * C3 * 4.0);
-        hipLaunchKernelGGL(k_asp_stats<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, C3, d_nvalid, d_rowoff, row_base, ms, C3);
+        ProfScope ps(c, "asp_stats", 0, (double)MN * C3 * 4.0);
+        hipLaunchKernelGGL(k_asp_stats<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, C3, d_nvalid, d_rowoffN, row_baseN, ms, C3);
         KCHECK(c);
     }
     { ConvArgs a = conv_args(E.asp_tdnn_ms, ms, 2 * C3, ib, 128, items, false); if ((rc = launch_conv_gemm(c, a, "asp_ms"))) return rc; }
-    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, C3, hid, 128, M, true, P); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
+    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, C3, hid, 128, MN, true, P); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; a.rowtab = rowtab_n; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
     T* logits = cat;   // cat is dead after mfa
-    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, M, true, P); WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
+    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, MN, true, P); a.rowtab = rowtab_n; if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
     {
-        ProfScope ps(c, "asp_pool", 0, (double)M * C3 * 8.0);
-        hipLaunchKernelGGL(k_asp_pool<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, C3, d_nvalid, d_rowoff, row_base, pooled, C3);
+        ProfScope ps(c, "asp_pool", 0, (double)MN * C3 * 8.0);
+        hipLaunchKernelGGL(k_asp_pool<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, C3, d_nvalid, d_rowoffN, row_baseN, pooled, C3);
         KCHECK(c);
     }
     // asp_bn folded into fc
@@ -272,21 +283,29 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, con
     return SD_OK;
 }
 
-int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, int64_t items, int64_t rows, float* d_emb)
+int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, const int* d_rowoffN, int row_baseN,
+              int64_t items, int64_t rows, int64_t rowsN, float* d_emb)
 {
-    if (c->ecapa_precision == 1) return run_ecapa_t<_Float16>(c, d_feats, d_nvalid, d_rowoff, row_base, items, rows, d_emb);
-    return run_ecapa_t<float>(c, d_feats, d_nvalid, d_rowoff, row_base, items, rows, d_emb);
+    if (c->ecapa_precision == 1) return run_ecapa_t<_Float16>(c, d_feats, d_nvalid, d_rowoff, row_base, d_rowoffN, row_baseN, items, rows, rowsN, d_emb);
+    return run_ecapa_t<float>(c, d_feats, d_nvalid, d_rowoff, row_base, d_rowoffN, row_baseN, items, rows, rowsN, d_emb);
 }
 
 // host side of the compact row plan: need / rowoff of `n` items from their nvalid (uploaded to d_rowoff[n + 1])
-int ecapa_row_plan(sd_ctx* c, const int* h_nvalid, int64_t n, std::vector<int>& rowoff, int* d_rowoff)
+// rowoff: wide space (need rows per item), rowoffN: narrow space (nvalid rows per item; = wide when nothing is skipped)
+int ecapa_row_plan(sd_ctx* c, const int* h_nvalid, int64_t n, std::vector<int>& rowoff, std::vector<int>& rowoffN, int* d_rowoff)
 {
-    rowoff.assign((size_t)n + 1, 0);
-    int64_t acc = 0;
-    for (int64_t i = 0; i < n; ++i) { rowoff[(size_t)i] = (int)acc; acc += ecapa_need_rows(h_nvalid[i], c->skip_dead_rows); }
+    rowoff.assign((size_t)n + 1, 0); rowoffN.assign((size_t)n + 1, 0);
+    int64_t acc = 0, accN = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        rowoff[(size_t)i] = (int)acc; rowoffN[(size_t)i] = (int)accN;
+        const int need = ecapa_need_rows(h_nvalid[i], c->skip_dead_rows);
+        int nv = h_nvalid[i]; if (nv > need) nv = need; if (nv < 1) nv = 1;
+        acc += need; accN += c->skip_dead_rows ? nv : need;
+    }
     if (acc > 0x7fffffff / 4) SD_FAIL(c, SD_ERR_ARG, "embedding stage: %lld feature rows in one shard (limit %d)", (long long)acc, 0x7fffffff / 4);
-    rowoff[(size_t)n] = (int)acc;
+    rowoff[(size_t)n] = (int)acc; rowoffN[(size_t)n] = (int)accN;
     HIPCHK(c, hipMemcpyAsync(d_rowoff, rowoff.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_rowoff + n + 1, rowoffN.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SD_OK;
 }
@@ -304,16 +323,17 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
     WS(c, int, nvalid, "emb_nvalid", items);
     WS(c, int, flags, "emb_flags", items);
     WS(c, int, cidx, "emb_cidx", items);
-    WS(c, int, d_rowoff, "emb_rowoff", items + 1);
+    WS(c, int, d_rowoff, "emb_rowoff", 2 * (items + 1));
     WS(c, float, emb_c, "emb_compact", items * SD_EMB_DIM);
     int n_active = 0;
     if ((rc = frontend_prepare(c, d_masks, items, first_item, lens, nnorm, nvalid, flags, true, &n_active, cidx))) return rc;
     { KernelStat& ks = c->stats["items_live"]; ks.launches++; ks.flops += (double)n_active; ks.bytes += (double)items; }   // bench: live / all items
     if (n_active > 0) {
-        std::vector<int> h_nvalid((size_t)n_active), rowoff;
+        std::vector<int> h_nvalid((size_t)n_active), rowoff, rowoffN;
         HIPCHK(c, hipMemcpyAsync(h_nvalid.data(), nvalid, (size_t)n_active * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if ((rc = ecapa_row_plan(c, h_nvalid.data(), n_active, rowoff, d_rowoff))) return rc;
+        if ((rc = ecapa_row_plan(c, h_nvalid.data(), n_active, rowoff, rowoffN, d_rowoff))) return rc;
+        const int* d_rowoffN = d_rowoff + n_active + 1;
         const int64_t rows_all = rowoff[(size_t)n_active];
         WS(c, float, feats, "emb_feats", rows_all * SD_FEAT_LD);
         if ((rc = frontend_features(c, d_wav, n, first_item, n_active, true, nnorm, d_rowoff, feats))) return rc;
@@ -323,9 +343,9 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
             int64_t a1 = a0;
             while (a1 < n_active && a1 - a0 < ROWTAB_MAX_ITEMS && rowoff[(size_t)a1 + 1] - rowoff[(size_t)a0] <= cap_rows) ++a1;
             if (a1 == a0) a1 = a0 + 1;
-            const int base = rowoff[(size_t)a0];
-            if ((rc = run_ecapa(c, feats + (size_t)base * SD_FEAT_LD, nvalid + a0, d_rowoff + a0, base, a1 - a0, rowoff[(size_t)a1] - base,
-                                emb_c + (size_t)a0 * SD_EMB_DIM))) return rc;
+            const int base = rowoff[(size_t)a0], baseN = rowoffN[(size_t)a0];
+            if ((rc = run_ecapa(c, feats + (size_t)base * SD_FEAT_LD, nvalid + a0, d_rowoff + a0, base, d_rowoffN + a0, baseN, a1 - a0,
+                                rowoff[(size_t)a1] - base, rowoffN[(size_t)a1] - baseN, emb_c + (size_t)a0 * SD_EMB_DIM))) return rc;
             a0 = a1;
         }
     }
