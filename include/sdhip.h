@@ -192,7 +192,7 @@ int sd_format_turn(const sd_turn* t, char* buf, int cap);
 int sd_stage_ms(const sd_ctx*, double* ms4);
 int sd_kernel_stats(const sd_ctx*, const char* kernel, double* total_ms, int64_t* launches, double* flops, double* bytes);
 void sd_reset_stats(sd_ctx*);
-/* keys: "emb_batch_items", "seg_batch_chunks", "profile", "linkage_wgs" (-1 auto, 0 one workgroup), "linkage_threads",
+/* keys: "emb_batch_items", "seg_batch_chunks", "profile", "linkage_wgs" (-1 auto, 0 one workgroup), "linkage_threads", "linkage_one_xcd",
  * "skip_dead_rows", "num_clusters", "min_clusters", "max_clusters", "ecapa_precision" (0 = f32 MFMA, 1 = fp16 MFMA),
  * "rank0_permille" (sd_diarize_sharded: share of rank 0, -1 = equal), "virtual_world" (test mode: a communicator of ONE rank plays all W
  * ranks of the plan in turn, slot by slot, so plan + slot assembly of a W-GPU job run on a 1-GPU box), "constrained_assignment" (1 = constrained_argmax of

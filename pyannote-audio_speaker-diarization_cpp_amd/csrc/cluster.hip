@@ -396,6 +396,15 @@ __device__ __forceinline__ bool mw_barrier(unsigned* counter, unsigned target, u
 // each workgroup's private state (cluster sizes, freshness flags) stays cached.
 template <class T> __device__ __forceinline__ T LDG(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void STG(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// One-XCD form (k_linkage_mw<true>): every participating workgroup sits on the SAME XCD (checked in the kernel from
+// HW_REG_XCC_ID, not assumed), so that XCD's L2 is the point of coherence: stores stay plain -- they write through the CU's L1
+// and KEEP the line in the L2 (an sc1 store drops it, and even a same-XCD reader then pays the cross-XCD round trip) -- while
+// loads stay sc1 (bypass the reader's L1, served by the L2).  MI355X_MICROARCH.md, table of store / load flavours.
+template <bool ONEX, class T> __device__ __forceinline__ void STX(T* p, T v)
+{
+    if constexpr (ONEX) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ MinIdx block_min_t(MinIdx m, MinIdx* sh, int nwaves)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -470,9 +479,10 @@ __device__ __forceinline__ Cand block_min_c(Cand m, Cand* sh, int nwaves)
 #define SLOT_WORDS 32
 typedef unsigned long long MwGran;
 
+template <bool ONEX>
 __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* size_all, int* cid, int* nb, double* md,
                                                          unsigned char* fresh_flag, double* Z, MwGran* gran /*[2][G][SLOT_WORDS], zeroed*/,
-                                                         unsigned* sync, int cap /*owned rows per workgroup, upper bound*/)
+                                                         unsigned* sync, int cap /*owned rows per workgroup, upper bound*/, int G)
 {
     extern __shared__ int dyn_lds[];
     int* act = dyn_lds;              // [cap] owned active rows, unordered
@@ -490,8 +500,22 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     __shared__ Cand s_best;
     __shared__ MinIdx s_nn;
     __shared__ int s_rowtie;
-    const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int T = blockDim.x, NW = T >> 6;
+    int g = blockIdx.x;
+    if constexpr (ONEX) {
+        // 8 G workgroups were launched; the first G that find themselves on XCC 0 take part (rank = ticket), the others leave.
+        // Under round-robin dispatch exactly the G workgroups with blockIdx % 8 == 0 qualify; under any other dispatch too few
+        // may arrive and the participants run into the poll timeout -- run_linkage then repeats the job with the multi-XCD form.
+        __shared__ int s_ticket;
+        if (tid == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));       // HW_REG_XCC_ID[3:0]
+            s_ticket = (xcc == 0) ? (int)atomicAdd(&sync[6], 1u) : -1;
+        }
+        __syncthreads();
+        g = s_ticket;
+        if (g < 0 || g >= G) return;
+    }
     const int64_t N = n;
     int* size = size_all + (size_t)g * n;
     unsigned bar = 0;
@@ -595,14 +619,14 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         const MwGran tag = (MwGran)bar << 32;
         if (tid == 0) {
             const unsigned long long av = (unsigned long long)__double_as_longlong(m.v), nv = (unsigned long long)__double_as_longlong(q.v);
-            STG(&sl[0], tag | (unsigned)av); STG(&sl[1], tag | (unsigned)(av >> 32)); STG(&sl[2], tag | (unsigned)m.i);
-            STG(&sl[3], tag | (unsigned)m.y); STG(&sl[4], tag | (unsigned)m.fresh);
-            STG(&sl[5], tag | (unsigned)nv); STG(&sl[6], tag | (unsigned)(nv >> 32)); STG(&sl[7], tag | (unsigned)q.i);
-            if (nL == 0) STG(&sl[8], tag | (unsigned)row_tie);          // rounds without refreshed rows: word 8 = "row x had a second pair at the merge height"
+            STX<ONEX>(&sl[0], tag | (unsigned)av); STX<ONEX>(&sl[1], tag | (unsigned)(av >> 32)); STX<ONEX>(&sl[2], tag | (unsigned)m.i);
+            STX<ONEX>(&sl[3], tag | (unsigned)m.y); STX<ONEX>(&sl[4], tag | (unsigned)m.fresh);
+            STX<ONEX>(&sl[5], tag | (unsigned)nv); STX<ONEX>(&sl[6], tag | (unsigned)(nv >> 32)); STX<ONEX>(&sl[7], tag | (unsigned)q.i);
+            if (nL == 0) STX<ONEX>(&sl[8], tag | (unsigned)row_tie);          // rounds without refreshed rows: word 8 = "row x had a second pair at the merge height"
         }
         if (tid < nL) {
             const unsigned long long pv = (unsigned long long)__double_as_longlong(rows[tid].v);
-            STG(&sl[8 + 3 * tid], tag | (unsigned)pv); STG(&sl[9 + 3 * tid], tag | (unsigned)(pv >> 32)); STG(&sl[10 + 3 * tid], tag | (unsigned)rows[tid].i);
+            STX<ONEX>(&sl[8 + 3 * tid], tag | (unsigned)pv); STX<ONEX>(&sl[9 + 3 * tid], tag | (unsigned)(pv >> 32)); STX<ONEX>(&sl[10 + 3 * tid], tag | (unsigned)rows[tid].i);
         }
     };
     auto word_d = [&](int sl, int wd) -> double {
@@ -646,7 +670,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         // owners store the refreshed rows (read back only by the owner's later arg-mins)
         if (tid < nLprev && (Lprev[tid] % G) == g) {
             const int x = Lprev[tid]; const MinIdx q = s_row[tid];
-            STG(&nb[x], q.i); STG(&md[x], (q.i < 0) ? (double)INFINITY : q.v); fresh_flag[x] = 1;
+            STX<ONEX>(&nb[x], q.i); STX<ONEX>(&md[x], (q.i < 0) ? (double)INFINITY : q.v); fresh_flag[x] = 1;
         }
         __syncthreads();
     };
@@ -790,15 +814,15 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                 const int z = zz[u];
                 if (z < 0) continue;
                 const double nd = lw_centroid(dzx[u], dzy[u], dist, nx, ny);
-                STG(&D[izy[u]], nd);
+                STX<ONEX>(&D[izy[u]], nd);
                 if (z > x && dzx[u] == dist) row_tie = 1;         // row x had a second neighbour at exactly the merge height
                 double mz = (z < n - 1) ? mdz[u] : INFINITY; int nz = nbz[u], fz = frz[u];
                 if (z < y) {
                     bool touch = false;
                     if (z < x && nz == x) { nz = y; touch = true; }
                     else if (nz == y) touch = true;
-                    if (nd < mz) { nz = y; mz = nd; fz = 1; STG(&md[z], nd); STG(&nb[z], y); fresh_flag[z] = 1; }
-                    else if (touch) { fz = (mz == nd); STG(&nb[z], nz); fresh_flag[z] = (unsigned char)fz; }
+                    if (nd < mz) { nz = y; mz = nd; fz = 1; STX<ONEX>(&md[z], nd); STX<ONEX>(&nb[z], y); fresh_flag[z] = 1; }
+                    else if (touch) { fz = (mz == nd); STX<ONEX>(&nb[z], nz); fresh_flag[z] = (unsigned char)fz; }
                 } else if (nd < q.v || (nd == q.v && z < q.i)) { q.v = nd; q.i = z; }
                 if (z < n - 1) cand_acc(m, mz, z, nz, fz);
             }
@@ -822,7 +846,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         if (y < n - 1) {
             if (nn.i >= 0) {
                 cy.v = nn.v; cy.i = y; cy.y = nn.i; cy.fresh = 1;
-                if (tid == 0 && (y % G) == g) { STG(&nb[y], nn.i); STG(&md[y], nn.v); fresh_flag[y] = 1; }
+                if (tid == 0 && (y % G) == g) { STX<ONEX>(&nb[y], nn.i); STX<ONEX>(&md[y], nn.v); fresh_flag[y] = 1; }
             } else {
                 cy.v = LDG(&md[y]); cy.i = y; cy.y = LDG(&nb[y]); cy.fresh = 0;
                 if (tid == 0 && (y % G) == g) fresh_flag[y] = 0;
@@ -927,15 +951,21 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     int rc;
     if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md))) return rc;
     int G = (int)c->linkage_wgs;
-    if (G < 0) G = N >= 60000 ? 128 : N >= 8000 ? 64 : N >= 1500 ? 32 : 0;      // auto (measured on clustered data, profiles/r01_linkage_scaling.txt, r02_linkage_stamps.txt)
+    // auto geometry (measured on clustered data, profiles/r01_linkage_scaling.txt, r02_linkage_stamps.txt): up to N = 30 000 the
+    // one-XCD form with one workgroup on each of the XCD's 32 CUs (172 ms at N = 12 602; all XCDs: 188 ms with 64 x 512)
+    const bool auto_onex = G < 0 && c->linkage_one_xcd != 0 && c->num_cu >= 256 && N >= 1500 && N < 30000;
+    if (auto_onex) G = 32;
+    if (G < 0) G = N >= 60000 ? 128 : N >= 8000 ? 64 : N >= 1500 ? 32 : 0;
     if (G > c->num_cu) G = c->num_cu;
     int TH = (int)c->linkage_threads;
-    if (TH <= 0) TH = N >= 8000 ? 512 : 256;           // measured: 188 vs 195 ms at N = 12 602, 327 vs 337 ms at N = 21 573, 4.68 vs 4.85 s at N = 172 773
+    if (TH <= 0) TH = (N >= 8000 || auto_onex) ? 512 : 256;           // measured: 188 vs 195 ms at N = 12 602, 327 vs 337 ms at N = 21 573, 4.68 vs 4.85 s at N = 172 773
     TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : 256;
     if (G <= 1) return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
     if ((N + G - 1) / G > 7000) G = (int)((N + 6999) / 7000);      // active-row lists live in LDS: 8 B per owned row
     if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
     int cap = (int)((N + G - 1) / G) + 1;
+    // one-XCD form while two workgroups per CU of one XCD (32 CUs) can hold the job; above, all XCDs' memory pipelines are worth more
+    bool onex = c->linkage_one_xcd != 0 && G <= 32 && c->num_cu >= 256;
     WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * SLOT_WORDS);
     HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * SLOT_WORDS * sizeof(MwGran), c->stream));
     WS(c, int, size_all, "cl_size_all", (int64_t)G * N);
@@ -948,9 +978,14 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     {
         ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
         int n_i = (int)N;
-        void* args[] = {&D, &n_i, &size_all, &cid, &nb, &md, &fresh_flag, &d_Z, &gran, &sync, &cap};
-        // cooperative launch: all G workgroups are resident together, or the launch is refused (they poll each other's slots)
-        const hipError_t le = hipLaunchCooperativeKernel((const void*)k_linkage_mw, dim3(G), dim3(TH), args, (size_t)cap * 8, c->stream);
+        void* args[] = {&D, &n_i, &size_all, &cid, &nb, &md, &fresh_flag, &d_Z, &gran, &sync, &cap, &G};
+        // cooperative launch: all workgroups are resident together, or the launch is refused (they poll each other's slots)
+        hipError_t le = hipErrorUnknown;
+        if (onex) {
+            le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<true>, dim3(8 * G), dim3(TH), args, (size_t)cap * 8, c->stream);
+            if (le != hipSuccess) { (void)hipGetLastError(); onex = false; }
+        }
+        if (!onex) le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<false>, dim3(G), dim3(TH), args, (size_t)cap * 8, c->stream);
         if (le != hipSuccess) { (void)hipGetLastError(); why = "cooperative launch refused"; }
     }
     unsigned h[16] = {0};
@@ -961,6 +996,13 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
 #ifdef SD_LINKAGE_STAMPS
         fprintf(stderr, "linkage stamps (us): retry-scan %u retry-argmin %u barrier %u digest %u pick %u bookkeeping %u lw %u reductions %u\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
 #endif
+        if (h[1] && onex) {
+            // too few workgroups found themselves on XCC 0 (dispatch not round-robin?): never again in this context; the
+            // multi-XCD form does the job (the distance matrix is rebuilt by the recursive call)
+            c->linkage_one_xcd = 0;
+            c->stats["linkage_one_xcd_timeouts"].launches += 1;
+            return run_linkage(c, d_X, N, d, d_Z);
+        }
         if (h[1]) why = "slot poll timed out";
         else if (h[5]) { why = "exact tie"; c->stats["linkage_tie_fallbacks"].launches += 1; }
     }

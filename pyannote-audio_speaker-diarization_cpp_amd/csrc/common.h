@@ -116,6 +116,7 @@ struct sd_ctx {
     int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation
     bool skip_dead_rows = true;                 // ECAPA: skip row panels beyond nvalid + receptive field
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
+    int64_t linkage_one_xcd = 1;               // 1 = k_linkage_mw<true> (all workgroups on one XCD) when G <= 64
     int64_t linkage_threads = 0;               // 0 auto (256, or 1024 for N >= 60000), else 256 / 512 / 1024 threads per cooperative workgroup
     int num_cu = 256;
     bool constrained_assignment = false;        // Clustering.py:81-94 (one cluster per local speaker of a chunk)

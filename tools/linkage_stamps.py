@@ -20,6 +20,9 @@ N = len(X)
 d = sdhip.Diarizer(None, None)
 d.set_option("profile", 1)
 Z0 = None
+onex = int(os.environ.get("ONEX", "1"))
+d.set_option("linkage_one_xcd", onex)
+print("linkage_one_xcd", onex)
 for G, T in combos:
     d.set_option("linkage_wgs", G); d.set_option("linkage_threads", T)
     d.reset_stats()
@@ -27,4 +30,5 @@ for G, T in combos:
     st = d.kernel_stats("linkage")
     rr = d.kernel_stats("linkage_retry_rounds")["flops"]
     if Z0 is None: Z0 = Z
+    print("one-XCD timeouts", d.kernel_stats("linkage_one_xcd_timeouts")["launches"], end="  ")
     print("N=%d G=%3d T=%4d linkage %.1f ms (%.2f us/merge) retry rounds %d same %s" % (N, G, T, st["ms"], st["ms"] * 1e3 / (N - 1), rr, np.array_equal(Z, Z0)), flush=True)
