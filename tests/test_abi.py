@@ -104,3 +104,14 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip() == "109 80000|[5.22281 -- 17.7441] --> Speaker_10|3616 0 3616 3616 7191|0 1 0|128"
+
+
+def test_reference_side_binding_of_seam4_compiles_against_the_reference_header(tmp_path):
+    """INTEGRATION.md seam 4 as a compilable file: Clustering::cluster / ::linkage re-implemented on sd_cluster / sd_linkage must
+    match the reference's own clustering.h (signatures, constness) and include/sdhip.h"""
+    import subprocess
+    ref = "/root/reference/pipeline/src/clustering"
+    if not os.path.exists(os.path.join(ref, "clustering.h")):
+        pytest.skip("reference tree absent (GPU box)")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-include", "vector", "-include", "algorithm", "-include", "cstdint", "-I", ref,
+                           "-I", os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "oracle", "ref_build", "seam4_binding.cpp"), "-o", str(tmp_path / "seam4.o")])
