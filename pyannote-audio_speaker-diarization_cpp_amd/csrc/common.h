@@ -114,6 +114,7 @@ struct sd_ctx {
     int64_t seg_batch_chunks = 4096;           // 128 LSTM workgroups per direction: one full wave of CUs
     int num_clusters = -1, min_clusters = -1, max_clusters = -1;   // optional constraints for the whole-path entry points
     int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation
+    bool conv_h256 = true;                      // fp16 mode: 256 x 256 tile kernel for the wide layers (conv_gemm_h.hip)
     bool skip_dead_rows = true;                 // ECAPA: skip row panels beyond nvalid + receptive field
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
     int64_t linkage_one_xcd = 1;               // 1 = k_linkage_mw<true> (all workgroups on one XCD) when G <= 64
@@ -158,6 +159,8 @@ void sd_flush_profile(sd_ctx* c);   // api.cpp: resolves pending event pairs int
 
 // ---- conv_gemm.hip
 int launch_conv_gemm(sd_ctx* c, const ConvArgs& a, const char* tag);
+// ---- conv_gemm_h.hip (fp16 mode, Cout >= 256: 256 x 256 tile; returns 1 = not applicable)
+int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- weights.cpp
 struct PackTensor { std::vector<int64_t> dims; std::vector<float> data; };
 typedef std::map<std::string, PackTensor> Pack;

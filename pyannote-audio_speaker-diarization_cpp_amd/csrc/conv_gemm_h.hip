@@ -1,0 +1,282 @@
+// conv_gemm_h.hip -- the fp16 mode's wide layers (Cout >= 256: block0, TDNN, MFA, ASP conv) on a 256 x 256 tile.
+//
+// conv_gemm.hip's fp16 instantiation keeps the f32 kernel's geometry: 128 x 128 tile, 4 waves of 64 x 64.  With
+// v_mfma_f32_32x32x16_f16 a K-step of 64 halves is only 16 MFMAs = 512 cycles per wave, and every MFMA needs one
+// ds_read_b128 of operand fragments: that kernel is bound by LDS traffic and by the L2 round trip of its load stream, not
+// by the matrix pipe (profiles/r02_layer_profile.txt).  Here one workgroup of 8 waves owns 256 x 256 outputs and each wave
+// 64 rows x 128 columns (2 x 4 MFMA tiles, 128 accumulator registers): 6 fragment reads feed 8 MFMAs (0.75 per MFMA
+// instead of 1), every staged byte feeds twice as many MFMAs (half the LDS writes and half the L2 reads per FLOP), and a
+// K-step is 32 MFMAs per wave between barriers.  LDS: 2 stages x (256 + 256) rows x 144 B = 144 KB, one workgroup per CU.
+//
+// Everything else is conv_gemm.hip's design: channels-last fp16 rows in the compact row space (rowtab), weights
+// [tap][Cout][CinPad16] fp16, buffer loads with the K position as scalar offset, a load stream one K-step ahead that runs
+// across tile boundaries, persistent PM x PN super-blocks per XCD, f32 epilogue (bias, ReLU / leaky, folded BN) with the
+// 4 x 4 quad transpose and one rounding to fp16 at the store.  Only what the ECAPA layers need is implemented: compact row
+// space, "same" reflect padding, no second input, no per-item bias, no tanh / sigmoid.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+#define HM 256
+#define HN 256
+#define HLDP 36            // LDS row: 64 halves + 8 halves of padding = 36 floats = 144 B (conflict-free ds_read_b128, see conv_gemm.hip)
+
+__global__ __launch_bounds__(512) void k_conv_gemm_h256(ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const As0 = lds;                          // [2][HM * HLDP]
+    float* const Bs0 = lds + 2 * HM * HLDP;          // [2][HN * HLDP]
+
+    const int w = blockIdx.x, G = gridDim.x;         // G is a multiple of 8
+    const int xcd = w & 7, wl = w >> 3, wpx = G >> 3;
+    const int mx = (a.m_tiles - xcd + 7) >> 3;       // row panels of this XCD: m = xcd + 8 j
+    const int PN = a.n_tiles < 8 ? a.n_tiles : 8;
+    const int PM = wpx / PN > 0 ? wpx / PN : 1;
+    const int pm = wl / PN, pn = wl - pm * PN;
+    if (pm >= PM) return;
+    const int n_groups = (a.n_tiles + PN - 1) / PN, m_groups = (mx + PM - 1) / PM;
+    const int sb_end = n_groups * m_groups;
+    auto sb_valid = [&](int sb, int& j, int& nt) -> bool {
+        const int mg = sb / n_groups, ng = sb - mg * n_groups;
+        j = mg * PM + pm; nt = ng * PN + pn;
+        return j < mx && nt < a.n_tiles;
+    };
+    auto next_sb = [&](int sb) -> int {
+        int j, nt;
+        for (++sb; sb < sb_end; ++sb) if (sb_valid(sb, j, nt)) return sb;
+        return sb_end;
+    };
+    const int q0 = next_sb(-1);
+    if (q0 >= sb_end) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;           // wave tile: rows wr * 64, columns wc * 128
+    const int c4 = tid & 7, r0 = tid >> 3;           // loader: 16-byte chunk c4 of row r0 + 64 p
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int kcs = a.Cin / 64;
+    const int S = a.KT * kcs;
+    const int half = a.KT / 2;
+    const size_t in_rows = (size_t)(a.in_rows > 0 ? a.in_rows : a.M);
+
+    int rrel[4], tt[4], nd[4];
+    unsigned voA[4], voB[4];
+    int2 pre[4]; int pre_base = 0;
+    auto prefetch_tab = [&](int sb) {
+        int j, nt;
+        (void)sb_valid(sb, j, nt);
+        const int m0 = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * HM);
+        pre_base = a.rowtab[m0 < a.M ? m0 : a.M - 1].x;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { int g = m0 + r0 + 64 * p; if (g > a.M - 1) g = a.M - 1; pre[p] = a.rowtab[g]; }
+    };
+    auto make_rsrc = [&](const void* base, size_t bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t rA = make_rsrc(a.X, 0);
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(a.W16, (size_t)a.KT * a.Cout * a.w_ld * 2);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)((r0 + 64 * p) * a.w_ld * 2 + c4 * 16);
+    int l_q = q0, l_kk = 0, l_kc = 0, m0l = 0, n0l = 0;
+    unsigned sK = 0, sB = 0;
+    auto set_tile = [&](int sb) {
+        int j, nt;
+        (void)sb_valid(sb, j, nt);
+        m0l = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * HM);
+        n0l = __builtin_amdgcn_readfirstlane(nt * HN);
+        const int base = __builtin_amdgcn_readfirstlane(pre_base);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { rrel[p] = pre[p].x - base; tt[p] = ROWTAB_T(pre[p].y); nd[p] = ROWTAB_LAST(pre[p].y); }
+        rA = make_rsrc((const char*)a.X + (size_t)base * a.x_ld * 2, (in_rows - base) * a.x_ld * 2);
+    };
+    auto set_tap = [&](int kk) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int qr = tt[p] + (kk - half) * a.dil;
+            if (qr < 0) qr = -qr;
+            if (qr >= a.Tin) qr = 2 * (a.Tin - 1) - qr;
+            if (qr < 0) qr = 0;
+            if (qr > nd[p]) qr = nd[p];
+            voA[p] = (unsigned)(rrel[p] + qr) * (unsigned)a.x_ld * 2 + c4 * 16;
+        }
+        // weight rows beyond Cout (a 256-wide tile over Cout = 1024 / 3072 never has any) are clamped by the descriptor
+        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * 2);
+    };
+    auto advance = [&]() {
+        if (++l_kc < kcs) { sK += 128; return; }
+        l_kc = 0; sK = 0;
+        if (++l_kk == a.KT) {
+            l_kk = 0;
+            const int nq = next_sb(l_q);
+            if (nq < sb_end) {
+                l_q = nq; set_tile(l_q);
+                const int nq2 = next_sb(l_q);
+                if (nq2 < sb_end) prefetch_tab(nq2);
+            }
+        }
+        set_tap(l_kk);
+    };
+    f4u ra[4], rb[4];
+    auto gload = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p], sK, 0));
+            rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sB + sK, 0));
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* A = As0 + buf * HM * HLDP; float* B = Bs0 + buf * HN * HLDP;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *(float4*)&A[(r0 + 64 * p) * HLDP + c4 * 4] = make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]);
+            *(float4*)&B[(r0 + 64 * p) * HLDP + c4 * 4] = make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]);
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // lane (li, lh) holds k = 16 kb + 8 lh .. +7 of row li: 16 bytes at float offset lh * 4 + kb * 8 of the 144-byte row
+    half8 ha[2][2], hb[2][4];
+    auto hfrag = [&](int buf, int kb, int fbuf) {
+        const float* Ab = As0 + buf * HM * HLDP + (wr * 64 + li) * HLDP + lh * 4 + kb * 8;
+        const float* Bb = Bs0 + buf * HN * HLDP + (wc * 128 + li) * HLDP + lh * 4 + kb * 8;
+        ha[fbuf][0] = __builtin_bit_cast(half8, *(const float4*)Ab);
+        ha[fbuf][1] = __builtin_bit_cast(half8, *(const float4*)(Ab + 32 * HLDP));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hb[fbuf][j] = __builtin_bit_cast(half8, *(const float4*)(Bb + j * 32 * HLDP));
+    };
+    auto hmma = [&](int fbuf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fbuf][0], hb[fbuf][j], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fbuf][1], hb[fbuf][j], acc[1][j], 0, 0, 0);
+        }
+    };
+
+    // prologue: stage step 0 of the first tile
+    prefetch_tab(l_q);
+    set_tile(l_q);
+    { const int nq2 = next_sb(l_q); if (nq2 < sb_end) prefetch_tab(nq2); }
+    set_tap(0);
+    int m0c = m0l, n0c = n0l;
+    gload();
+    lstore(0);
+    __syncthreads();
+    advance();
+    hfrag(0, 0, 0);
+
+    int q = q0, s = 0, buf = 0;
+    while (true) {
+        // one K-step: fragments of k-block kb + 1 are read while the 8 MFMAs of kb run; the next step's global loads are issued
+        // first and restaged to the other LDS buffer during k-block 2; one barrier per step
+        hfrag(buf, 1, 1);
+        gload();
+        hmma(0);
+        __builtin_amdgcn_sched_barrier(0);
+        hfrag(buf, 2, 0);
+        hmma(1);
+        __builtin_amdgcn_sched_barrier(0);
+        hfrag(buf, 3, 1);
+        hmma(0);
+        lstore(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        hfrag(buf ^ 1, 0, 0);
+        hmma(1);
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+
+        if (s == S - 1) {
+            // ---- epilogue.  C layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); see conv_gemm.hip
+            const float slope = (a.act1 == 1) ? 0.0f : ((a.act1 == 2) ? 0.01f : 1.0f);
+            const int lq = lane & 3;
+            _Float16* const Y = (_Float16*)a.Y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cc = n0c + wc * 128 + j * 32 + li;
+                const int ccl = cc < a.Cout ? cc : a.Cout - 1;
+                const float cb = a.bias ? a.bias[ccl] : 0.0f;
+                const float cs = a.scale ? a.scale[ccl] : 1.0f, ch = a.scale ? a.shift[ccl] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        float x[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[i][j][4 * gq + e] + cb;
+                            acc[i][j][4 * gq + e] = 0.0f;
+                            v = fmaxf(v, v * slope);
+                            x[e] = v * cs + ch;
+                        }
+                        // 4 x 4 transpose across the lane quad (two butterfly stages on DPP quad_perm)
+                        float s0 = (lq & 1) ? x[0] : x[1];
+                        float s1 = (lq & 1) ? x[2] : x[3];
+                        float r0_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xF, 0xF, true));
+                        float r1_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xF, 0xF, true));
+                        if (lq & 1) { x[0] = r0_; x[2] = r1_; } else { x[1] = r0_; x[3] = r1_; }
+                        s0 = (lq & 2) ? x[0] : x[2];
+                        s1 = (lq & 2) ? x[1] : x[3];
+                        r0_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0x4E, 0xF, 0xF, true));
+                        r1_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0x4E, 0xF, 0xF, true));
+                        if (lq & 2) { x[0] = r0_; x[1] = r1_; } else { x[2] = r0_; x[3] = r1_; }
+                        const int g = m0c + wr * 64 + i * 32 + 8 * gq + 4 * lh + lq;
+                        const int co = n0c + wc * 128 + j * 32 + (li & ~3);
+                        if (g < a.M && co < a.Cout) {
+                            const half4 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+                            *(half4*)(Y + (size_t)g * a.y_ld + co) = hv;
+                        }
+                    }
+                }
+            }
+            q = next_sb(q);
+            if (q >= sb_end) break;
+            { int j_, nt_; (void)sb_valid(q, j_, nt_); m0c = __builtin_amdgcn_readfirstlane((xcd + 8 * j_) * HM); n0c = __builtin_amdgcn_readfirstlane(nt_ * HN); }
+            s = 0;
+        } else {
+            ++s;
+        }
+        buf ^= 1;
+    }
+}
+
+// fp16 mode only; returns 1 when the layer does not fit this kernel (the caller then uses conv_gemm.hip's 128 x 128 form)
+int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& in, const char* tag)
+{
+    ConvArgs a = in;
+    if (a.prec != 1 || !a.rowtab || !a.W16 || a.X2 || a.item_bias || a.R || a.act2 || a.pad_mode != 0 || a.Cout < 256 || (a.Cout & 3) || (a.y_ld & 3) ||
+        a.Cin % 64 != 0 || a.M < 8 * HM) return 1;
+    static bool attr_set = false;
+    const size_t lds_bytes = (size_t)2 * (HM + HN) * HLDP * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_gemm_h256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        attr_set = true;
+    }
+    if (a.w_ld <= 0) a.w_ld = a.Cin;
+    a.m_tiles = (a.M + HM - 1) / HM;
+    a.n_tiles = (a.Cout + HN - 1) / HN;
+    int grid = (c->num_cu / 8) * 8;
+    if (grid < 8) grid = 8;
+    const int lx_max = ((a.m_tiles + 7) / 8) * a.n_tiles;
+    if (grid / 8 > lx_max) grid = lx_max * 8;
+    const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
+    const double flops = 2.0 * (double)a.M * a.Cout * cin * a.KT;
+    const double bytes = 2.0 * ((double)a.M * cin + (double)a.M * a.Cout + (double)a.Cout * cin * a.KT);
+    {
+        ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
+        ProfScope ps16(c, "conv_gemm_f16", flops, bytes);
+        hipLaunchKernelGGL(k_conv_gemm_h256, dim3(grid), dim3(512), lds_bytes, c->stream, a);
+    }
+    if (hipGetLastError() != hipSuccess) SD_FAIL(c, SD_ERR_HIP, "k_conv_gemm_h256 launch failed (%s)", tag);
+    return SD_OK;
+}

@@ -159,6 +159,24 @@ def test_ecapa_fp16_mfma_within_reference_tolerance(diarizer, weights):
     assert np.array_equal(diarizer.ecapa(feats, lens), e32)                 # and the f32 path is back, bit for bit
 
 
+def test_ecapa_fp16_wide_tile_kernel_gives_the_same_bits(diarizer):
+    """fp16 mode: the 256 x 256 kernel of the wide layers (conv_gemm_h.hip) and the 128 x 128 kernel feed the same k-blocks to the
+    same MFMA in the same order: embeddings must be bit-identical, whichever kernel a batch size selects"""
+    rng = np.random.default_rng(23)
+    lens = np.array([1.0, 0.5, 0.25, 0.9, 0.7, 0.33, 1.0, 0.6, 0.8, 0.45], np.float32)
+    feats = (3.0 * rng.standard_normal((len(lens), 501, 80))).astype(np.float32)
+    diarizer.set_option("ecapa_precision", 1)
+    try:
+        diarizer.set_option("conv_h256", 1)
+        e_wide = diarizer.ecapa(feats, lens)
+        diarizer.set_option("conv_h256", 0)
+        e_128 = diarizer.ecapa(feats, lens)
+    finally:
+        diarizer.set_option("conv_h256", 1)
+        diarizer.set_option("ecapa_precision", 0)
+    assert np.isfinite(e_wide).all() and np.array_equal(e_wide, e_128)
+
+
 def test_embed_parity(diarizer, weights):
     rng = np.random.default_rng(4)
     wav, masks = _wav_and_masks(rng, 100)
