@@ -78,13 +78,13 @@ def cpu_baseline(ws, we, seconds, planted, threads=None):
 
 def rank0_share_estimate(world, hours_per_gpu):
     """share of the chunks for rank 0 such that its finalize + inference takes as long as the other ranks' inference.
-    Stage rates measured on MI355X on the planted workload (profiles/r02_*): inference ~2.0 s per hour of audio, finalize ~0.25 s
+    Stage rates measured on MI355X on the planted workload (profiles/r02_*): inference ~1.36 s per hour of audio (f32), finalize ~0.18 s
     at 1 h growing ~ h^1.3 (linkage).  A wrong estimate only unbalances the ranks."""
     if world == 1:
         return 1.0
     total_h = world * hours_per_gpu
-    t_inf = 2.0 * total_h
-    t_fin = 0.25 * total_h ** 1.3 + 0.02
+    t_inf = 1.36 * total_h
+    t_fin = 0.18 * total_h ** 1.3 + 0.02
     s0 = (t_inf - (world - 1) * t_fin) / world              # s0 + t_fin == (t_inf - s0) / (world - 1)
     return max(0.0, min(1.0 / world, s0 / t_inf))
 
