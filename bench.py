@@ -320,6 +320,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)          # the JSON line stays the last thing on stdout: whatever a library printf()s at teardown goes to stderr
     d.close()
     if world > 1:
         dist.barrier()

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <unistd.h>
 
 #define ENTER(ctx) do { if (!(ctx)) return SD_ERR_ARG; (ctx)->err.clear(); if (hipSetDevice((ctx)->device) != hipSuccess) SD_FAIL(ctx, SD_ERR_HIP, "hipSetDevice failed"); } while (0)
 #define NCCLCHK(ctx, expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) SD_FAIL(ctx, SD_ERR_HIP, "%s failed: %s", #expr, ncclGetErrorString(_r)); } while (0)
@@ -84,7 +85,15 @@ extern "C" int sd_comm_init(sd_ctx* c, const void* id, int rank, int world)
     ncclUniqueId u;
     memcpy(&u, id, SD_COMM_ID_BYTES);
     ncclComm_t comm = nullptr;
-    NCCLCHK(c, ncclCommInitRank(&comm, world, u, rank));
+    // RCCL printf()s a version banner to stdout when the first communicator is created; a host program's stdout is its result
+    // channel (the CLI's turn block, bench.py's JSON line), so the banner is sent to stderr
+    fflush(stdout);
+    const int saved = dup(1);
+    if (saved >= 0) (void)dup2(2, 1);
+    const ncclResult_t ir = ncclCommInitRank(&comm, world, u, rank);
+    fflush(stdout);
+    if (saved >= 0) { (void)dup2(saved, 1); close(saved); }
+    NCCLCHK(c, ir);
     c->comm = comm; c->rank = rank; c->world = world;
     return SD_OK;
 }
