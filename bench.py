@@ -106,6 +106,7 @@ def main():
                     "(rank0_share_estimate), 1/N = equal shares, 0 = rank 0 only finalizes")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL communicator inside the library, "
                     "all-gather, assembly) even with one rank")
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (sd_set_option), e.g. emb_batch_items=1536; tuning only")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,6 +171,9 @@ def main():
     d = sdhip.Diarizer(os.path.join(tmp, "segment.sdw"), os.path.join(tmp, "embedding.sdw"), local)
     if a.precision == "f16":
         d.set_option("ecapa_precision", 1)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        d.set_option(k, int(v))
     d_pcm = torch.from_numpy(pcm_host).to(dev)
     torch.cuda.synchronize()
     if planted and hi > lo:
