@@ -161,6 +161,8 @@ void sd_flush_profile(sd_ctx* c);   // api.cpp: resolves pending event pairs int
 int launch_conv_gemm(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- conv_gemm_h.hip (fp16 mode, Cout >= 256: 256 x 256 tile; returns 1 = not applicable)
 int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& a, const char* tag);
+// ---- conv_narrow.hip (f32, Cout <= 96, "valid" convs of SincNet: tile as wide as the layer; returns 1 = not applicable)
+int launch_conv_narrow(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- weights.cpp
 struct PackTensor { std::vector<int64_t> dims; std::vector<float> data; };
 typedef std::map<std::string, PackTensor> Pack;

@@ -48,11 +48,12 @@ __global__ __launch_bounds__(256) void k_chunk_norm(const float* __restrict__ wa
 // ---------------------------------------------------------------- k_pool_norm
 // in  [chunk][Lc][C]  ->  out [chunk][Lp][Cpad],  Lp = Lc/3
 // out = leaky_relu(instance_norm(maxpool3(abs?(in))))   per (chunk, channel) statistics
+#define PN_T 960          // threads per chunk: Q = PN_T / C row groups per channel keep 12-16 loads per channel in flight
 template <int C, int CPAD, bool ABS>
-__global__ __launch_bounds__(240) void k_pool_norm(const float* __restrict__ in, int Lc, int Lp, const float* __restrict__ gw,
+__global__ __launch_bounds__(PN_T) void k_pool_norm(const float* __restrict__ in, int Lc, int Lp, const float* __restrict__ gw,
                                                    const float* __restrict__ gb, float* __restrict__ out)
 {
-    constexpr int Q = 240 / C;
+    constexpr int Q = PN_T / C;
     __shared__ float red[Q][C];
     __shared__ float sa[C], sb[C];
     const int ck = blockIdx.x, tid = threadIdx.x;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(240) void k_pool_norm(const float* __restrict__ in,
         dst[(size_t)q * CPAD + c] = y > 0.0f ? y : 0.01f * y;
     }
     // zero the padding channels
-    for (int idx = tid; idx < Lp * (CPAD - C); idx += 240) {
+    for (int idx = tid; idx < Lp * (CPAD - C); idx += PN_T) {
         const int q = idx / (CPAD - C), cc = C + idx % (CPAD - C);
         dst[(size_t)q * CPAD + cc] = 0.0f;
     }
@@ -265,27 +266,30 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
         a.X = xn; a.x_ld = 10; a.W = S.conv0.W; a.Y = c0; a.y_ld = 80;
         a.M = (int)(CB * L0); a.TpIn = SD_CHUNK / 10; a.TpOut = L0; a.Tin = SD_CHUNK / 10; a.T = L0;
         a.Cin = 256; a.cin_real = 251; a.Cout = 80; a.KT = 1; a.dil = 1; a.pad_mode = 1;
-        if ((rc = launch_conv_gemm(c, a, "sinc0"))) return rc;
+        if ((rc = launch_conv_narrow(c, a, "sinc0")) == 1) rc = launch_conv_gemm(c, a, "sinc0");
+        if (rc) return rc;
     }
-    hipLaunchKernelGGL((k_pool_norm<80, 96, true>), dim3((unsigned)CB), dim3(240), 0, st, c0, L0, P0, S.in_w[0], S.in_b[0], p0);
+    hipLaunchKernelGGL((k_pool_norm<80, 96, true>), dim3((unsigned)CB), dim3(PN_T), 0, st, c0, L0, P0, S.in_w[0], S.in_b[0], p0);
     KCHECK(c);
     {
         ConvArgs a; memset(&a, 0, sizeof(a));
         a.X = p0; a.x_ld = 96; a.W = S.conv1.W; a.bias = S.conv1.bias; a.Y = c1; a.y_ld = 60;
         a.M = (int)(CB * L1); a.TpIn = P0; a.TpOut = L1; a.Tin = P0; a.T = L1;
         a.Cin = 96; a.cin_real = 80; a.Cout = 60; a.KT = 5; a.dil = 1; a.pad_mode = 1;
-        if ((rc = launch_conv_gemm(c, a, "sinc1"))) return rc;
+        if ((rc = launch_conv_narrow(c, a, "sinc1")) == 1) rc = launch_conv_gemm(c, a, "sinc1");
+        if (rc) return rc;
     }
-    hipLaunchKernelGGL((k_pool_norm<60, 64, false>), dim3((unsigned)CB), dim3(240), 0, st, c1, L1, P1, S.in_w[1], S.in_b[1], p1);
+    hipLaunchKernelGGL((k_pool_norm<60, 64, false>), dim3((unsigned)CB), dim3(PN_T), 0, st, c1, L1, P1, S.in_w[1], S.in_b[1], p1);
     KCHECK(c);
     {
         ConvArgs a; memset(&a, 0, sizeof(a));
         a.X = p1; a.x_ld = 64; a.W = S.conv2.W; a.bias = S.conv2.bias; a.Y = c2; a.y_ld = 60;
         a.M = (int)(CB * L2); a.TpIn = P1; a.TpOut = L2; a.Tin = P1; a.T = L2;
         a.Cin = 64; a.cin_real = 60; a.Cout = 60; a.KT = 5; a.dil = 1; a.pad_mode = 1;
-        if ((rc = launch_conv_gemm(c, a, "sinc2"))) return rc;
+        if ((rc = launch_conv_narrow(c, a, "sinc2")) == 1) rc = launch_conv_gemm(c, a, "sinc2");
+        if (rc) return rc;
     }
-    hipLaunchKernelGGL((k_pool_norm<60, 64, false>), dim3((unsigned)CB), dim3(240), 0, st, c2, L2, P2, S.in_w[2], S.in_b[2], p2);
+    hipLaunchKernelGGL((k_pool_norm<60, 64, false>), dim3((unsigned)CB), dim3(PN_T), 0, st, c2, L2, P2, S.in_w[2], S.in_b[2], p2);
     KCHECK(c);
     // if P2 > 293 (cannot happen for L <= 80000) only the first F frames would be used
     const float* lin = p2; int lin_ld = 64; int lin_rows_per_chunk = P2;
