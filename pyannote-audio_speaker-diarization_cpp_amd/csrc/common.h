@@ -66,6 +66,7 @@ struct ConvArgs {
     // frame reads that last frame instead (it can only feed frames that are themselves beyond nvalid).  null = dense mapping.
     const int2* rowtab;
     int in_rows;
+    int y_f32;             // fp16 mode: Y is float all the same (the attention logits feed an exp)
     int prec;              // 0 = f32 (X, X2, W, Y are float), 1 = fp16 end to end (X, X2, W16, Y are _Float16; option ecapa_precision)
 };
 #define ROWTAB_T(y) ((y) & 1023)

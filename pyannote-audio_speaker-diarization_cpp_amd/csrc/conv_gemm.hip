@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                                 const int co = n0c + wc * 64 + j * 32 + (li & ~3);
                                 if (g < a.M && co < a.Cout) {
                                     if (DBG == 1) { if (x[j][0] == 12345.678f) a.Y[0] = x[j][1]; }
-                                    else if constexpr (F16) {
+                                    else if (F16 && !a.y_f32) {
                                         const half4 hv = {(_Float16)x[j][0], (_Float16)x[j][1], (_Float16)x[j][2], (_Float16)x[j][3]};
                                         *(half4*)((_Float16*)a.Y + (size_t)g * a.y_ld + co) = hv;
                                     } else *(float4*)(a.Y + (size_t)g * a.y_ld + co) = make_float4(x[j][0], x[j][1], x[j][2], x[j][3]);
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                                     if (g >= a.M || cco[j] >= a.Cout) continue;
                                     float v = x[j][e];
                                     if (a.R) v += a.R[(size_t)g * a.r_ld + cco[j]];
-                                    if constexpr (F16) ((_Float16*)a.Y)[(size_t)g * a.y_ld + cco[j]] = (_Float16)v;
+                                    if (F16 && !a.y_f32) ((_Float16*)a.Y)[(size_t)g * a.y_ld + cco[j]] = (_Float16)v;
                                     else a.Y[(size_t)g * a.y_ld + cco[j]] = v;
                                 }
                             }

@@ -233,8 +233,11 @@ __global__ __launch_bounds__(512) void k_conv_gemm_h256(ConvArgs a)
                         const int g = m0c + wr * 64 + i * 32 + 8 * gq + 4 * lh + lq;
                         const int co = n0c + wc * 128 + j * 32 + (li & ~3);
                         if (g < a.M && co < a.Cout) {
-                            const half4 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
-                            *(half4*)(Y + (size_t)g * a.y_ld + co) = hv;
+                            if (a.y_f32) *(float4*)(a.Y + (size_t)g * a.y_ld + co) = make_float4(x[0], x[1], x[2], x[3]);
+                            else {
+                                const half4 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+                                *(half4*)(Y + (size_t)g * a.y_ld + co) = hv;
+                            }
                         }
                     }
                 }

@@ -95,14 +95,14 @@ template <class T> __global__ void k_asp_stats(const T* __restrict__ x, int ld, 
 
 // attentive statistics pooling: masked softmax over time of the logits, weighted mean/std of x.
 // One pass over both tensors: online softmax (running max, rescaled weights) + weighted Welford update.
-template <class T> __global__ void k_asp_pool(const T* __restrict__ x, const T* __restrict__ logit, int ld, const int* __restrict__ nvalid,
+template <class T> __global__ void k_asp_pool(const T* __restrict__ x, const float* __restrict__ logit, int ld, const int* __restrict__ nvalid,
                            const int* __restrict__ rowoff, int row_base, float* __restrict__ pooled, int C)
 {
     const int item = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= C) return;
     const int nv = nvalid[item];
     const T* px = x + (size_t)(rowoff[item] - row_base) * ld + ch;
-    const T* pl = logit + (size_t)(rowoff[item] - row_base) * ld + ch;
+    const float* pl = logit + (size_t)(rowoff[item] - row_base) * ld + ch;
     float mx = -INFINITY, W = 0.0f, mean = 0.0f, m2 = 0.0f;
     auto step = [&](float l, float v) {
         if (l > mx) { const float s = expf(mx - l); W *= s; m2 *= s; mx = l; }      // expf(-inf) = 0 on the first frame
@@ -271,8 +271,11 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, con
     }
     { ConvArgs a = conv_args(E.asp_tdnn_ms, ms, 2 * C3, ib, 128, items, false); if ((rc = launch_conv_gemm(c, a, "asp_ms"))) return rc; }
     { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, C3, hid, 128, MN, true, P); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; a.rowtab = rowtab_n; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
-    T* logits = cat;   // cat is dead after mfa
-    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, MN, true, P); a.rowtab = rowtab_n; if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
+    // attention logits stay f32 in either mode (they feed an exp: fp16's 3 decimal digits at |logit| ~ 30 would be percents of a weight).
+    // f32 mode: cat is dead after mfa and large enough; fp16 mode: its own buffer
+    float* logits;
+    if (P) { WS(c, float, lg, "ec_logits", MN * C3); logits = lg; } else logits = (float*)cat;
+    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, MN, true, P); a.rowtab = rowtab_n; a.y_f32 = 1; if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
     {
         ProfScope ps(c, "asp_pool", 0, (double)MN * C3 * 8.0);
         hipLaunchKernelGGL(k_asp_pool<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, C3, d_nvalid, d_rowoffN, row_baseN, pooled, C3);
