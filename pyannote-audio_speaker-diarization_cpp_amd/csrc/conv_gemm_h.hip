@@ -24,8 +24,12 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define HN 256
 #define HLDP 36            // LDS row: 64 halves + 8 halves of padding = 36 floats = 144 B (conflict-free ds_read_b128, see conv_gemm.hip)
 
-__global__ __launch_bounds__(512) void k_conv_gemm_h256(ConvArgs a)
+// H = true: fp16 operands (v_mfma_f32_32x32x16_f16, one MFMA per tile and k-block of 16); H = false: f32 operands
+// (v_mfma_f32_32x32x2_f32 over the k pairs (k, k + 16) of a 32-chunk, four MFMAs per tile and K-group, conv_gemm.hip's order)
+template <bool H>
+__global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
 {
+    constexpr int ES = H ? 2 : 4;                    // bytes per element; a K-step is 128 bytes of every row either way
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const As0 = lds;                          // [2][HM * HLDP]
     float* const Bs0 = lds + 2 * HM * HLDP;          // [2][HN * HLDP]
@@ -33,7 +37,10 @@ __global__ __launch_bounds__(512) void k_conv_gemm_h256(ConvArgs a)
     const int w = blockIdx.x, G = gridDim.x;         // G is a multiple of 8
     const int xcd = w & 7, wl = w >> 3, wpx = G >> 3;
     const int mx = (a.m_tiles - xcd + 7) >> 3;       // row panels of this XCD: m = xcd + 8 j
-    const int PN = a.n_tiles < 8 ? a.n_tiles : 8;
+    // super-block shape (profiles/r02_layer_profile.txt): with 32 workgroups per XCD, 4 column tiles x 8 row panels beats 8 x 4 by a third
+    // on the 3072 x 3072 layer (each W K-slice is shared by 8 workgroups instead of 4; f32 137 vs 103 TF, fp16 962 vs 778 TF)
+    const int pnmax = a.sched > 0 ? a.sched : 4;
+    const int PN = a.n_tiles < pnmax ? a.n_tiles : pnmax;
     const int PM = wpx / PN > 0 ? wpx / PN : 1;
     const int pm = wl / PN, pn = wl - pm * PN;
     if (pm >= PM) return;
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_h256(ConvArgs a)
     const int c4 = tid & 7, r0 = tid >> 3;           // loader: 16-byte chunk c4 of row r0 + 64 p
     const int li = lane & 31, lh = lane >> 5;
 
-    const int kcs = a.Cin / 64;
+    const int kcs = a.Cin / (128 / ES);
     const int S = a.KT * kcs;
     const int half = a.KT / 2;
     const size_t in_rows = (size_t)(a.in_rows > 0 ? a.in_rows : a.M);
@@ -78,9 +85,9 @@ __global__ __launch_bounds__(512) void k_conv_gemm_h256(ConvArgs a)
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
     };
     __amdgpu_buffer_rsrc_t rA = make_rsrc(a.X, 0);
-    const __amdgpu_buffer_rsrc_t rB = make_rsrc(a.W16, (size_t)a.KT * a.Cout * a.w_ld * 2);
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(H ? a.W16 : (const void*)a.W, (size_t)a.KT * a.Cout * a.w_ld * ES);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)((r0 + 64 * p) * a.w_ld * 2 + c4 * 16);
+    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)((r0 + 64 * p) * a.w_ld * ES + c4 * 16);
     int l_q = q0, l_kk = 0, l_kc = 0, m0l = 0, n0l = 0;
     unsigned sK = 0, sB = 0;
     auto set_tile = [&](int sb) {
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_h256(ConvArgs a)
         const int base = __builtin_amdgcn_readfirstlane(pre_base);
 #pragma unroll
         for (int p = 0; p < 4; ++p) { rrel[p] = pre[p].x - base; tt[p] = ROWTAB_T(pre[p].y); nd[p] = ROWTAB_LAST(pre[p].y); }
-        rA = make_rsrc((const char*)a.X + (size_t)base * a.x_ld * 2, (in_rows - base) * a.x_ld * 2);
+        rA = make_rsrc((const char*)a.X + (size_t)base * a.x_ld * ES, (in_rows - base) * a.x_ld * ES);
     };
     auto set_tap = [&](int kk) {
 #pragma unroll
@@ -101,10 +108,10 @@ __global__ __launch_bounds__(512) void k_conv_gemm_h256(ConvArgs a)
             if (qr >= a.Tin) qr = 2 * (a.Tin - 1) - qr;
             if (qr < 0) qr = 0;
             if (qr > nd[p]) qr = nd[p];
-            voA[p] = (unsigned)(rrel[p] + qr) * (unsigned)a.x_ld * 2 + c4 * 16;
+            voA[p] = (unsigned)(rrel[p] + qr) * (unsigned)a.x_ld * ES + c4 * 16;
         }
         // weight rows beyond Cout (a 256-wide tile over Cout = 1024 / 3072 never has any) are clamped by the descriptor
-        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * 2);
+        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * ES);
     };
     auto advance = [&]() {
         if (++l_kc < kcs) { sK += 128; return; }
@@ -145,21 +152,35 @@ __global__ __launch_bounds__(512) void k_conv_gemm_h256(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // lane (li, lh) holds k = 16 kb + 8 lh .. +7 of row li: 16 bytes at float offset lh * 4 + kb * 8 of the 144-byte row
-    half8 ha[2][2], hb[2][4];
+    // one 16-byte fragment per lane, row and K-group kb (4 groups per K-step).  fp16: lane (li, lh) holds k = 16 kb + 8 lh .. +7 of
+    // row li (float offset lh * 4 + kb * 8 of the 144-byte row); f32: k = 16 lh + 4 kb .. +3 (float offset lh * 16 + kb * 4)
+    float4 ha[2][2], hb[2][4];
     auto hfrag = [&](int buf, int kb, int fbuf) {
-        const float* Ab = As0 + buf * HM * HLDP + (wr * 64 + li) * HLDP + lh * 4 + kb * 8;
-        const float* Bb = Bs0 + buf * HN * HLDP + (wc * 128 + li) * HLDP + lh * 4 + kb * 8;
-        ha[fbuf][0] = __builtin_bit_cast(half8, *(const float4*)Ab);
-        ha[fbuf][1] = __builtin_bit_cast(half8, *(const float4*)(Ab + 32 * HLDP));
+        const int ko = H ? lh * 4 + kb * 8 : lh * 16 + kb * 4;
+        const float* Ab = As0 + buf * HM * HLDP + (wr * 64 + li) * HLDP + ko;
+        const float* Bb = Bs0 + buf * HN * HLDP + (wc * 128 + li) * HLDP + ko;
+        ha[fbuf][0] = *(const float4*)Ab;
+        ha[fbuf][1] = *(const float4*)(Ab + 32 * HLDP);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) hb[fbuf][j] = __builtin_bit_cast(half8, *(const float4*)(Bb + j * 32 * HLDP));
+        for (int j = 0; j < 4; ++j) hb[fbuf][j] = *(const float4*)(Bb + j * 32 * HLDP);
     };
     auto hmma = [&](int fbuf) {
+        if constexpr (H) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fbuf][0], hb[fbuf][j], acc[0][j], 0, 0, 0);
-            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fbuf][1], hb[fbuf][j], acc[1][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ha[fbuf][0]), __builtin_bit_cast(half8, hb[fbuf][j]), acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ha[fbuf][1]), __builtin_bit_cast(half8, hb[fbuf][j]), acc[1][j], 0, 0, 0);
+            }
+        } else {
+            const float a0[4] = {ha[fbuf][0].x, ha[fbuf][0].y, ha[fbuf][0].z, ha[fbuf][0].w}, a1[4] = {ha[fbuf][1].x, ha[fbuf][1].y, ha[fbuf][1].z, ha[fbuf][1].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float bv = e == 0 ? hb[fbuf][j].x : e == 1 ? hb[fbuf][j].y : e == 2 ? hb[fbuf][j].z : hb[fbuf][j].w;
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bv, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bv, acc[1][j], 0, 0, 0);
+                }
         }
     };
 
@@ -233,7 +254,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_h256(ConvArgs a)
                         const int g = m0c + wr * 64 + i * 32 + 8 * gq + 4 * lh + lq;
                         const int co = n0c + wc * 128 + j * 32 + (li & ~3);
                         if (g < a.M && co < a.Cout) {
-                            if (a.y_f32) *(float4*)(a.Y + (size_t)g * a.y_ld + co) = make_float4(x[0], x[1], x[2], x[3]);
+                            if (!H || a.y_f32) *(float4*)(a.Y + (size_t)g * a.y_ld + co) = make_float4(x[0], x[1], x[2], x[3]);
                             else {
                                 const half4 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
                                 *(half4*)(Y + (size_t)g * a.y_ld + co) = hv;
@@ -253,33 +274,39 @@ __global__ __launch_bounds__(512) void k_conv_gemm_h256(ConvArgs a)
     }
 }
 
-// fp16 mode only; returns 1 when the layer does not fit this kernel (the caller then uses conv_gemm.hip's 128 x 128 form)
+// returns 1 when the layer does not fit this kernel (the caller then uses conv_gemm.hip's 128 x 128 form)
 int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& in, const char* tag)
 {
     ConvArgs a = in;
-    if (a.prec != 1 || !a.rowtab || !a.W16 || a.X2 || a.item_bias || a.R || a.act2 || a.pad_mode != 0 || a.Cout < 256 || (a.Cout & 3) || (a.y_ld & 3) ||
-        a.Cin % 64 != 0 || a.M < 8 * HM) return 1;
+    const bool h = a.prec == 1;
+    if (!a.rowtab || (h && !a.W16) || a.X2 || a.item_bias || a.R || a.act2 || a.pad_mode != 0 || a.Cout < 256 || (a.Cout & 3) || (a.y_ld & 3) ||
+        a.Cin % (h ? 64 : 32) != 0 || a.M < 8 * HM) return 1;
+    // short contractions stay on the 128 x 128 form (measured: block0 K = 480 and ASP conv K = 128 in f32, ASP conv in fp16)
+    if ((int64_t)a.Cin * a.KT < (h ? 256 : 1024)) return 1;
     static bool attr_set = false;
     const size_t lds_bytes = (size_t)2 * (HM + HN) * HLDP * sizeof(float);
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv_gemm_h256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        if (hipFuncSetAttribute((const void*)k_conv_gemm_w256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_gemm_w256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
         attr_set = true;
     }
     if (a.w_ld <= 0) a.w_ld = a.Cin;
     a.m_tiles = (a.M + HM - 1) / HM;
     a.n_tiles = (a.Cout + HN - 1) / HN;
+    a.sched = c->conv_pn;
     int grid = (c->num_cu / 8) * 8;
     if (grid < 8) grid = 8;
     const int lx_max = ((a.m_tiles + 7) / 8) * a.n_tiles;
     if (grid / 8 > lx_max) grid = lx_max * 8;
     const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
     const double flops = 2.0 * (double)a.M * a.Cout * cin * a.KT;
-    const double bytes = 2.0 * ((double)a.M * cin + (double)a.M * a.Cout + (double)a.Cout * cin * a.KT);
+    const double bytes = (h ? 2.0 : 4.0) * ((double)a.M * cin + (double)a.M * a.Cout + (double)a.Cout * cin * a.KT);
     {
         ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
-        ProfScope ps16(c, "conv_gemm_f16", flops, bytes);
-        hipLaunchKernelGGL(k_conv_gemm_h256, dim3(grid), dim3(512), lds_bytes, c->stream, a);
+        ProfScope ps16(c, h ? "conv_gemm_f16" : "conv_gemm_f32", flops, bytes);
+        if (h) hipLaunchKernelGGL(k_conv_gemm_w256<true>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
+        else hipLaunchKernelGGL(k_conv_gemm_w256<false>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
     }
-    if (hipGetLastError() != hipSuccess) SD_FAIL(c, SD_ERR_HIP, "k_conv_gemm_h256 launch failed (%s)", tag);
+    if (hipGetLastError() != hipSuccess) SD_FAIL(c, SD_ERR_HIP, "k_conv_gemm_w256 launch failed (%s)", tag);
     return SD_OK;
 }

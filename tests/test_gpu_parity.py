@@ -177,6 +177,21 @@ def test_ecapa_fp16_wide_tile_kernel_gives_the_same_bits(diarizer):
     assert np.isfinite(e_wide).all() and np.array_equal(e_wide, e_128)
 
 
+def test_ecapa_f32_wide_tile_kernel_gives_the_same_bits(diarizer):
+    """f32: the 256 x 256 kernel (TDNN, MFA) sums K in conv_gemm.hip's order: bit-identical embeddings"""
+    rng = np.random.default_rng(29)
+    lens = np.array([1.0, 0.5, 0.25, 0.9, 0.7, 0.33, 1.0, 0.6, 0.8, 0.45], np.float32)
+    feats = (3.0 * rng.standard_normal((len(lens), 501, 80))).astype(np.float32)
+    try:
+        diarizer.set_option("conv_w256_f32", 1)
+        e_wide = diarizer.ecapa(feats, lens)
+        diarizer.set_option("conv_w256_f32", 0)
+        e_128 = diarizer.ecapa(feats, lens)
+    finally:
+        diarizer.set_option("conv_w256_f32", 1)
+    assert np.isfinite(e_wide).all() and np.array_equal(e_wide, e_128)
+
+
 def test_embed_parity(diarizer, weights):
     rng = np.random.default_rng(4)
     wav, masks = _wav_and_masks(rng, 100)

@@ -13,6 +13,8 @@ nn.save_pack(tmp + "/s.sdw", nn.synth_segmentation_weights(4321)); nn.save_pack(
 d = sdhip.Diarizer(tmp + "/s.sdw", tmp + "/e.sdw", 0)
 d.set_option("skip_dead_rows", skip)
 d.set_option("ecapa_precision", 1 if prec == "f16" else 0)
+for kv in filter(None, os.environ.get("OPTS", "").split(",")):
+    k, v = kv.split("="); d.set_option(k, int(v)); print("option", k, v)
 pcm = synth.make_pcm(3600, seed=1234)
 n = len(pcm)
 dev = torch.device("cuda", 0)
