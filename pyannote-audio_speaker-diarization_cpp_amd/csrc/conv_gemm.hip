@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     // (workgroup wl owns position (wl / PN, wl % PN) of every block).  They advance through K roughly in step,
     // so each A and W K-slice is pulled into the XCD's L2 once per block and shared by PN resp. PM workgroups
     // (measured before this order: 125 GB of fabric reads for the 3072x3072 layer against 4.9 GB algorithmic).
-    const int PN = a.n_tiles < 8 ? a.n_tiles : 8;
+    const int pnmax = a.sched >= 100 ? a.sched - 100 : 8;          // (tuning: conv_pn128)
+    const int PN = a.n_tiles < pnmax ? a.n_tiles : pnmax;
     const int PM = wpx / PN > 0 ? wpx / PN : 1;
     const int pm = wl / PN, pn = wl - pm * PN;
     if (pm >= PM) return;
@@ -538,7 +539,7 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     }
     a.m_tiles = (a.M + BM - 1) / BM;
     a.n_tiles = (a.Cout + BN - 1) / BN;
-    a.sched = SD_CONV_SCHED_DEFAULT;
+    a.sched = c->conv_pn128 > 0 ? 100 + c->conv_pn128 : SD_CONV_SCHED_DEFAULT;
     const int grid = conv_grid(c, a);
     // algorithmic work: valid rows only (T of every TpOut), un-padded input channels
     const double rows = a.rowtab ? (double)a.M
