@@ -270,7 +270,7 @@ def main():
         if world == 1 and a.precision == "f32" and os.path.exists(pmc_path):
             try:
                 pj = json.load(open(pmc_path))
-                cur = git_blob_sha1(os.path.join(PKG, "csrc", "conv_gemm.hip"))
+                cur = "+".join(git_blob_sha1(os.path.join(PKG, "csrc", f)) for f in ("conv_gemm.hip", "conv_gemm_h.hip", "conv_narrow.hip"))
                 if pj.get("conv_gemm_blob") == cur and pj.get("workload", "raw") == a.workload:
                     traffic, traffic_src, mfma_util = pj["bytes_per_launch"], pj["source"], pj.get("mfma")
                 else:

@@ -8,6 +8,9 @@ import csv, collections, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+CONV_SOURCES = ("conv_gemm.hip", "conv_gemm_h.hip", "conv_narrow.hip")   # the MFMA convolution kernels the counters are folded over
+
+
 def blob(path):
     data = open(path, "rb").read()
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
@@ -18,7 +21,7 @@ def agg(path, counter=None):
     n = collections.defaultdict(set)
     for r in csv.DictReader(open(path)):
         kn = r['Kernel_Name']
-        if kn.startswith('void k_conv_gemm<') or kn.startswith('k_conv_gemm_h256') or kn.startswith('void k_conv_narrow<') or kn.startswith('k_stft_fbank'):
+        if kn.startswith('void k_conv_gemm<') or kn.startswith('void k_conv_gemm_w256<') or kn.startswith('void k_conv_narrow<') or kn.startswith('k_stft_fbank'):
             k = kn.split('(')[0]
             k = k[5:] if k.startswith('void ') else k
             d[k][r['Counter_Name']] += float(r['Counter_Value'])
@@ -43,7 +46,7 @@ n = sum(fn.values())
 assert n == sum(wn.values()), (fn, wn)
 fb = sum(v['FETCH_SIZE'] for v in f.values()) * 1024
 wb = sum(v['WRITE_SIZE'] for v in w.values()) * 1024
-out = {"conv_gemm_blob": blob(os.path.join(ROOT, "pyannote-audio_speaker-diarization_cpp_amd", "csrc", "conv_gemm.hip")), "workload": workload,
+out = {"conv_gemm_blob": "+".join(blob(os.path.join(ROOT, "pyannote-audio_speaker-diarization_cpp_amd", "csrc", f)) for f in CONV_SOURCES), "workload": workload,
        "bytes_per_launch": round((2 * fb + wb) / n), "launches": n,
        "fetch_raw_bytes_per_launch": round(fb / n), "fetch_x2_bytes_per_launch": round(2 * fb / n), "write_bytes_per_launch": round(wb / n),
        "per_kernel": {k: {"launches": fn[k], "fetch_x2_bytes_per_launch": round(2 * f[k]['FETCH_SIZE'] * 1024 / fn[k]),
