@@ -200,20 +200,35 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
     while (true) {
         // one K-step: fragments of k-block kb + 1 are read while the 8 MFMAs of kb run; the next step's global loads are issued
         // first and restaged to the other LDS buffer during k-block 2; one barrier per step
+        // f32: a K-group is 32 MFMAs (2048 cycles).  Left alone the scheduler sinks the six fragment reads of the next group to the
+        // end of the region -- one MFMA in front of their first use -- and the eight ds_writes to the last three MFMAs in front of
+        // the barrier, so every group boundary and every barrier waits on LDS latency with an empty matrix pipe (13 % of the
+        // cycles, profiles/pmc_conv_gemm_bench.json).  sched_group_barrier pins them behind the FIRST MFMAs of the region, one
+        // memory instruction per MFMA (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write).
+#define W_PAIR(mask, n) do { _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); } } while (0)
         hfrag(buf, 1, 1);
         gload();
         hmma(0);
+        if constexpr (!H) {
+            W_PAIR(0x100, 6);
+#pragma unroll
+            for (int i_ = 0; i_ < 8; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         hfrag(buf, 2, 0);
         hmma(1);
+        if constexpr (!H) { W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, 26, 0); }
         __builtin_amdgcn_sched_barrier(0);
         hfrag(buf, 3, 1);
         hmma(0);
         lstore(buf ^ 1);
+        if constexpr (!H) { W_PAIR(0x100, 6); W_PAIR(0x200, 8); __builtin_amdgcn_sched_group_barrier(0x008, 18, 0); }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         hfrag(buf ^ 1, 0, 0);
         hmma(1);
+        if constexpr (!H) { W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, 26, 0); }
         __builtin_amdgcn_sched_barrier(0);
         advance();
 
