@@ -214,21 +214,31 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
 #pragma unroll
             for (int i_ = 0; i_ < 8; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
             __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+        } else {
+            // fp16: a K-group is 8 MFMAs of 32 cycles; same rule, the eight loads / stores ride behind the last two MFMAs
+            W_PAIR(0x100, 6);
+#pragma unroll
+            for (int i_ = 0; i_ < 2; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 4, 0); }
         }
         __builtin_amdgcn_sched_barrier(0);
         hfrag(buf, 2, 0);
         hmma(1);
-        if constexpr (!H) { W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, 26, 0); }
+        W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, H ? 2 : 26, 0);
         __builtin_amdgcn_sched_barrier(0);
         hfrag(buf, 3, 1);
         hmma(0);
         lstore(buf ^ 1);
         if constexpr (!H) { W_PAIR(0x100, 6); W_PAIR(0x200, 8); __builtin_amdgcn_sched_group_barrier(0x008, 18, 0); }
+        else {
+            W_PAIR(0x100, 6);
+#pragma unroll
+            for (int i_ = 0; i_ < 2; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 4, 0); }
+        }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         hfrag(buf ^ 1, 0, 0);
         hmma(1);
-        if constexpr (!H) { W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, 26, 0); }
+        W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, H ? 2 : 26, 0);
         __builtin_amdgcn_sched_barrier(0);
         advance();
 
@@ -296,8 +306,9 @@ int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& in, const char* tag)
     const bool h = a.prec == 1;
     if (!a.rowtab || (h && !a.W16) || a.X2 || a.item_bias || a.R || a.act2 || a.pad_mode != 0 || a.Cout < 256 || (a.Cout & 3) || (a.y_ld & 3) ||
         a.Cin % (h ? 64 : 32) != 0 || a.M < 8 * HM) return 1;
-    // short contractions stay on the 128 x 128 form (measured: block0 K = 480 and ASP conv K = 128 in f32, ASP conv in fp16)
-    if ((int64_t)a.Cin * a.KT < (h ? 256 : 1024)) return 1;
+    // fp16: the shortest contraction (ASP conv, K = 128) stays on the 128 x 128 form (measured); f32 takes every wide layer since the
+    // K-groups are pinned (block0 K = 400: 92 -> 102 TF, ASP conv K = 128: 95 -> 105 TF)
+    if ((int64_t)a.Cin * a.KT < (c->conv_w256_kmin > 0 ? c->conv_w256_kmin : (h ? 256 : 128))) return 1;
     static bool attr_set = false;
     const size_t lds_bytes = (size_t)2 * (HM + HN) * HLDP * sizeof(float);
     if (!attr_set) {

@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_narrow(ConvArgs a)
         rowbase[p] = (size_t)b * a.TpIn; tt[p] = t;
     }
     f4u ra[4], rb[NJ];
-    auto gload = [&](int s) {
+    // the load stream never branches: the step after the last one re-reads the last one (its staging lands in the idle LDS buffer),
+    // so every K-step is one basic block the scheduling pins below can work in
+    auto gloadA = [&](int s) {
         const int kk = s / kcs, kc = s - kk * kcs;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -43,6 +45,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_narrow(ConvArgs a)
             if (qr > a.Tin - 1) qr = a.Tin - 1;
             ra[p] = *(const f4u*)(a.X + (rowbase[p] + qr) * a.x_ld + kc * 32 + c4 * 4);
         }
+    };
+    auto gloadB = [&](int s) {
+        const int kk = s / kcs, kc = s - kk * kcs;
 #pragma unroll
         for (int p = 0; p < NJ; ++p) {
             int co = r0 + 32 * p;
@@ -62,31 +67,57 @@ __global__ __launch_bounds__(256, 2) void k_conv_narrow(ConvArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
-    gload(0);
+    // operand fragments of K-group qq (k = 16 lh + 4 qq .. +3 of the 32-chunk), double buffered in registers
+    float4 fa[2], fb[2][NJ];
+    auto lfrag = [&](int buf, int qq, int f) {
+        fa[f] = *(const float4*)(&As[buf][(wr * 32 + li) * NLDP + lh * 16] + qq * 4);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[f][j] = *(const float4*)(&Bs[buf][li * NLDP + lh * 16] + j * 32 * NLDP + qq * 4);
+    };
+    auto mma = [&](int f) {
+        const float av[4] = {fa[f].x, fa[f].y, fa[f].z, fa[f].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float bv = e == 0 ? fb[f][j].x : e == 1 ? fb[f][j].y : e == 2 ? fb[f][j].z : fb[f][j].w;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv, acc[j], 0, 0, 0);
+            }
+    };
+
+    gloadA(0); gloadB(0);
     lstore(0);
     __syncthreads();
+    lfrag(0, 0, 0);
+    // one K-step = 4 K-groups of 4 NJ MFMAs.  Memory instructions are pinned one by one behind the first MFMAs of their group
+    // (sched_group_barrier masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write), see conv_gemm_h.hip
+#define N_PAIR(mask, n) do { _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); } } while (0)
     for (int s = 0; s < S; ++s) {
         const int buf = s & 1;
-        if (s + 1 < S) gload(s + 1);
-        const float* Ab = &As[buf][(wr * 32 + li) * NLDP + lh * 16];
-        const float* Bb = &Bs[buf][li * NLDP + lh * 16];
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const float4 fa = *(const float4*)(Ab + qq * 4);
-            float4 fb[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) fb[j] = *(const float4*)(Bb + j * 32 * NLDP + qq * 4);
-            const float av[4] = {fa.x, fa.y, fa.z, fa.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const float bv = e == 0 ? fb[j].x : e == 1 ? fb[j].y : e == 2 ? fb[j].z : fb[j].w;
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv, acc[j], 0, 0, 0);
-                }
-        }
-        if (s + 1 < S) lstore(buf ^ 1);
+        const int sn = s + 1 < S ? s + 1 : S - 1;
+        lfrag(buf, 1, 1);
+        gloadA(sn);
+        mma(0);
+        N_PAIR(0x100, 1 + NJ); N_PAIR(0x020, 4);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 5 - NJ, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        lfrag(buf, 2, 0);
+        gloadB(sn);
+        mma(1);
+        N_PAIR(0x100, 1 + NJ); N_PAIR(0x020, NJ);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 1 - 2 * NJ, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        lfrag(buf, 3, 1);
+        mma(0);
+        lstore(buf ^ 1);
+        N_PAIR(0x100, 1 + NJ); N_PAIR(0x200, NJ == 3 ? 7 : 5);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        lfrag(buf ^ 1, 0, 0);
+        mma(1);
+        N_PAIR(0x100, 1 + NJ);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 1 - NJ, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // epilogue: C layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); bias, then the 4 x 4 quad transpose of conv_gemm.hip
     const int lq = lane & 3;
