@@ -112,26 +112,33 @@ __device__ __forceinline__ double readlane_d(double v, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-template <int CTRL, int RM> __device__ __forceinline__ MinIdx dpp_step(MinIdx m)
+// Wave minimum in two moves instead of six (value, index) butterfly steps of ~12 dependent instructions each: the minimum VALUE
+// first (v_min_f64 over DPP moves), then a ballot of the lanes that hold it.  One lane in the ballot (the rule on data without
+// ties): its index is read with v_readlane.  Several: the lowest index among them, as `better` decides.  Same result as the
+// butterfly for every input without NaN (distances are never NaN here).
+__device__ __forceinline__ double wave_min_d(double v)
 {
-    MinIdx t; t.v = dppd<CTRL, RM>(m.v); t.i = dppi<CTRL, RM>(m.i);
-    return better(m, t);
+    v = fmin(v, dppd<0xB1, 0xF>(v)); v = fmin(v, dppd<0x4E, 0xF>(v)); v = fmin(v, dppd<0x141, 0xF>(v)); v = fmin(v, dppd<0x140, 0xF>(v));
+    v = fmin(v, dppd<0x142, 0xA>(v)); v = fmin(v, dppd<0x143, 0xC>(v));
+    return readlane_d(v, 63);
 }
-// lanes 31 / 63 end up with the minima of lanes 0-31 / 32-63
-__device__ __forceinline__ MinIdx half_min(MinIdx m)
+__device__ __forceinline__ int wave_min_i(int v)
 {
-    m = dpp_step<0xB1, 0xF>(m);      // quad_perm [1,0,3,2]
-    m = dpp_step<0x4E, 0xF>(m);      // quad_perm [2,3,0,1]
-    m = dpp_step<0x141, 0xF>(m);     // row_half_mirror
-    m = dpp_step<0x140, 0xF>(m);     // row_mirror: every lane holds its row's minimum
-    m = dpp_step<0x142, 0xA>(m);     // row_bcast15 into rows 1 and 3
-    return m;
+    v = min(v, dppi<0xB1, 0xF>(v)); v = min(v, dppi<0x4E, 0xF>(v)); v = min(v, dppi<0x141, 0xF>(v)); v = min(v, dppi<0x140, 0xF>(v));
+    v = min(v, dppi<0x142, 0xA>(v)); v = min(v, dppi<0x143, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ MinIdx wave_min(MinIdx m)
 {
-    m = half_min(m);
-    m = dpp_step<0x143, 0xC>(m);     // row_bcast31 into rows 2 and 3
-    MinIdx r; r.v = readlane_d(m.v, 63); r.i = __builtin_amdgcn_readlane(m.i, 63);
+    const bool has = m.i >= 0;
+    const double vmin = wave_min_d(has ? m.v : (double)INFINITY);
+    const bool at = has && m.v == vmin;
+    const unsigned long long mask = __ballot(at);
+    MinIdx r; r.v = INFINITY; r.i = -1;
+    if (mask == 0) return r;
+    r.v = vmin;
+    if (mask & (mask - 1)) r.i = wave_min_i(at ? m.i : 0x7fffffff);
+    else r.i = __builtin_amdgcn_readlane(m.i, __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1));
     return r;
 }
 
@@ -438,17 +445,26 @@ __device__ __forceinline__ void cand_acc(Cand& m, double v, int z, int y, int fr
         else m.fresh |= tie;
     }
 }
-template <int CTRL, int RM> __device__ __forceinline__ Cand dpp_step_c(Cand m)
-{
-    Cand t; t.v = dppd<CTRL, RM>(m.v); t.i = dppi<CTRL, RM>(m.i); t.y = dppi<CTRL, RM>(m.y); t.fresh = dppi<CTRL, RM>(m.fresh);
-    return cbetter(m, t);
-}
+// same two moves for candidates.  cbetter's tie rule survives: the winner is the lowest row among the lanes at the minimum, and
+// CAND_TIE is raised when a DIFFERENT row sits at the same finite bound (flags inherited from the losers add nothing to that)
 __device__ __forceinline__ Cand wave_min_c(Cand m)
 {
-    m = dpp_step_c<0xB1, 0xF>(m); m = dpp_step_c<0x4E, 0xF>(m); m = dpp_step_c<0x141, 0xF>(m); m = dpp_step_c<0x140, 0xF>(m);
-    m = dpp_step_c<0x142, 0xA>(m); m = dpp_step_c<0x143, 0xC>(m);
-    Cand r; r.v = readlane_d(m.v, 63); r.i = __builtin_amdgcn_readlane(m.i, 63);
-    r.y = __builtin_amdgcn_readlane(m.y, 63); r.fresh = __builtin_amdgcn_readlane(m.fresh, 63);
+    const bool has = m.i >= 0;
+    const double vmin = wave_min_d(has ? m.v : (double)INFINITY);
+    const bool at = has && m.v == vmin;
+    const unsigned long long mask = __ballot(at);
+    Cand r; r.v = INFINITY; r.i = -1; r.y = -1; r.fresh = 0;
+    if (mask == 0) return r;
+    unsigned long long wm = mask;
+    int extra = 0;
+    if (mask & (mask - 1)) {
+        const int ii = wave_min_i(at ? m.i : 0x7fffffff);
+        wm = __ballot(at && m.i == ii);
+        if (wm != mask && vmin < (double)INFINITY) extra = CAND_TIE;
+    }
+    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1);
+    r.v = vmin; r.i = __builtin_amdgcn_readlane(m.i, l); r.y = __builtin_amdgcn_readlane(m.y, l);
+    r.fresh = __builtin_amdgcn_readlane(m.fresh, l) | extra;
     return r;
 }
 __device__ __forceinline__ Cand block_min_c(Cand m, Cand* sh, int nwaves)
@@ -458,9 +474,24 @@ __device__ __forceinline__ Cand block_min_c(Cand m, Cand* sh, int nwaves)
     __syncthreads();
     if (lane == 0) sh[w] = m;
     __syncthreads();
-    Cand r = sh[0];
-    for (int k = 1; k < nwaves; ++k) r = cbetter(r, sh[k]);
-    return r;
+    Cand r; r.v = INFINITY; r.i = -1; r.y = -1; r.fresh = 0;
+    if (lane < nwaves) r = sh[lane];
+    return wave_min_c(r);                // every wave folds the per-wave winners itself
+}
+// the two reductions of a merge round (NN(y) partial and local arg-min) through ONE LDS exchange
+__device__ __forceinline__ void block_min_qc(MinIdx& q, Cand& m, MinIdx* shq, Cand* shc, int nwaves)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    q = wave_min(q);
+    m = wave_min_c(m);
+    __syncthreads();
+    if (lane == 0) { shq[w] = q; shc[w] = m; }
+    __syncthreads();
+    MinIdx rq; rq.v = INFINITY; rq.i = -1;
+    Cand r; r.v = INFINITY; r.i = -1; r.y = -1; r.fresh = 0;
+    if (lane < nwaves) { rq = shq[lane]; r = shc[lane]; }
+    q = wave_min(rq);
+    m = wave_min_c(r);
 }
 
 // ---------------------------------------------------------------- k_linkage_mw : the cooperative kernel
@@ -481,25 +512,27 @@ typedef unsigned long long MwGran;
 
 template <bool ONEX>
 __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* size_all, int* cid, int* nb, double* md,
-                                                         unsigned char* fresh_flag, double* Z, MwGran* gran /*[2][G][SLOT_WORDS], zeroed*/,
+                                                         double* Z, MwGran* gran /*[2][G][SLOT_WORDS], zeroed*/,
                                                          unsigned* sync, int cap /*owned rows per workgroup, upper bound*/, int G)
 {
-    extern __shared__ int dyn_lds[];
-    int* act = dyn_lds;              // [cap] owned active rows, unordered
-    int* pos = dyn_lds + cap;        // [cap] pos[z / G] = index of owned row z in act
+    extern __shared__ __attribute__((aligned(16))) int dyn_lds[];
+    // per owned row, 24 B of LDS: the active list and, beside every entry, the row's lower bound / neighbour / freshness.  The
+    // owner is the only reader of these in the hot loops (local arg-min, Lance-Williams pass), so they never leave the CU; the
+    // global md / nb copies are still written (row y's old bound is read by everybody) but not read back by the owner.
+    double* l_md = (double*)dyn_lds;                 // [cap] bound of act[p]
+    int* act = (int*)(l_md + cap);                   // [cap] owned active rows, unordered
+    int* pos = act + cap;                            // [cap] pos[z / G] = index of owned row z in act
+    int* l_nb = pos + cap;                           // [cap] neighbour of act[p]
+    unsigned char* l_fr = (unsigned char*)(l_nb + cap);   // [cap] freshness of act[p]
     __shared__ MinIdx sh[MWT_MAX / 64];
     __shared__ Cand shc[MWT_MAX / 64];
     __shared__ MinIdx s_part[KR][MWT_MAX / 64];
     __shared__ unsigned s_words[MWT][SLOT_WORDS];      // this round's slots of all workgroups, as received
     __shared__ Cand s_cand[MWT + 1];        // published local bests of the G <= 256 workgroups (+ row y)
-    __shared__ MinIdx s_nnp[MWT];
     __shared__ MinIdx s_row[KR];
     __shared__ int s_L[2][KR];
     __shared__ int s_nL[2];
     __shared__ int s_cnt;
-    __shared__ Cand s_best;
-    __shared__ MinIdx s_nn;
-    __shared__ int s_rowtie;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int T = blockDim.x, NW = T >> 6;
     int g = blockIdx.x;
@@ -558,11 +591,11 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = p0 + u * T;
-                int z = p < cnt ? act[p] : -1;
+                const int pc = p < cnt ? p : 0;
+                int z = p < cnt ? act[pc] : -1;
                 if (z >= n - 1) z = -1;
                 zz[u] = z;
-                const int zc = z >= 0 ? z : 0;
-                v[u] = md[zc]; ny_[u] = nb[zc]; fr[u] = fresh_flag[zc];
+                v[u] = l_md[pc]; ny_[u] = l_nb[pc]; fr[u] = l_fr[pc];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -632,51 +665,55 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     auto word_d = [&](int sl, int wd) -> double {
         return __longlong_as_double((long long)(((unsigned long long)s_words[sl][wd + 1] << 32) | s_words[sl][wd]));
     };
-    // after a barrier: gather all slots; reduce the NN(y) partials, the refreshed rows, the global best; pick the next refresh list
+    // after consume(): every WAVE folds the G slots itself -- global best, NN(y), "row x had a second pair" -- so a merge round
+    // needs no LDS broadcast and no workgroup barrier here; only a retry round (refreshed rows are folded one per wave) has two
+    Cand d_best; MinIdx d_nn; int d_rowtie = 0;
+    d_best.v = INFINITY; d_best.i = -1; d_best.y = -1; d_best.fresh = 0; d_nn = none;
     auto digest = [&](int nLprev, const int* Lprev, int yrow, bool with_nn) {
-        if (nLprev == 0) { if (tid == 0) s_rowtie = 0; __syncthreads(); if (tid < G && s_words[tid][8]) s_rowtie = 1; }
-        if (tid < G) {
+        if (tid < G) {          // kept for pick_stale (read there behind a barrier)
             Cand c; c.v = word_d(tid, 0); c.i = (int)s_words[tid][2]; c.y = (int)s_words[tid][3]; c.fresh = (int)s_words[tid][4]; s_cand[tid] = c;
-            MinIdx a; a.v = word_d(tid, 5); a.i = (int)s_words[tid][7]; s_nnp[tid] = a;
         }
-        if (wv < (nLprev + 1) / 2) {          // refreshed rows: 2 per wave (one per 32-lane half), all lanes active
-            const int r = tid >> 5, l = tid & 31;
-            MinIdx a = none, pl[8];
-            if (r < nLprev) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const int u = l + 32 * e; const int uc = u < G ? u : 0; pl[e].v = word_d(uc, 8 + 3 * r); pl[e].i = u < G ? (int)s_words[uc][10 + 3 * r] : -1; }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a = better(a, pl[e]);
+        if (nLprev > 0) {
+            for (int r = wv; r < nLprev; r += NW) {          // refreshed rows: one wave folds the G partial minima of a row
+                MinIdx a = none;
+                for (int u = lane; u < G; u += 64) { MinIdx pq; pq.v = word_d(u, 8 + 3 * r); pq.i = (int)s_words[u][10 + 3 * r]; a = better(a, pq); }
+                a = wave_min(a);
+                if (lane == 0) s_row[r] = a;
             }
-            a = half_min(a);
-            if (l == 31 && r < nLprev) s_row[r] = a;
+            __syncthreads();
         }
-        __syncthreads();
-        if (wv == 0) {                 // global best over the published candidates and the rows refreshed in this round (now exact)
-            Cand b; b.v = INFINITY; b.i = -1; b.y = -1; b.fresh = 0;
-            for (int u = lane; u < G; u += 64) b = cbetter(b, s_cand[u]);
-            if (lane < nLprev) {
-                Cand c; c.i = Lprev[lane]; c.y = s_row[lane].i; c.v = (c.y < 0) ? INFINITY : s_row[lane].v; c.fresh = 1;
-                if (c.y >= 0) b = cbetter(b, c);
+        Cand b; b.v = INFINITY; b.i = -1; b.y = -1; b.fresh = 0;
+        MinIdx a = none;
+        int rt = 0;
+        for (int u = lane; u < G; u += 64) {
+            Cand c; c.v = word_d(u, 0); c.i = (int)s_words[u][2]; c.y = (int)s_words[u][3]; c.fresh = (int)s_words[u][4];
+            b = cbetter(b, c);
+            if (with_nn) { MinIdx pq; pq.v = word_d(u, 5); pq.i = (int)s_words[u][7]; a = better(a, pq); }
+            if (nLprev == 0) rt |= (int)s_words[u][8];
+        }
+        if (lane < nLprev) {           // the rows refreshed in this round are exact now
+            Cand c; c.i = Lprev[lane]; c.y = s_row[lane].i; c.v = (c.y < 0) ? INFINITY : s_row[lane].v; c.fresh = 1;
+            if (c.y >= 0) b = cbetter(b, c);
+        }
+        d_best = wave_min_c(b);
+        if (with_nn) d_nn = wave_min(a);
+        d_rowtie = (nLprev == 0 && __ballot(rt != 0) != 0ull) ? 1 : 0;
+        if (nLprev > 0) {
+            // owners store the refreshed rows (read back only by the owner's later arg-mins)
+            if (tid < nLprev && (Lprev[tid] % G) == g) {
+                const int x = Lprev[tid]; const MinIdx q = s_row[tid];
+                const double qv = (q.i < 0) ? (double)INFINITY : q.v;
+                const int px = pos[x / G];
+                l_nb[px] = q.i; l_md[px] = qv; l_fr[px] = 1;
+                STX<ONEX>(&nb[x], q.i); STX<ONEX>(&md[x], qv);
             }
-            b = wave_min_c(b);
-            if (lane == 0) s_best = b;
-        } else if (wv == 1 && with_nn) {
-            MinIdx a = none;
-            for (int u = lane; u < G; u += 64) a = better(a, s_nnp[u]);
-            a = wave_min(a);
-            if (lane == 0) s_nn = a;
+            __syncthreads();
         }
-        // owners store the refreshed rows (read back only by the owner's later arg-mins)
-        if (tid < nLprev && (Lprev[tid] % G) == g) {
-            const int x = Lprev[tid]; const MinIdx q = s_row[tid];
-            STX<ONEX>(&nb[x], q.i); STX<ONEX>(&md[x], (q.i < 0) ? (double)INFINITY : q.v); fresh_flag[x] = 1;
-        }
-        __syncthreads();
     };
     // the next refresh list: the KR best stale candidates among s_cand[0..G) and `extra` (row y after a merge); wave 0
     // extracts them one by one from registers, every workgroup arrives at the same list
     auto pick_stale = [&](Cand extra, int slot) {
+        __syncthreads();               // s_cand of this round complete
         if (wv == 0) {
             MinIdx c[5];
 #pragma unroll
@@ -721,7 +758,10 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
 
     // ---- initial state: exact bounds from k_row_nn; owned rows g, g+G, ...
     int cnt0 = 0;
-    for (int z = g + G * tid, i2 = tid; z < n; z += G * T, i2 += T) { act[i2] = z; pos[i2] = i2; if (z < n - 1) fresh_flag[z] = 1; }
+    for (int z = g + G * tid, i2 = tid; z < n; z += G * T, i2 += T) {
+        act[i2] = z; pos[i2] = i2;
+        l_md[i2] = z < n - 1 ? md[z] : (double)INFINITY; l_nb[i2] = z < n - 1 ? nb[z] : -1; l_fr[i2] = 1;
+    }
     if (tid == 0) { cnt0 = (n - g + G - 1) / G; if (cnt0 < 0) cnt0 = 0; s_cnt = cnt0; s_nL[0] = 0; s_nL[1] = 0; }
     __syncthreads();
     {
@@ -731,9 +771,18 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     if (!consume(9)) return;
     digest(0, s_L[0], -1, false);
     par ^= 1;
-    Cand best = s_best;
+    Cand best = d_best;
     if (!((best.fresh & 1) && best.y >= 0)) pick_stale(nocand, lp);
     int x = best.i, y = best.y; double dist = best.v; bool fresh = (best.fresh & 1) != 0;
+    // cluster sizes of the pair about to merge, requested as soon as the pair is known (an L2 round trip off the merge's serial path)
+    int nx_pre = 0, ny_pre = 0, cx_pre = 0, cy_pre = 0;            // (workgroup 0's first thread also needs the pair's dendrogram ids)
+    auto prefetch_pair = [&]() {
+        if (fresh && y >= 0) {
+            nx_pre = size[x]; ny_pre = size[y];
+            if (g == 0 && tid == 0) { cx_pre = cid[x]; cy_pre = cid[y]; }
+        }
+    };
+    prefetch_pair();
     // a merge is taken from the arg-min only when its pair is the UNIQUE closest pair; otherwise the kernel stops and
     // run_linkage repeats the job with k_linkage_heap, which owns the reference's tie order
     auto tie_stop = [&](int flags) -> bool {
@@ -758,25 +807,27 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
             STAMP2(2);
             digest(nL, L, -1, false);
             par ^= 1;
-            best = s_best;
+            best = d_best;
             STAMP2(3);
             lp ^= 1;
             if (!((best.fresh & 1) && best.y >= 0)) pick_stale(nocand, lp);
             STAMP2(4);
             x = best.i; dist = best.v; y = best.y; fresh = (best.fresh & 1) != 0;
+            prefetch_pair();
         }
         if (tie_stop(best.fresh)) return;
         // ---- merge (x, y) at height dist
-        const int nx = size[x], ny = size[y];
+        const int nx = nx_pre, ny = ny_pre;
         __syncthreads();
         if (tid == 0) {
             size[x] = 0; size[y] = nx + ny;
             if ((x % G) == g) {                               // owner drops x from its active list
                 const int p = pos[x / G], c2 = s_cnt - 1, last = act[c2];
                 act[p] = last; pos[last / G] = p; s_cnt = c2;
+                l_md[p] = l_md[c2]; l_nb[p] = l_nb[c2]; l_fr[p] = l_fr[c2];
             }
             if (g == 0) {
-                int ix = cid[x], iy = cid[y];
+                int ix = cx_pre, iy = cy_pre;
                 if (ix > iy) { const int t = ix; ix = iy; iy = t; }
                 Z[(size_t)k * 4 + 0] = (double)ix; Z[(size_t)k * 4 + 1] = (double)iy;
                 Z[(size_t)k * 4 + 2] = dist;       Z[(size_t)k * 4 + 3] = (double)(nx + ny);
@@ -795,19 +846,20 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         int zdummy = 0;                                   // any valid row other than x and y (n >= 3 here)
         while (zdummy == x || zdummy == y) ++zdummy;
         for (int p0 = tid; p0 < cnt; p0 += T * 4) {
-            double dzx[4], dzy[4], mdz[4]; int zz[4], nbz[4], frz[4]; int64_t izy[4];
+            double dzx[4], dzy[4], mdz[4]; int zz[4], nbz[4], frz[4], pp[4]; int64_t izy[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = p0 + u * T;
-                int z = p < cnt ? act[p] : -1;
+                const int pc = p < cnt ? p : 0;
+                pp[u] = pc;
+                int z = p < cnt ? act[pc] : -1;
                 if (z == y) z = -1;
                 zz[u] = z;
                 const int zc = z >= 0 ? z : zdummy;
                 izy[u] = cidx(N, zc, y);
                 dzx[u] = LDG(&D[cidx(N, zc, x)]);
                 dzy[u] = LDG(&D[izy[u]]);
-                const int zr = zc < n - 1 ? zc : n - 2;
-                nbz[u] = nb[zr]; mdz[u] = md[zr]; frz[u] = fresh_flag[zr];
+                nbz[u] = l_nb[pc]; mdz[u] = l_md[pc]; frz[u] = l_fr[pc];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -821,15 +873,14 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                     bool touch = false;
                     if (z < x && nz == x) { nz = y; touch = true; }
                     else if (nz == y) touch = true;
-                    if (nd < mz) { nz = y; mz = nd; fz = 1; STX<ONEX>(&md[z], nd); STX<ONEX>(&nb[z], y); fresh_flag[z] = 1; }
-                    else if (touch) { fz = (mz == nd); STX<ONEX>(&nb[z], nz); fresh_flag[z] = (unsigned char)fz; }
+                    if (nd < mz) { nz = y; mz = nd; fz = 1; l_md[pp[u]] = nd; l_nb[pp[u]] = y; l_fr[pp[u]] = 1; STX<ONEX>(&md[z], nd); STX<ONEX>(&nb[z], y); }
+                    else if (touch) { fz = (mz == nd); l_nb[pp[u]] = nz; l_fr[pp[u]] = (unsigned char)fz; STX<ONEX>(&nb[z], nz); }
                 } else if (nd < q.v || (nd == q.v && z < q.i)) { q.v = nd; q.i = z; }
                 if (z < n - 1) cand_acc(m, mz, z, nz, fz);
             }
         }
         STAMP2(6);
-        q = block_min_t(q, sh, NW);
-        m = block_min_c(m, shc, NW);
+        block_min_qc(q, m, sh, shc, NW);
         row_tie = __syncthreads_or(row_tie);
         publish(q, m, 0, s_row, row_tie);
         STAMP2(7);
@@ -838,18 +889,18 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         digest(0, s_L[lp], y, true);
         STAMP2(3);
         par ^= 1;
-        if (s_rowtie) { if (g == 0 && tid == 0) sync[5] = 1; return; }
-        best = s_best;
-        const MinIdx nn = s_nn;
+        if (d_rowtie) { if (g == 0 && tid == 0) sync[5] = 1; return; }
+        best = d_best;
+        const MinIdx nn = d_nn;
         // row y: exact by construction when it has an active neighbour above (cl.cpp:395-404), else its old (stale) bound
         Cand cy; cy.i = -1; cy.v = INFINITY; cy.y = -1; cy.fresh = 0;
         if (y < n - 1) {
             if (nn.i >= 0) {
                 cy.v = nn.v; cy.i = y; cy.y = nn.i; cy.fresh = 1;
-                if (tid == 0 && (y % G) == g) { STX<ONEX>(&nb[y], nn.i); STX<ONEX>(&md[y], nn.v); fresh_flag[y] = 1; }
+                if (tid == 0 && (y % G) == g) { const int py = pos[y / G]; l_nb[py] = nn.i; l_md[py] = nn.v; l_fr[py] = 1; STX<ONEX>(&nb[y], nn.i); STX<ONEX>(&md[y], nn.v); }
             } else {
                 cy.v = LDG(&md[y]); cy.i = y; cy.y = LDG(&nb[y]); cy.fresh = 0;
-                if (tid == 0 && (y % G) == g) fresh_flag[y] = 0;
+                if (tid == 0 && (y % G) == g) l_fr[pos[y / G]] = 0;
             }
             best = cbetter(best, cy);
         }
@@ -857,6 +908,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         if (!((best.fresh & 1) && best.y >= 0)) pick_stale(cy, lp);
         STAMP2(4);
         x = best.i; dist = best.v; y = best.y; fresh = (best.fresh & 1) != 0;
+        prefetch_pair();
     }
 #ifdef SD_LINKAGE_STAMPS
     if (g == 0 && tid == 0) for (int i = 0; i < 8; ++i) sync[8 + i] = (unsigned)(acc[i] / 100);   // microseconds
@@ -958,10 +1010,10 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     if (G < 0) G = N >= 60000 ? 128 : N >= 8000 ? 64 : N >= 1500 ? 32 : 0;
     if (G > c->num_cu) G = c->num_cu;
     int TH = (int)c->linkage_threads;
-    if (TH <= 0) TH = (N >= 8000 || auto_onex) ? 512 : 256;           // measured: 188 vs 195 ms at N = 12 602, 327 vs 337 ms at N = 21 573, 4.68 vs 4.85 s at N = 172 773
+    if (TH <= 0) TH = auto_onex ? 256 : N >= 8000 ? 512 : 256;           // measured: 188 vs 195 ms at N = 12 602, 327 vs 337 ms at N = 21 573, 4.68 vs 4.85 s at N = 172 773
     TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : 256;
     if (G <= 1) return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
-    if ((N + G - 1) / G > 7000) G = (int)((N + 6999) / 7000);      // active-row lists live in LDS: 8 B per owned row
+    if ((N + G - 1) / G > 4000) G = (int)((N + 3999) / 4000);      // active-row lists and bounds live in LDS: 24 B per owned row
     if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
     int cap = (int)((N + G - 1) / G) + 1;
     // one-XCD form while two workgroups per CU of one XCD (32 CUs) can hold the job; above, all XCDs' memory pipelines are worth more
@@ -969,7 +1021,6 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * SLOT_WORDS);
     HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * SLOT_WORDS * sizeof(MwGran), c->stream));
     WS(c, int, size_all, "cl_size_all", (int64_t)G * N);
-    WS(c, unsigned char, fresh_flag, "cl_fresh", N + 16);
     hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)(((int64_t)G * N + 255) / 256)), dim3(256), 0, c->stream, size_all, 1, (int64_t)G * N, 0);
     KCHECK(c);
     WS(c, unsigned, sync, "cl_sync", 16);
@@ -978,14 +1029,14 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     {
         ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
         int n_i = (int)N;
-        void* args[] = {&D, &n_i, &size_all, &cid, &nb, &md, &fresh_flag, &d_Z, &gran, &sync, &cap, &G};
+        void* args[] = {&D, &n_i, &size_all, &cid, &nb, &md, &d_Z, &gran, &sync, &cap, &G};
         // cooperative launch: all workgroups are resident together, or the launch is refused (they poll each other's slots)
         hipError_t le = hipErrorUnknown;
         if (onex) {
-            le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<true>, dim3(8 * G), dim3(TH), args, (size_t)cap * 8, c->stream);
+            le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<true>, dim3(8 * G), dim3(TH), args, (size_t)cap * 24, c->stream);
             if (le != hipSuccess) { (void)hipGetLastError(); onex = false; }
         }
-        if (!onex) le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<false>, dim3(G), dim3(TH), args, (size_t)cap * 8, c->stream);
+        if (!onex) le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<false>, dim3(G), dim3(TH), args, (size_t)cap * 24, c->stream);
         if (le != hipSuccess) { (void)hipGetLastError(); why = "cooperative launch refused"; }
     }
     unsigned h[16] = {0};
