@@ -180,15 +180,17 @@ extern "C" int sd_ecapa(sd_ctx* c, const float* h_feats, const float* h_lens, in
 {
     ENTER(c);
     if (!h_feats || !h_lens || !h_emb || items <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_ecapa: bad argument");
-    std::vector<int> nv((size_t)items), rowoff, rowoffN;
+    std::vector<int> nv((size_t)items);
+    EcapaRowPlan plan;
     for (int64_t i = 0; i < items; ++i) {
         float lt = h_lens[i] * (float)SD_T;
         int v = (int)ceilf(lt); if (v > SD_T) v = SD_T; if (v < 1) v = 1;
         nv[(size_t)i] = v;
     }
-    DTMP(c, dv, items * sizeof(int)); DTMP(c, dr, 2 * (items + 1) * sizeof(int)); DTMP(c, de, items * SD_EMB_DIM * sizeof(float));
-    int rc = ecapa_row_plan(c, nv.data(), items, rowoff, rowoffN, (int*)dr.p);
+    DTMP(c, dv, items * sizeof(int)); DTMP(c, dr, EC_SPACES * (items + 1) * sizeof(int)); DTMP(c, de, items * SD_EMB_DIM * sizeof(float));
+    int rc = ecapa_row_plan(c, nv.data(), items, plan, (int*)dr.p);
     if (rc) return rc;
+    const std::vector<int>& rowoff = plan.off[0];
     const int64_t rows = rowoff[(size_t)items];
     std::vector<float> tmp((size_t)rows * SD_FEAT_LD, 0.0f);                                 // compact rows: the frames each item needs
     for (int64_t i = 0; i < items; ++i)
@@ -203,10 +205,7 @@ extern "C" int sd_ecapa(sd_ctx* c, const float* h_feats, const float* h_lens, in
         int64_t a1 = a0;
         while (a1 < items && a1 - a0 < ROWTAB_MAX_ITEMS && rowoff[(size_t)a1 + 1] - rowoff[(size_t)a0] <= cap_rows) ++a1;
         if (a1 == a0) a1 = a0 + 1;
-        const int base = rowoff[(size_t)a0], baseN = rowoffN[(size_t)a0];
-        if ((rc = run_ecapa(c, (const float*)df.p + (size_t)base * SD_FEAT_LD, (const int*)dv.p + a0, (const int*)dr.p + a0, base,
-                            (const int*)dr.p + items + 1 + a0, baseN, a1 - a0, rowoff[(size_t)a1] - base, rowoffN[(size_t)a1] - baseN,
-                            (float*)de.p + (size_t)a0 * SD_EMB_DIM))) return rc;
+        if ((rc = run_ecapa(c, (const float*)df.p, (const int*)dv.p, plan, a0, a1, (float*)de.p))) return rc;
         a0 = a1;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));

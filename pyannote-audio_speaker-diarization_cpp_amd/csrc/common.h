@@ -181,10 +181,19 @@ int frontend_prepare(sd_ctx* c, const float* d_masks, int64_t items, int64_t fir
 int frontend_features(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_item, int64_t run_items, bool compact, const int* d_nnorm,
                       const int* d_rowoff, float* d_feats /*[rowoff[run_items]][96]*/);
 // ---- ecapa.hip
-int ecapa_need_rows(int nvalid, bool skip_dead_rows);
-int ecapa_row_plan(sd_ctx* c, const int* h_nvalid, int64_t n, std::vector<int>& rowoff, std::vector<int>& rowoffN, int* d_rowoff /*[2][n + 1]: wide, narrow*/);
-int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, const int* d_rowoffN, int row_baseN,
-              int64_t items, int64_t rows, int64_t rowsN, float* d_emb);
+// Compact row spaces of the embedding network: space s stores the frames t < min(501, nvalid + EC_MARGIN[s]) of every item.
+// A layer is only computed where a later valid frame can see it (ecapa.hip): block0 / block 1 run in space 0, block 2 in space 1,
+// block 3 in space 2, MFA and the attentive pooling in space 3 (the valid frames alone).
+#define EC_SPACES 4
+struct EcapaRowPlan {
+    int64_t n = 0;
+    std::vector<int> off[EC_SPACES];      // host prefix sums [n + 1]
+    const int* d_off = nullptr;           // device copy [EC_SPACES][n + 1]
+};
+int ecapa_need_rows(int nvalid, bool skip_dead_rows);             // rows of an item in space 0
+int ecapa_row_plan(sd_ctx* c, const int* h_nvalid, int64_t n, EcapaRowPlan& plan, int* d_off /*[EC_SPACES][n + 1]*/);
+// items [a0, a1) of the plan; d_feats = space-0 rows of ALL the plan's items
+int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid /*[n]*/, const EcapaRowPlan& plan, int64_t a0, int64_t a1, float* d_emb /*[n][192]*/);
 int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item, float* d_emb);
 // ---- pyannet.hip
 int run_segment(sd_ctx* c, const float* d_wav, int64_t n, int64_t chunk_lo, int64_t chunk_hi, float* d_seg);

@@ -41,8 +41,11 @@ template <class T> __device__ __forceinline__ void st4(T* p, float4 v)
     if constexpr (sizeof(T) == 4) *(float4*)p = v;
     else { typename Vec4<_Float16>::type h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; *(typename Vec4<_Float16>::type*)p = h; }
 }
+// rows = rows of t2's space; the residual and the output live in other (larger) spaces: their row of (item, t) is
+// map[row].x + t of the space table (nullptr = the same space as t2)
 template <class T> __global__ void k_se_apply(const T* __restrict__ t2, const float* __restrict__ gate, const T* __restrict__ res, int res_ld,
-                           T* __restrict__ y, int y_ld, int C, int64_t rows, const int2* __restrict__ rowtab)
+                           T* __restrict__ y, int y_ld, int C, int64_t rows, const int2* __restrict__ rowtab,
+                           const int2* __restrict__ res_map, const int2* __restrict__ out_map)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int c4n = C / 4;
@@ -50,12 +53,15 @@ template <class T> __global__ void k_se_apply(const T* __restrict__ t2, const fl
     const int64_t row = idx / c4n;
     const int c = (int)(idx - row * c4n) * 4;
     const int64_t item = ROWTAB_ITEM(rowtab[row].y);
+    int64_t rrow = row, orow = row;
+    if (res_map) { const int2 e = res_map[row]; rrow = (int64_t)e.x + ROWTAB_T(e.y); }
+    if (out_map) { const int2 e = out_map[row]; orow = (int64_t)e.x + ROWTAB_T(e.y); }
     const float4 a = ld4(t2 + row * C + c);
     const float4 g = *(const float4*)(gate + item * C + c);
-    const float4 r = ld4(res + row * res_ld + c);
+    const float4 r = ld4(res + rrow * res_ld + c);
     float4 o;
     o.x = g.x * a.x + r.x; o.y = g.y * a.y + r.y; o.z = g.z * a.z + r.z; o.w = g.w * a.w + r.w;
-    st4(y + row * y_ld + c, o);
+    st4(y + orow * y_ld + c, o);
 }
 
 // copy a channel slice [rows][w] between strided buffers (Res2Net first sub-band is identity)
@@ -172,37 +178,50 @@ static ConvArgs conv_args(const ConvLayer& L, const void* X, int x_ld, void* Y, 
 
 // One-sided reach of the network: 2 (block0, k5) + 7 * (2 + 3 + 4) (each Res2Net block chains 7 k3 convs of dilation 2 / 3 / 4;
 // the 1x1 convs and the SE gate add none) = 65 frames.  Frames >= nvalid are excluded from every statistic (SE mean, ASP),
-// so frames at or beyond min(501, nvalid + 65) cannot influence the embedding and are not stored at all.
-int ecapa_need_rows(int nvalid, bool skip_dead_rows)
+// so frames at or beyond min(501, nvalid + 65) cannot influence the embedding and are not stored at all.  The margin shrinks
+// on the way through the network: what block 3 hands to MFA is read at t < nvalid only, so its dilation-4 chain needs its input
+// up to nvalid + 28, block 2's output is needed that far and its dilation-3 chain needs nvalid + 49, block 1's chain nvalid + 63.
+static const int EC_MARGIN[EC_SPACES] = {65, 49, 28, 0};
+static int ec_space_rows(int nvalid, bool skip_dead_rows, int s)
 {
     if (!skip_dead_rows) return SD_T;
-    const int need = nvalid + 65;
+    const int need = nvalid + EC_MARGIN[s];
     return need > SD_T ? SD_T : (need < 1 ? 1 : need);
 }
+int ecapa_need_rows(int nvalid, bool skip_dead_rows) { return ec_space_rows(nvalid, skip_dead_rows, 0); }
 
-// d_feats: compact rows [rows][96] of `items` items; d_rowoff[items + 1] (first compact row of every item, in a row space that
-// starts at row_base for this batch); d_nvalid[items].  Two row spaces: the WIDE one (need_i = nvalid_i + receptive-field margin)
-// carries block0 and the three SE-Res2Net blocks; MFA is a 1x1 layer whose output is only ever read at frames < nvalid (ASP
-// statistics and pooling), so it reads wide rows and writes the NARROW space (nvalid_i rows per item, d_rowoffN / row_baseN /
-// rowsN), in which the ASP layers then run: 17 % fewer rows for half of the network's FLOPs on the planted hour.
+// d_feats: space-0 rows [plan.off[0][n]][96] of all the plan's items; this call runs items [a0, a1).  Per block b (dilation 2, 3, 4):
+//   tdnn1 and the Res2Net chain run in space b (block input: x0 in space 0, x1 / x2 in `cat`, which is stored in space 1),
+//   tdnn2, the SE statistics and the gate run in space b + 1, the block output (gate * t2 + input) goes to `cat` (space 1 rows).
+// MFA reads `cat` and writes space 3 (the valid frames), where the attentive pooling then runs.  A layer whose output space
+// differs from its input space goes through a row table (k_build_rowtab): output row -> item's first input row, frame, last
+// stored input frame.  On the planted hour: 4 % fewer rows for tdnn1 / Res2Net, 9 % for tdnn2, 17 % for MFA / ASP than space 0.
 template <class T>
-static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, const int* d_rowoffN, int row_baseN,
-                       int64_t items, int64_t rows, int64_t rowsN, float* d_emb)
+static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_all, const EcapaRowPlan& plan, int64_t a0, int64_t a1, float* d_emb_all)
 {
     constexpr int P = sizeof(T) == 2 ? 1 : 0;                  // conv_gemm precision of the per-frame layers
     const EcapaWeights& E = c->ew;
     if (!E.loaded) SD_FAIL(c, SD_ERR_MODEL, "embedding model not loaded");
+    const int64_t items = a1 - a0;
     if (items <= 0) return SD_OK;
     if (items > ROWTAB_MAX_ITEMS) SD_FAIL(c, SD_ERR_ARG, "ecapa batch of %lld items (limit %d)", (long long)items, ROWTAB_MAX_ITEMS);
     const int C = E.C, C3 = 3 * C;
-    const int64_t M = rows;
+    int64_t R[EC_SPACES]; int rbase[EC_SPACES]; const int* ro[EC_SPACES];
+    for (int sp = 0; sp < EC_SPACES; ++sp) {
+        rbase[sp] = plan.off[sp][(size_t)a0];
+        R[sp] = plan.off[sp][(size_t)a1] - rbase[sp];
+        ro[sp] = plan.d_off + (size_t)sp * (plan.n + 1) + a0;
+    }
+    const float* d_feats = d_feats_all + (size_t)rbase[0] * SD_FEAT_LD;
+    const int* d_nvalid = d_nvalid_all + a0;
+    float* d_emb = d_emb_all + (size_t)a0 * SD_EMB_DIM;
+    const int64_t M = R[0], MN = R[3];
     if (M > 0x7fffffff / 2) SD_FAIL(c, SD_ERR_ARG, "ecapa batch too large");
     WS(c, T, x0, "ec_x0", M * C);
     WS(c, T, t1, "ec_t1", M * C);
     WS(c, T, rr, "ec_r", M * C);
-    WS(c, T, t2, "ec_t2", M * C);
-    WS(c, T, cat, "ec_cat", M * C3);
-    const int64_t MN = rowsN;
+    WS(c, T, t2, "ec_t2", R[1] * C);
+    WS(c, T, cat, "ec_cat", R[1] * C3);
     WS(c, T, mfa, "ec_mfa", MN * C3);
     WS(c, T, hid, "ec_hid", MN * 128);
     WS(c, float, se_s, "ec_se_s", items * C);
@@ -211,16 +230,20 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, con
     WS(c, float, ms, "ec_ms", items * 2 * C3);
     WS(c, float, ib, "ec_ib", items * 128);
     WS(c, float, pooled, "ec_pooled", items * 2 * C3);
-    WS(c, int2, rowtab, "ec_rowtab", M + 128);
-    WS(c, int2, rowtab_nw, "ec_rowtab_nw", MN + 128);          // narrow rows -> wide input (MFA)
-    WS(c, int2, rowtab_n, "ec_rowtab_n", MN + 128);            // narrow -> narrow (ASP layers)
     int rc;
     hipStream_t st = c->stream;
-    hipLaunchKernelGGL(k_build_rowtab, dim3((unsigned)items), dim3(256), 0, st, d_rowoff, row_base, d_rowoff, row_base, rowtab);
-    hipLaunchKernelGGL(k_build_rowtab, dim3((unsigned)items), dim3(256), 0, st, d_rowoffN, row_baseN, d_rowoff, row_base, rowtab_nw);
-    hipLaunchKernelGGL(k_build_rowtab, dim3((unsigned)items), dim3(256), 0, st, d_rowoffN, row_baseN, d_rowoffN, row_baseN, rowtab_n);
-    KCHECK(c);
-#define WITH_LIST(a) do { (a).rowtab = rowtab; } while (0)
+    // row tables [output space][input space], built on first use
+    int2* tabs[EC_SPACES][EC_SPACES] = {};
+    auto tab = [&](int so, int si) -> int2* {
+        if (tabs[so][si]) return tabs[so][si];
+        char key[32]; snprintf(key, sizeof(key), "ec_rowtab_%d%d", so, si);
+        int2* p = ws_get<int2>(c, key, (size_t)R[so] + 128);
+        if (!p) return nullptr;
+        hipLaunchKernelGGL(k_build_rowtab, dim3((unsigned)items), dim3(256), 0, st, ro[so], rbase[so], ro[si], rbase[si], p);
+        tabs[so][si] = p;
+        return p;
+    };
+#define TAB(var, so, si) int2* var = tab(so, si); if (!var) SD_FAIL(c, SD_ERR_HIP, "hipMalloc of a row table failed")
 
     // blocks[0]: TDNNBlock(80 -> C, k5)
     const void* f_in = d_feats; int f_ld = SD_FEAT_LD;
@@ -230,55 +253,63 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, con
         KCHECK(c);
         f_in = fh; f_ld = 128;
     }
-    { ConvArgs a = conv_args(E.block0, f_in, f_ld, x0, C, M, true, P); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "block0"))) return rc; }
+    { TAB(t00, 0, 0); ConvArgs a = conv_args(E.block0, f_in, f_ld, x0, C, M, true, P); a.act1 = 1; a.rowtab = t00; if ((rc = launch_conv_gemm(c, a, "block0"))) return rc; }
 
     for (int b = 0; b < 3; ++b) {
         const auto& B = E.blk[b];
+        const int cs = b, os = b + 1, is = b == 0 ? 0 : 1;       // chain space, output space, space the block input is stored in
+        const int64_t Mc = R[cs], Mo = R[os];
         const T* xin = (b == 0) ? x0 : cat + (size_t)(b - 1) * C;
         const int xin_ld = (b == 0) ? C : C3;
-        { ConvArgs a = conv_args(B.tdnn1, xin, xin_ld, t1, C, M, true, P); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "tdnn1"))) return rc; }
+        TAB(t_in, cs, is); TAB(t_cc, cs, cs); TAB(t_oc, os, cs);
+        { ConvArgs a = conv_args(B.tdnn1, xin, xin_ld, t1, C, Mc, true, P); a.act1 = 1; a.rowtab = t_in; a.in_rows = (int)R[is]; if ((rc = launch_conv_gemm(c, a, "tdnn1"))) return rc; }
         const int S = C / 8;
-        hipLaunchKernelGGL(k_copy_slice<T>, GRID1(M * (S / 4)), 0, st, t1, C, rr, C, S, M);
+        hipLaunchKernelGGL(k_copy_slice<T>, GRID1(Mc * (S / 4)), 0, st, t1, C, rr, C, S, Mc);
         KCHECK(c);
         for (int i = 1; i < 8; ++i) {
-            ConvArgs a = conv_args(B.res[i - 1], t1 + i * S, C, rr + i * S, C, M, true, P);
+            ConvArgs a = conv_args(B.res[i - 1], t1 + i * S, C, rr + i * S, C, Mc, true, P);
             a.act1 = 1;
             if (i >= 2) { a.X2 = (const float*)(rr + (i - 1) * S); a.x2_ld = C; }
-            WITH_LIST(a);
+            a.rowtab = t_cc;
             if ((rc = launch_conv_gemm(c, a, "res2net"))) return rc;
         }
-        { ConvArgs a = conv_args(B.tdnn2, rr, C, t2, C, M, true, P); a.act1 = 1; WITH_LIST(a); if ((rc = launch_conv_gemm(c, a, "tdnn2"))) return rc; }
+        { ConvArgs a = conv_args(B.tdnn2, rr, C, t2, C, Mo, true, P); a.act1 = 1; a.rowtab = t_oc; a.in_rows = (int)Mc; if ((rc = launch_conv_gemm(c, a, "tdnn2"))) return rc; }
         {
-            ProfScope ps(c, "se_mean", 0, (double)M * C * 4.0);
-            hipLaunchKernelGGL(k_masked_mean<T>, dim3((C + 255) / 256, (unsigned)items), dim3(256), 0, st, t2, C, d_nvalid, d_rowoff, row_base, se_s, C);
+            ProfScope ps(c, "se_mean", 0, (double)Mo * C * 4.0);
+            hipLaunchKernelGGL(k_masked_mean<T>, dim3((C + 255) / 256, (unsigned)items), dim3(256), 0, st, t2, C, d_nvalid, ro[os], rbase[os], se_s, C);
             KCHECK(c);
         }
         { ConvArgs a = conv_args(B.se1, se_s, C, se_h, 128, items, false); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "se1"))) return rc; }
         { ConvArgs a = conv_args(B.se2, se_h, 128, se_g, C, items, false); a.act2 = 2; if ((rc = launch_conv_gemm(c, a, "se2"))) return rc; }
         {
-            ProfScope ps(c, "se_apply", 0, (double)M * C * 12.0);
-            hipLaunchKernelGGL(k_se_apply<T>, GRID1(M * (C / 4)), 0, st, t2, se_g, xin, xin_ld, cat + (size_t)b * C, C3, C, M, rowtab);
+            // block output = gate * t2 + block input, stored in `cat` (space 1 rows) at the frames of space os
+            const int2* res_map = nullptr; const int2* out_map = nullptr;
+            if (os != is) { TAB(m, os, is); res_map = m; }
+            if (os != 1) { TAB(m, os, 1); out_map = m; }
+            ProfScope ps(c, "se_apply", 0, (double)Mo * C * 12.0);
+            hipLaunchKernelGGL(k_se_apply<T>, GRID1(Mo * (C / 4)), 0, st, t2, se_g, xin, xin_ld, cat + (size_t)b * C, C3, C, Mo, t_oc, res_map, out_map);
             KCHECK(c);
         }
     }
     // mfa: TDNNBlock(3C -> 3C, k1) over cat(x1,x2,x3)
-    { ConvArgs a = conv_args(E.mfa, cat, C3, mfa, C3, MN, true, P); a.act1 = 1; a.rowtab = rowtab_nw; a.in_rows = (int)M; if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
+    TAB(t31, 3, 1); TAB(t33, 3, 3);
+    { ConvArgs a = conv_args(E.mfa, cat, C3, mfa, C3, MN, true, P); a.act1 = 1; a.rowtab = t31; a.in_rows = (int)R[1]; if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
     // ASP with global context: cat[x, mean, std] @ W == x @ Wx + (mean,std) @ Wms  (per-item bias)
     {
         ProfScope ps(c, "asp_stats", 0, (double)MN * C3 * 4.0);
-        hipLaunchKernelGGL(k_asp_stats<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, C3, d_nvalid, d_rowoffN, row_baseN, ms, C3);
+        hipLaunchKernelGGL(k_asp_stats<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, C3, d_nvalid, ro[3], rbase[3], ms, C3);
         KCHECK(c);
     }
     { ConvArgs a = conv_args(E.asp_tdnn_ms, ms, 2 * C3, ib, 128, items, false); if ((rc = launch_conv_gemm(c, a, "asp_ms"))) return rc; }
-    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, C3, hid, 128, MN, true, P); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; a.rowtab = rowtab_n; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
+    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, C3, hid, 128, MN, true, P); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; a.rowtab = t33; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
     // attention logits stay f32 in either mode (they feed an exp: fp16's 3 decimal digits at |logit| ~ 30 would be percents of a weight).
     // f32 mode: cat is dead after mfa and large enough; fp16 mode: its own buffer
     float* logits;
     if (P) { WS(c, float, lg, "ec_logits", MN * C3); logits = lg; } else logits = (float*)cat;
-    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, MN, true, P); a.rowtab = rowtab_n; a.y_f32 = 1; if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
+    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, MN, true, P); a.rowtab = t33; a.y_f32 = 1; if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
     {
         ProfScope ps(c, "asp_pool", 0, (double)MN * C3 * 8.0);
-        hipLaunchKernelGGL(k_asp_pool<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, C3, d_nvalid, d_rowoffN, row_baseN, pooled, C3);
+        hipLaunchKernelGGL(k_asp_pool<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, C3, d_nvalid, ro[3], rbase[3], pooled, C3);
         KCHECK(c);
     }
     // asp_bn folded into fc
@@ -286,29 +317,25 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats, const int* d_nvalid, con
     return SD_OK;
 }
 
-int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const int* d_rowoff, int row_base, const int* d_rowoffN, int row_baseN,
-              int64_t items, int64_t rows, int64_t rowsN, float* d_emb)
+int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const EcapaRowPlan& plan, int64_t a0, int64_t a1, float* d_emb)
 {
-    if (c->ecapa_precision == 1) return run_ecapa_t<_Float16>(c, d_feats, d_nvalid, d_rowoff, row_base, d_rowoffN, row_baseN, items, rows, rowsN, d_emb);
-    return run_ecapa_t<float>(c, d_feats, d_nvalid, d_rowoff, row_base, d_rowoffN, row_baseN, items, rows, rowsN, d_emb);
+    if (c->ecapa_precision == 1) return run_ecapa_t<_Float16>(c, d_feats, d_nvalid, plan, a0, a1, d_emb);
+    return run_ecapa_t<float>(c, d_feats, d_nvalid, plan, a0, a1, d_emb);
 }
 
-// host side of the compact row plan: need / rowoff of `n` items from their nvalid (uploaded to d_rowoff[n + 1])
-// rowoff: wide space (need rows per item), rowoffN: narrow space (nvalid rows per item; = wide when nothing is skipped)
-int ecapa_row_plan(sd_ctx* c, const int* h_nvalid, int64_t n, std::vector<int>& rowoff, std::vector<int>& rowoffN, int* d_rowoff)
+// host side of the compact row plan: first row of every item in each space, from the items' nvalid (uploaded to d_off)
+int ecapa_row_plan(sd_ctx* c, const int* h_nvalid, int64_t n, EcapaRowPlan& plan, int* d_off)
 {
-    rowoff.assign((size_t)n + 1, 0); rowoffN.assign((size_t)n + 1, 0);
-    int64_t acc = 0, accN = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        rowoff[(size_t)i] = (int)acc; rowoffN[(size_t)i] = (int)accN;
-        const int need = ecapa_need_rows(h_nvalid[i], c->skip_dead_rows);
-        int nv = h_nvalid[i]; if (nv > need) nv = need; if (nv < 1) nv = 1;
-        acc += need; accN += c->skip_dead_rows ? nv : need;
+    plan.n = n; plan.d_off = d_off;
+    for (int sp = 0; sp < EC_SPACES; ++sp) {
+        std::vector<int>& off = plan.off[sp];
+        off.assign((size_t)n + 1, 0);
+        int64_t acc = 0;
+        for (int64_t i = 0; i < n; ++i) { off[(size_t)i] = (int)acc; acc += ec_space_rows(h_nvalid[i], c->skip_dead_rows, sp); }
+        if (acc > 0x7fffffff / 4) SD_FAIL(c, SD_ERR_ARG, "embedding stage: %lld feature rows in one shard (limit %d)", (long long)acc, 0x7fffffff / 4);
+        off[(size_t)n] = (int)acc;
+        HIPCHK(c, hipMemcpyAsync(d_off + (size_t)sp * (n + 1), off.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
-    if (acc > 0x7fffffff / 4) SD_FAIL(c, SD_ERR_ARG, "embedding stage: %lld feature rows in one shard (limit %d)", (long long)acc, 0x7fffffff / 4);
-    rowoff[(size_t)n] = (int)acc; rowoffN[(size_t)n] = (int)accN;
-    HIPCHK(c, hipMemcpyAsync(d_rowoff, rowoff.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_rowoff + n + 1, rowoffN.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SD_OK;
 }
@@ -326,17 +353,18 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
     WS(c, int, nvalid, "emb_nvalid", items);
     WS(c, int, flags, "emb_flags", items);
     WS(c, int, cidx, "emb_cidx", items);
-    WS(c, int, d_rowoff, "emb_rowoff", 2 * (items + 1));
+    WS(c, int, d_rowoff, "emb_rowoff", EC_SPACES * (items + 1));
     WS(c, float, emb_c, "emb_compact", items * SD_EMB_DIM);
     int n_active = 0;
     if ((rc = frontend_prepare(c, d_masks, items, first_item, lens, nnorm, nvalid, flags, true, &n_active, cidx))) return rc;
     { KernelStat& ks = c->stats["items_live"]; ks.launches++; ks.flops += (double)n_active; ks.bytes += (double)items; }   // bench: live / all items
     if (n_active > 0) {
-        std::vector<int> h_nvalid((size_t)n_active), rowoff, rowoffN;
+        std::vector<int> h_nvalid((size_t)n_active);
+        EcapaRowPlan plan;
         HIPCHK(c, hipMemcpyAsync(h_nvalid.data(), nvalid, (size_t)n_active * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if ((rc = ecapa_row_plan(c, h_nvalid.data(), n_active, rowoff, rowoffN, d_rowoff))) return rc;
-        const int* d_rowoffN = d_rowoff + n_active + 1;
+        if ((rc = ecapa_row_plan(c, h_nvalid.data(), n_active, plan, d_rowoff))) return rc;
+        const std::vector<int>& rowoff = plan.off[0];
         const int64_t rows_all = rowoff[(size_t)n_active];
         WS(c, float, feats, "emb_feats", rows_all * SD_FEAT_LD);
         if ((rc = frontend_features(c, d_wav, n, first_item, n_active, true, nnorm, d_rowoff, feats))) return rc;
@@ -346,9 +374,7 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
             int64_t a1 = a0;
             while (a1 < n_active && a1 - a0 < ROWTAB_MAX_ITEMS && rowoff[(size_t)a1 + 1] - rowoff[(size_t)a0] <= cap_rows) ++a1;
             if (a1 == a0) a1 = a0 + 1;
-            const int base = rowoff[(size_t)a0], baseN = rowoffN[(size_t)a0];
-            if ((rc = run_ecapa(c, feats + (size_t)base * SD_FEAT_LD, nvalid + a0, d_rowoff + a0, base, d_rowoffN + a0, baseN, a1 - a0,
-                                rowoff[(size_t)a1] - base, rowoffN[(size_t)a1] - baseN, emb_c + (size_t)a0 * SD_EMB_DIM))) return rc;
+            if ((rc = run_ecapa(c, feats, nvalid, plan, a0, a1, emb_c))) return rc;
             a0 = a1;
         }
     }
