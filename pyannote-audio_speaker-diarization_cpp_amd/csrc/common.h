@@ -117,6 +117,7 @@ struct sd_ctx {
     int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation
     bool conv_w256_f32 = true;                  // f32: the same 256 x 256 kernel for the wide, long-K ECAPA layers (TDNN, MFA)
     int conv_pn128 = 0;                         // 128 x 128 kernel: column tiles per super-block (0 = 8); tuning
+    int ecapa_ld_pad = 0;                       // elements added to the leading dimensions of the ECAPA activation buffers (multiple of 8)
     int conv_w256_kmin = 0;                     // 256 x 256 kernel: shortest contraction Cin * KT it takes (0 = built-in: 1024 f32, 256 fp16); tuning
     int conv_pn = 0;                            // 256 x 256 kernel: column tiles per super-block (0 = 8); tuning
     bool conv_h256 = true;                      // fp16 mode: 256 x 256 tile kernel for the wide layers (conv_gemm_h.hip)

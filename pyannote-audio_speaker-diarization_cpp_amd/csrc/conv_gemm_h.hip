@@ -245,6 +245,33 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
         if (s == S - 1) {
             // ---- epilogue.  C layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); see conv_gemm.hip
             const float slope = (a.act1 == 1) ? 0.0f : ((a.act1 == 2) ? 0.01f : 1.0f);
+            if constexpr (!H) {
+                // f32: every accumulator register is one output row for 32 consecutive columns across a half-wave: stored as it
+                // lies, 128 contiguous bytes per row and instruction, no lane transposes (half the epilogue's VALU work).  The
+                // descriptor starts at the tile's first row and ends at the batch's last one, so rows >= M are dropped by the range
+                // check; the row term travels in the scalar offset.
+                const int rows_left = a.M - m0c;
+                const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.Y + (size_t)m0c * a.y_ld, (size_t)(rows_left < HM ? rows_left : HM) * a.y_ld * 4);
+                const unsigned ybytes = (unsigned)a.y_ld * 4u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cc = n0c + wc * 128 + j * 32 + li;
+                    const float cb = a.bias ? a.bias[cc] : 0.0f;
+                    const float cs = a.scale ? a.scale[cc] : 1.0f, ch = a.scale ? a.shift[cc] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const unsigned vo = (unsigned)(wr * 64 + i * 32 + 4 * lh) * ybytes + (unsigned)cc * 4u;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[i][j][r] + cb;
+                            acc[i][j][r] = 0.0f;
+                            v = fmaxf(v, v * slope);
+                            v = v * cs + ch;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rY, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * ybytes, 0);
+                        }
+                    }
+                }
+            } else {
             const int lq = lane & 3;
             _Float16* const Y = (_Float16*)a.Y;
 #pragma unroll
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
                         const int g = m0c + wr * 64 + i * 32 + 8 * gq + 4 * lh + lq;
                         const int co = n0c + wc * 128 + j * 32 + (li & ~3);
                         if (g < a.M && co < a.Cout) {
-                            if (!H || a.y_f32) *(float4*)(a.Y + (size_t)g * a.y_ld + co) = make_float4(x[0], x[1], x[2], x[3]);
+                            if (a.y_f32) *(float4*)(a.Y + (size_t)g * a.y_ld + co) = make_float4(x[0], x[1], x[2], x[3]);
                             else {
                                 const half4 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
                                 *(half4*)(Y + (size_t)g * a.y_ld + co) = hv;
@@ -287,6 +314,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
                         }
                     }
                 }
+            }
             }
             q = next_sb(q);
             if (q >= sb_end) break;
@@ -304,7 +332,7 @@ int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& in, const char* tag)
 {
     ConvArgs a = in;
     const bool h = a.prec == 1;
-    if (!a.rowtab || (h && !a.W16) || a.X2 || a.item_bias || a.R || a.act2 || a.pad_mode != 0 || a.Cout < 256 || (a.Cout & 3) || (a.y_ld & 3) ||
+    if (!a.rowtab || (h && !a.W16) || a.X2 || a.item_bias || a.R || a.act2 || a.pad_mode != 0 || a.Cout < 256 || (a.Cout % HN) != 0 || (a.y_ld & 3) ||
         a.Cin % (h ? 64 : 32) != 0 || a.M < 8 * HM) return 1;
     // fp16: the shortest contraction (ASP conv, K = 128) stays on the 128 x 128 form (measured); f32 takes every wide layer since the
     // K-groups are pinned (block0 K = 400: 92 -> 102 TF, ASP conv K = 128: 95 -> 105 TF)

@@ -43,7 +43,7 @@ template <class T> __device__ __forceinline__ void st4(T* p, float4 v)
 }
 // rows = rows of t2's space; the residual and the output live in other (larger) spaces: their row of (item, t) is
 // map[row].x + t of the space table (nullptr = the same space as t2)
-template <class T> __global__ void k_se_apply(const T* __restrict__ t2, const float* __restrict__ gate, const T* __restrict__ res, int res_ld,
+template <class T> __global__ void k_se_apply(const T* __restrict__ t2, int t2_ld, const float* __restrict__ gate, const T* __restrict__ res, int res_ld,
                            T* __restrict__ y, int y_ld, int C, int64_t rows, const int2* __restrict__ rowtab,
                            const int2* __restrict__ res_map, const int2* __restrict__ out_map)
 {
@@ -56,7 +56,7 @@ template <class T> __global__ void k_se_apply(const T* __restrict__ t2, const fl
     int64_t rrow = row, orow = row;
     if (res_map) { const int2 e = res_map[row]; rrow = (int64_t)e.x + ROWTAB_T(e.y); }
     if (out_map) { const int2 e = out_map[row]; orow = (int64_t)e.x + ROWTAB_T(e.y); }
-    const float4 a = ld4(t2 + row * C + c);
+    const float4 a = ld4(t2 + row * t2_ld + c);
     const float4 g = *(const float4*)(gate + item * C + c);
     const float4 r = ld4(res + rrow * res_ld + c);
     float4 o;
@@ -206,6 +206,9 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
     if (items <= 0) return SD_OK;
     if (items > ROWTAB_MAX_ITEMS) SD_FAIL(c, SD_ERR_ARG, "ecapa batch of %lld items (limit %d)", (long long)items, ROWTAB_MAX_ITEMS);
     const int C = E.C, C3 = 3 * C;
+    // leading dimensions of the activation buffers: rows of exactly 4 KB / 12 KB put the same 128-byte K-slice of all 256 rows of
+    // a tile on the same few HBM channels; option ecapa_ld_pad (elements, multiple of 8) skews them
+    const int LD = C + c->ecapa_ld_pad, LD3 = C3 + c->ecapa_ld_pad;
     int64_t R[EC_SPACES]; int rbase[EC_SPACES]; const int* ro[EC_SPACES];
     for (int sp = 0; sp < EC_SPACES; ++sp) {
         rbase[sp] = plan.off[sp][(size_t)a0];
@@ -217,12 +220,12 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
     float* d_emb = d_emb_all + (size_t)a0 * SD_EMB_DIM;
     const int64_t M = R[0], MN = R[3];
     if (M > 0x7fffffff / 2) SD_FAIL(c, SD_ERR_ARG, "ecapa batch too large");
-    WS(c, T, x0, "ec_x0", M * C);
-    WS(c, T, t1, "ec_t1", M * C);
-    WS(c, T, rr, "ec_r", M * C);
-    WS(c, T, t2, "ec_t2", R[1] * C);
-    WS(c, T, cat, "ec_cat", R[1] * C3);
-    WS(c, T, mfa, "ec_mfa", MN * C3);
+    WS(c, T, x0, "ec_x0", M * LD);
+    WS(c, T, t1, "ec_t1", M * LD);
+    WS(c, T, rr, "ec_r", M * LD);
+    WS(c, T, t2, "ec_t2", R[1] * LD);
+    WS(c, T, cat, "ec_cat", R[1] * LD3);
+    WS(c, T, mfa, "ec_mfa", MN * LD3);
     WS(c, T, hid, "ec_hid", MN * 128);
     WS(c, float, se_s, "ec_se_s", items * C);
     WS(c, float, se_h, "ec_se_h", items * 128);
@@ -253,30 +256,30 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
         KCHECK(c);
         f_in = fh; f_ld = 128;
     }
-    { TAB(t00, 0, 0); ConvArgs a = conv_args(E.block0, f_in, f_ld, x0, C, M, true, P); a.act1 = 1; a.rowtab = t00; if ((rc = launch_conv_gemm(c, a, "block0"))) return rc; }
+    { TAB(t00, 0, 0); ConvArgs a = conv_args(E.block0, f_in, f_ld, x0, LD, M, true, P); a.act1 = 1; a.rowtab = t00; if ((rc = launch_conv_gemm(c, a, "block0"))) return rc; }
 
     for (int b = 0; b < 3; ++b) {
         const auto& B = E.blk[b];
         const int cs = b, os = b + 1, is = b == 0 ? 0 : 1;       // chain space, output space, space the block input is stored in
         const int64_t Mc = R[cs], Mo = R[os];
         const T* xin = (b == 0) ? x0 : cat + (size_t)(b - 1) * C;
-        const int xin_ld = (b == 0) ? C : C3;
+        const int xin_ld = (b == 0) ? LD : LD3;
         TAB(t_in, cs, is); TAB(t_cc, cs, cs); TAB(t_oc, os, cs);
-        { ConvArgs a = conv_args(B.tdnn1, xin, xin_ld, t1, C, Mc, true, P); a.act1 = 1; a.rowtab = t_in; a.in_rows = (int)R[is]; if ((rc = launch_conv_gemm(c, a, "tdnn1"))) return rc; }
+        { ConvArgs a = conv_args(B.tdnn1, xin, xin_ld, t1, LD, Mc, true, P); a.act1 = 1; a.rowtab = t_in; a.in_rows = (int)R[is]; if ((rc = launch_conv_gemm(c, a, "tdnn1"))) return rc; }
         const int S = C / 8;
-        hipLaunchKernelGGL(k_copy_slice<T>, GRID1(Mc * (S / 4)), 0, st, t1, C, rr, C, S, Mc);
+        hipLaunchKernelGGL(k_copy_slice<T>, GRID1(Mc * (S / 4)), 0, st, t1, LD, rr, LD, S, Mc);
         KCHECK(c);
         for (int i = 1; i < 8; ++i) {
-            ConvArgs a = conv_args(B.res[i - 1], t1 + i * S, C, rr + i * S, C, Mc, true, P);
+            ConvArgs a = conv_args(B.res[i - 1], t1 + i * S, LD, rr + i * S, LD, Mc, true, P);
             a.act1 = 1;
-            if (i >= 2) { a.X2 = (const float*)(rr + (i - 1) * S); a.x2_ld = C; }
+            if (i >= 2) { a.X2 = (const float*)(rr + (i - 1) * S); a.x2_ld = LD; }
             a.rowtab = t_cc;
             if ((rc = launch_conv_gemm(c, a, "res2net"))) return rc;
         }
-        { ConvArgs a = conv_args(B.tdnn2, rr, C, t2, C, Mo, true, P); a.act1 = 1; a.rowtab = t_oc; a.in_rows = (int)Mc; if ((rc = launch_conv_gemm(c, a, "tdnn2"))) return rc; }
+        { ConvArgs a = conv_args(B.tdnn2, rr, LD, t2, LD, Mo, true, P); a.act1 = 1; a.rowtab = t_oc; a.in_rows = (int)Mc; if ((rc = launch_conv_gemm(c, a, "tdnn2"))) return rc; }
         {
             ProfScope ps(c, "se_mean", 0, (double)Mo * C * 4.0);
-            hipLaunchKernelGGL(k_masked_mean<T>, dim3((C + 255) / 256, (unsigned)items), dim3(256), 0, st, t2, C, d_nvalid, ro[os], rbase[os], se_s, C);
+            hipLaunchKernelGGL(k_masked_mean<T>, dim3((C + 255) / 256, (unsigned)items), dim3(256), 0, st, t2, LD, d_nvalid, ro[os], rbase[os], se_s, C);
             KCHECK(c);
         }
         { ConvArgs a = conv_args(B.se1, se_s, C, se_h, 128, items, false); a.act1 = 1; if ((rc = launch_conv_gemm(c, a, "se1"))) return rc; }
@@ -287,29 +290,29 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
             if (os != is) { TAB(m, os, is); res_map = m; }
             if (os != 1) { TAB(m, os, 1); out_map = m; }
             ProfScope ps(c, "se_apply", 0, (double)Mo * C * 12.0);
-            hipLaunchKernelGGL(k_se_apply<T>, GRID1(Mo * (C / 4)), 0, st, t2, se_g, xin, xin_ld, cat + (size_t)b * C, C3, C, Mo, t_oc, res_map, out_map);
+            hipLaunchKernelGGL(k_se_apply<T>, GRID1(Mo * (C / 4)), 0, st, t2, LD, se_g, xin, xin_ld, cat + (size_t)b * C, LD3, C, Mo, t_oc, res_map, out_map);
             KCHECK(c);
         }
     }
     // mfa: TDNNBlock(3C -> 3C, k1) over cat(x1,x2,x3)
     TAB(t31, 3, 1); TAB(t33, 3, 3);
-    { ConvArgs a = conv_args(E.mfa, cat, C3, mfa, C3, MN, true, P); a.act1 = 1; a.rowtab = t31; a.in_rows = (int)R[1]; if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
+    { ConvArgs a = conv_args(E.mfa, cat, LD3, mfa, LD3, MN, true, P); a.act1 = 1; a.rowtab = t31; a.in_rows = (int)R[1]; if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
     // ASP with global context: cat[x, mean, std] @ W == x @ Wx + (mean,std) @ Wms  (per-item bias)
     {
         ProfScope ps(c, "asp_stats", 0, (double)MN * C3 * 4.0);
-        hipLaunchKernelGGL(k_asp_stats<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, C3, d_nvalid, ro[3], rbase[3], ms, C3);
+        hipLaunchKernelGGL(k_asp_stats<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, LD3, d_nvalid, ro[3], rbase[3], ms, C3);
         KCHECK(c);
     }
     { ConvArgs a = conv_args(E.asp_tdnn_ms, ms, 2 * C3, ib, 128, items, false); if ((rc = launch_conv_gemm(c, a, "asp_ms"))) return rc; }
-    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, C3, hid, 128, MN, true, P); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; a.rowtab = t33; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
+    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, LD3, hid, 128, MN, true, P); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; a.rowtab = t33; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
     // attention logits stay f32 in either mode (they feed an exp: fp16's 3 decimal digits at |logit| ~ 30 would be percents of a weight).
     // f32 mode: cat is dead after mfa and large enough; fp16 mode: its own buffer
     float* logits;
-    if (P) { WS(c, float, lg, "ec_logits", MN * C3); logits = lg; } else logits = (float*)cat;
-    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, C3, MN, true, P); a.rowtab = t33; a.y_f32 = 1; if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
+    if (P) { WS(c, float, lg, "ec_logits", MN * LD3); logits = lg; } else logits = (float*)cat;
+    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, LD3, MN, true, P); a.rowtab = t33; a.y_f32 = 1; if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
     {
         ProfScope ps(c, "asp_pool", 0, (double)MN * C3 * 8.0);
-        hipLaunchKernelGGL(k_asp_pool<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, C3, d_nvalid, ro[3], rbase[3], pooled, C3);
+        hipLaunchKernelGGL(k_asp_pool<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, LD3, d_nvalid, ro[3], rbase[3], pooled, C3);
         KCHECK(c);
     }
     // asp_bn folded into fc
