@@ -227,7 +227,8 @@ def main():
     live_local = stats_live["flops"] / max(stats_live["launches"], 1)
     # dominant kernel: k_conv_gemm.  f32 mode: every launch is the f32-MFMA instantiation.  fp16 mode: the roofline is that of the fp16
     # instantiations (ECAPA per-frame layers: k_conv_gemm_h256 + k_conv_gemm<F16>); the f32 launches left (PyanNet) are listed beside it
-    cg = d.kernel_stats("conv_gemm_f16" if a.precision == "f16" else "conv_gemm")
+    cg_all = d.kernel_stats("conv_gemm_f16" if a.precision == "f16" else "conv_gemm")      # every MFMA convolution launch of the precision
+    cg = d.kernel_stats("conv_w256_f16" if a.precision == "f16" else "conv_w256_f32")       # the dominant kernel alone: k_conv_gemm_w256
     cg_f32 = d.kernel_stats("conv_gemm_f32")
     stages = d.stage_ms()
     extra = {}
@@ -272,7 +273,10 @@ def main():
                 pj = json.load(open(pmc_path))
                 cur = "+".join(git_blob_sha1(os.path.join(PKG, "csrc", f)) for f in ("conv_gemm.hip", "conv_gemm_h.hip", "conv_narrow.hip"))
                 if pj.get("conv_gemm_blob") == cur and pj.get("workload", "raw") == a.workload:
-                    traffic, traffic_src, mfma_util = pj["bytes_per_launch"], pj["source"], pj.get("mfma")
+                    pk = pj["per_kernel"]["k_conv_gemm_w256<false>"]
+                    traffic, traffic_src = pk["fetch_x2_bytes_per_launch"] + pk["write_bytes_per_launch"], pj["source"]
+                    mfma_util = {"k_conv_gemm_w256<false>": pj.get("mfma", {}).get("k_conv_gemm_w256<false>"), "all_kernels": pj.get("mfma"),
+                                 "traffic_all_mfma_conv_launches_bytes_per_launch": pj["bytes_per_launch"]}
                 else:
                     recorded = {"note": "PMC recording is of another kernel source or workload: not quoted", "recorded_blob": pj.get("conv_gemm_blob"),
                                 "current_blob": cur, "recorded_workload": pj.get("workload", "raw")}
@@ -308,11 +312,19 @@ def main():
                                           "pipelined rate of back-to-back jobs (rank 0 finalizes job k while the others infer job k+1)"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_conv_gemm (v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else
-                                   "k_conv_gemm_h256 + k_conv_gemm<F16> (v_mfma_f32_32x32x16_f16, fp16 activations; the ECAPA per-frame layers)",
+                         "kernel": "k_conv_gemm_w256<false> (v_mfma_f32_32x32x2_f32, 256 x 256 tile): every ECAPA layer with Cout >= 256" if a.precision == "f32" else
+                                   "k_conv_gemm_w256<true> (v_mfma_f32_32x32x16_f16, fp16 activations): the wide ECAPA layers",
+                         "all_mfma_conv_launches": {"what": "k_conv_gemm_w256 + k_conv_gemm (128 x 128 tile: Res2Net, ASP tdnn%s) %s" %
+                                                            ((", PyanNet) + k_conv_narrow (SincNet)", "of the step") if a.precision == "f32" else ("", "in fp16")),
+                                                    "achieved": round(cg_all["flops"] / max(cg_all["ms"], 1e-9) / 1e9, 2),
+                                                    "frac": round(cg_all["flops"] / max(cg_all["ms"], 1e-9) / 1e9 / peak, 4),
+                                                    "launches_per_step": cg_all["launches"] // max(a.steps, 1),
+                                                    "kernel_ms_per_step": round(cg_all["ms"] / max(a.steps, 1), 2),
+                                                    "algorithmic_gflop_per_step": round(cg_all["flops"] / max(a.steps, 1) / 1e9, 1)},
                          "f32_launches_beside": None if a.precision == "f32" else {"what": "PyanNet layers, f32 MFMA", "kernel_ms_per_step": round(cg_f32["ms"] / max(a.steps, 1), 2),
                                                                                    "TFLOPs": round(cg_f32["flops"] / max(cg_f32["ms"], 1e-9) / 1e9, 1)},
                          "launches_per_step": cg["launches"] // max(a.steps, 1),
+                         "avg_launch_ms": round(cg["ms"] / max(cg["launches"], 1), 4),
                          "kernel_ms_per_step": round(cg["ms"] / max(a.steps, 1), 2),
                          "algorithmic_gflop_per_step": round(cg["flops"] / max(a.steps, 1) / 1e9, 1),
                          "algorithmic_bytes_per_launch": round(cg["bytes"] / max(cg["launches"], 1)),
