@@ -272,14 +272,14 @@ def main():
             try:
                 pj = json.load(open(pmc_path))
                 cur = "+".join(git_blob_sha1(os.path.join(PKG, "csrc", f)) for f in ("conv_gemm.hip", "conv_gemm_h.hip", "conv_narrow.hip"))
-                if pj.get("conv_gemm_blob") == cur and pj.get("workload", "raw") == a.workload:
+                if pj.get("conv_gemm_blob") == cur and pj.get("workload", "raw") == a.workload and float(pj.get("hours_per_gpu", 1.0)) == float(a.hours_per_gpu):
                     pk = pj["per_kernel"]["k_conv_gemm_w256<false>"]
-                    traffic, traffic_src = pk["fetch_x2_bytes_per_launch"] + pk["write_bytes_per_launch"], pj["source"]
+                    traffic, traffic_src = pk["fetch_x2_bytes_per_launch"] + pk["write_bytes_per_launch"], pj["source"] + " -- this field: the k_conv_gemm_w256<false> launches alone"
                     mfma_util = {"k_conv_gemm_w256<false>": pj.get("mfma", {}).get("k_conv_gemm_w256<false>"), "all_kernels": pj.get("mfma"),
                                  "traffic_all_mfma_conv_launches_bytes_per_launch": pj["bytes_per_launch"]}
                 else:
-                    recorded = {"note": "PMC recording is of another kernel source or workload: not quoted", "recorded_blob": pj.get("conv_gemm_blob"),
-                                "current_blob": cur, "recorded_workload": pj.get("workload", "raw")}
+                    recorded = {"note": "PMC recording is of another kernel source, workload or size: not quoted", "recorded_blob": pj.get("conv_gemm_blob"),
+                                "current_blob": cur, "recorded_workload": pj.get("workload", "raw"), "recorded_hours_per_gpu": pj.get("hours_per_gpu", 1.0)}
             except Exception:
                 pass
         turns = turns_box[0] or []
@@ -315,7 +315,7 @@ def main():
                          "kernel": "k_conv_gemm_w256<false> (v_mfma_f32_32x32x2_f32, 256 x 256 tile): every ECAPA layer with Cout >= 256" if a.precision == "f32" else
                                    "k_conv_gemm_w256<true> (v_mfma_f32_32x32x16_f16, fp16 activations): the wide ECAPA layers",
                          "all_mfma_conv_launches": {"what": "k_conv_gemm_w256 + k_conv_gemm (128 x 128 tile: Res2Net, ASP tdnn%s) %s" %
-                                                            ((", PyanNet) + k_conv_narrow (SincNet)", "of the step") if a.precision == "f32" else ("", "in fp16")),
+                                                            ((", PyanNet) + k_conv_narrow (SincNet", "of the step") if a.precision == "f32" else ("", "in fp16")),
                                                     "achieved": round(cg_all["flops"] / max(cg_all["ms"], 1e-9) / 1e9, 2),
                                                     "frac": round(cg_all["flops"] / max(cg_all["ms"], 1e-9) / 1e9 / peak, 4),
                                                     "launches_per_step": cg_all["launches"] // max(a.steps, 1),

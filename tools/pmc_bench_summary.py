@@ -46,7 +46,7 @@ n = sum(fn.values())
 assert n == sum(wn.values()), (fn, wn)
 fb = sum(v['FETCH_SIZE'] for v in f.values()) * 1024
 wb = sum(v['WRITE_SIZE'] for v in w.values()) * 1024
-out = {"conv_gemm_blob": "+".join(blob(os.path.join(ROOT, "pyannote-audio_speaker-diarization_cpp_amd", "csrc", f)) for f in CONV_SOURCES), "workload": workload,
+out = {"conv_gemm_blob": "+".join(blob(os.path.join(ROOT, "pyannote-audio_speaker-diarization_cpp_amd", "csrc", f)) for f in CONV_SOURCES), "workload": workload, "hours_per_gpu": 1.0,
        "bytes_per_launch": round((2 * fb + wb) / n), "launches": n,
        "fetch_raw_bytes_per_launch": round(fb / n), "fetch_x2_bytes_per_launch": round(2 * fb / n), "write_bytes_per_launch": round(wb / n),
        "per_kernel": {k: {"launches": fn[k], "fetch_x2_bytes_per_launch": round(2 * f[k]['FETCH_SIZE'] * 1024 / fn[k]),
