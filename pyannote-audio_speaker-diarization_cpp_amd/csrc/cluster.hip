@@ -1032,6 +1032,11 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         void* args[] = {&D, &n_i, &size_all, &cid, &nb, &md, &d_Z, &gran, &sync, &cap, &G};
         // cooperative launch: all workgroups are resident together, or the launch is refused (they poll each other's slots)
         hipError_t le = hipErrorUnknown;
+        if ((size_t)cap * 24 > 48 * 1024) {          // the row lists of a hand-set geometry may pass the default dynamic-LDS limit
+            (void)hipFuncSetAttribute((const void*)k_linkage_mw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 24);
+            (void)hipFuncSetAttribute((const void*)k_linkage_mw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 24);
+            (void)hipGetLastError();
+        }
         if (onex) {
             le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<true>, dim3(8 * G), dim3(TH), args, (size_t)cap * 24, c->stream);
             if (le != hipSuccess) { (void)hipGetLastError(); onex = false; }
