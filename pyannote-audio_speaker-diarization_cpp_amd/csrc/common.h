@@ -90,6 +90,7 @@ struct SegWeights {
     bool loaded = false;
     float wn_w = 1, wn_b = 0;          // InstanceNorm1d(1) affine on the waveform
     ConvLayer conv0, conv1, conv2;     // sincnet convs (conv0: Cin = 256 padded taps, x_ld = 10)
+    float* conv0_wsum = nullptr;       // [80] sum of conv0's taps per filter (the shared-conv0 path folds the chunk normalisation into an affine map)
     float* in_w[3] = {nullptr, nullptr, nullptr};   // InstanceNorm affine per stage
     float* in_b[3] = {nullptr, nullptr, nullptr};
     ConvLayer lstm_ih[4];              // [1024][in] both directions stacked, bias = b_ih + b_hh
@@ -118,6 +119,8 @@ struct sd_ctx {
     bool conv_w256_f32 = true;                  // f32: the same 256 x 256 kernel for the wide, long-K ECAPA layers (TDNN, MFA)
     int conv_pn128 = 0;                         // 128 x 128 kernel: column tiles per super-block (0 = 8); tuning
     int ecapa_ld_pad = 0;                       // elements added to the leading dimensions of the ECAPA activation buffers (multiple of 8)
+    bool wav_padded = false;                    // the waveform buffer in use was allocated by the library with 512 zeroed floats behind the samples
+    bool seg_shared_conv0 = true;               // SincNet conv0 once over the waveform instead of once per (90 % overlapping) chunk
     int conv_w256_kmin = 0;                     // 256 x 256 kernel: shortest contraction Cin * KT it takes (0 = built-in: 1024 f32, 256 fp16); tuning
     int conv_pn = 0;                            // 256 x 256 kernel: column tiles per super-block (0 = 8); tuning
     bool conv_h256 = true;                      // fp16 mode: 256 x 256 tile kernel for the wide layers (conv_gemm_h.hip)

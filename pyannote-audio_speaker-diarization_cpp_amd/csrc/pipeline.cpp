@@ -21,6 +21,7 @@ __global__ void k_pcm_to_f32(const int16_t* __restrict__ pcm, float* __restrict_
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) wav[i] = (float)pcm[i] * (1.0f / 32768.0f);
+    else if (i < n + 512) wav[i] = 0.0f;          // padding: SincNet's 256-tap rows read 4 samples past the last window (zero weights, finite data)
 }
 // embeddings are widened to double before clustering (sd.cpp:2555)
 __global__ void k_f32_to_f64(const float* __restrict__ a, double* __restrict__ b, int64_t n)
@@ -56,6 +57,7 @@ extern "C" int sd_segment_dev(sd_ctx* c, const float* d_wav, int64_t n, float* d
     ENTER(c);
     if (!d_wav || !d_out || n <= 1) SD_FAIL(c, SD_ERR_ARG, "sd_segment_dev: bad argument");
     if (chunks != sd_num_chunks(n, nullptr)) SD_FAIL(c, SD_ERR_ARG, "sd_segment_dev: chunks must equal sd_num_chunks(n)");
+    c->wav_padded = false;                   // the caller's buffer: nothing is known about the bytes behind sample n
     int rc = run_segment(c, d_wav, n, 0, chunks, d_out);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -69,8 +71,10 @@ extern "C" int sd_segment(sd_ctx* c, const float* h_wav, int64_t n, float* h_out
     const int64_t nc = sd_num_chunks(n, nullptr);
     *chunks = nc;
     if (nc <= 0) SD_FAIL(c, SD_ERR_SHORT, "audio of %lld samples yields no chunk", (long long)n);
-    DTMP(c, dw, n * sizeof(float)); DTMP(c, ds, nc * SD_FRAMES * 3 * sizeof(float));
+    DTMP(c, dw, (n + 512) * sizeof(float)); DTMP(c, ds, nc * SD_FRAMES * 3 * sizeof(float));
     HIPCHK(c, hipMemcpy(dw.p, h_wav, n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset((float*)dw.p + n, 0, 512 * sizeof(float)));
+    c->wav_padded = true;
     int rc = run_segment(c, (const float*)dw.p, n, 0, nc, (float*)ds.p);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -191,8 +195,9 @@ extern "C" int sd_reconstruct(sd_ctx* c, const float* h_seg, const uint8_t* h_bi
 int pcm_to_wav(sd_ctx* c, const int16_t* d_pcm, int64_t n, float** d_wav)
 {
     WS(c, float, w, "wav_f32", n + 512);
-    hipLaunchKernelGGL(k_pcm_to_f32, GRID1(n), 0, c->stream, d_pcm, w, n);
+    hipLaunchKernelGGL(k_pcm_to_f32, GRID1(n + 512), 0, c->stream, d_pcm, w, n);
     KCHECK(c);
+    c->wav_padded = true;
     *d_wav = w;
     return SD_OK;
 }
@@ -355,6 +360,8 @@ extern "C" int sd_diarize_f32(sd_ctx* c, const float* h_wav, int64_t n, sd_turn*
     for (int i = 0; i < 4; ++i) c->stage_ms[i] = 0;
     WS(c, float, d_wav, "wav_f32", n + 512);
     HIPCHK(c, hipMemcpyAsync(d_wav, h_wav, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_wav + n, 0, 512 * sizeof(float), c->stream));
+    c->wav_padded = true;
     WS(c, float, d_seg, "dz_seg", chunks * SD_FRAMES * 3);
     WS(c, float, d_emb, "dz_emb", chunks * 3 * SD_EMB_DIM);
     int rc;

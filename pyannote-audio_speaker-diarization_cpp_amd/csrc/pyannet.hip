@@ -45,24 +45,58 @@ __global__ __launch_bounds__(256) void k_chunk_norm(const float* __restrict__ wa
     for (int j = tid; j < SD_CHUNK; j += 256) y[j] = (j < L) ? x[j] * a + c : 0.0f;
 }
 
+// ---------------------------------------------------------------- k_chunk_stats (shared-conv0 path)
+// The chunks overlap by 90 % and conv0 is linear, so it is applied ONCE to the raw waveform (row r = the 251-tap window at
+// sample 10 r; chunk ck's frame f is row 800 ck + f) and the chunk's InstanceNorm1d(1) becomes an affine map of that output:
+//   conv0((x - mean) * rstd * w + b)[f][ch] = a_ck * Y[800 ck + f][ch] + c_ck * sum_k W[ch][k],   a = rstd * w,  c = b - mean * rstd * w.
+// This kernel only produces (a, c) per chunk -- same statistics, same summation order as k_chunk_norm.
+__global__ __launch_bounds__(256) void k_chunk_stats(const float* __restrict__ wav, int64_t origin, int64_t first_chunk, int L,
+                                                     float w, float b, float2* __restrict__ st)
+{
+    __shared__ float red[256];
+    const int ck = blockIdx.x, tid = threadIdx.x;
+    const int64_t base = (first_chunk + ck) * (int64_t)SD_HOP - origin;
+    const float* x = wav + base;
+    float s = 0.0f;
+    for (int j = tid; j < L; j += 256) s += x[j];
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float mean = red[0] / (float)L;
+    __syncthreads();
+    float v = 0.0f;
+    for (int j = tid; j < L; j += 256) { const float d = x[j] - mean; v += d * d; }
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float rstd = rsqrtf(red[0] / (float)L + 1e-5f);
+    if (tid == 0) st[ck] = make_float2(rstd * w, b - mean * rstd * w);
+}
+
 // ---------------------------------------------------------------- k_pool_norm
 // in  [chunk][Lc][C]  ->  out [chunk][Lp][Cpad],  Lp = Lc/3
 // out = leaky_relu(instance_norm(maxpool3(abs?(in))))   per (chunk, channel) statistics
 #define PN_T 960          // threads per chunk: Q = PN_T / C row groups per channel keep 12-16 loads per channel in flight
-template <int C, int CPAD, bool ABS>
+// SHARED (stage 0 of the shared-conv0 path): `in` is the conv of the raw waveform, chunk ck starts at row ck * chunk_rows and
+// its values are a_ck * in + c_ck * wsum[channel] (k_chunk_stats)
+template <int C, int CPAD, bool ABS, bool SHARED>
 __global__ __launch_bounds__(PN_T) void k_pool_norm(const float* __restrict__ in, int Lc, int Lp, const float* __restrict__ gw,
-                                                   const float* __restrict__ gb, float* __restrict__ out)
+                                                   const float* __restrict__ gb, float* __restrict__ out,
+                                                   const float2* __restrict__ cst, const float* __restrict__ wsum, int chunk_rows)
 {
     constexpr int Q = PN_T / C;
     __shared__ float red[Q][C];
     __shared__ float sa[C], sb[C];
     const int ck = blockIdx.x, tid = threadIdx.x;
     const int c = tid % C, ql = tid / C;
-    const float* src = in + (size_t)ck * Lc * C;
+    const float* src = in + (SHARED ? (size_t)ck * chunk_rows * C : (size_t)ck * Lc * C);
     float* dst = out + (size_t)ck * Lp * CPAD;
+    float ca = 1.0f, cc = 0.0f;
+    if (SHARED) { const float2 e = cst[ck]; ca = e.x; cc = e.y * wsum[c]; }
     float s = 0.0f;
     for (int q = ql; q < Lp; q += Q) {
         float v0 = src[(size_t)(3 * q) * C + c], v1 = src[(size_t)(3 * q + 1) * C + c], v2 = src[(size_t)(3 * q + 2) * C + c];
+        if (SHARED) { v0 = v0 * ca + cc; v1 = v1 * ca + cc; v2 = v2 * ca + cc; }
         if (ABS) { v0 = fabsf(v0); v1 = fabsf(v1); v2 = fabsf(v2); }
         const float m = fmaxf(v0, fmaxf(v1, v2));
         dst[(size_t)q * CPAD + c] = m;
@@ -246,8 +280,6 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
     }
     const int F = P2 > SD_FRAMES ? SD_FRAMES : P2;
     const int64_t CB = cnt;
-    WS(c, float, xn, "sg_xn", CB * SD_CHUNK + 512);
-    WS(c, float, c0, "sg_c0", CB * L0 * 80);
     WS(c, float, p0, "sg_p0", CB * P0 * 96);
     WS(c, float, c1, "sg_c1", CB * L1 * 60);
     WS(c, float, p1, "sg_p1", CB * P1 * 64);
@@ -259,18 +291,40 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
     WS(c, float, y0, "sg_y0", CB * F * 128);
     WS(c, float, y1, "sg_y1", CB * F * 128);
     int rc;
-    hipLaunchKernelGGL(k_chunk_norm, dim3((unsigned)CB), dim3(256), 0, st, d_wav, c->wav_origin, first_chunk, L, S.wn_w, S.wn_b, xn);
-    KCHECK(c);
-    {   // conv0: rows = output positions, row r reads xn[10 r .. 10 r + 256)
+    if (c->seg_shared_conv0 && c->wav_padded && S.conv0.Cout == 80 && S.conv0_wsum) {
+        // conv0 once over the batch's stretch of the waveform: rows 0 .. 800 (CB - 1) + L0 (chunk ck's frames start at row 800 ck;
+        // the last window ends 4 samples behind the last chunk, inside the waveform's padding), then the chunk's normalisation as an
+        // affine map inside the pooling kernel.  10x fewer FLOPs and 10x less output than one conv per chunk.
+        const int hop_rows = SD_HOP / 10;
+        const int64_t MY = (int64_t)hop_rows * (CB - 1) + L0;
+        WS(c, float2, cst, "sg_cst", CB);
+        WS(c, float, c0s, "sg_c0s", MY * 80);
+        hipLaunchKernelGGL(k_chunk_stats, dim3((unsigned)CB), dim3(256), 0, st, d_wav, c->wav_origin, first_chunk, L, S.wn_w, S.wn_b, cst);
+        KCHECK(c);
         ConvArgs a; memset(&a, 0, sizeof(a));
-        a.X = xn; a.x_ld = 10; a.W = S.conv0.W; a.Y = c0; a.y_ld = 80;
-        a.M = (int)(CB * L0); a.TpIn = SD_CHUNK / 10; a.TpOut = L0; a.Tin = SD_CHUNK / 10; a.T = L0;
+        a.X = d_wav + (first_chunk * (int64_t)SD_HOP - c->wav_origin); a.x_ld = 10; a.W = S.conv0.W; a.Y = c0s; a.y_ld = 80;
+        a.M = (int)MY; a.TpIn = a.TpOut = a.Tin = a.T = (int)MY;
         a.Cin = 256; a.cin_real = 251; a.Cout = 80; a.KT = 1; a.dil = 1; a.pad_mode = 1;
         if ((rc = launch_conv_narrow(c, a, "sinc0")) == 1) rc = launch_conv_gemm(c, a, "sinc0");
         if (rc) return rc;
+        hipLaunchKernelGGL((k_pool_norm<80, 96, true, true>), dim3((unsigned)CB), dim3(PN_T), 0, st, c0s, L0, P0, S.in_w[0], S.in_b[0], p0, cst, S.conv0_wsum, hop_rows);
+        KCHECK(c);
+    } else {
+        WS(c, float, xn, "sg_xn", CB * SD_CHUNK + 512);
+        WS(c, float, c0, "sg_c0", CB * L0 * 80);
+        hipLaunchKernelGGL(k_chunk_norm, dim3((unsigned)CB), dim3(256), 0, st, d_wav, c->wav_origin, first_chunk, L, S.wn_w, S.wn_b, xn);
+        KCHECK(c);
+        {   // conv0: rows = output positions, row r reads xn[10 r .. 10 r + 256)
+            ConvArgs a; memset(&a, 0, sizeof(a));
+            a.X = xn; a.x_ld = 10; a.W = S.conv0.W; a.Y = c0; a.y_ld = 80;
+            a.M = (int)(CB * L0); a.TpIn = SD_CHUNK / 10; a.TpOut = L0; a.Tin = SD_CHUNK / 10; a.T = L0;
+            a.Cin = 256; a.cin_real = 251; a.Cout = 80; a.KT = 1; a.dil = 1; a.pad_mode = 1;
+            if ((rc = launch_conv_narrow(c, a, "sinc0")) == 1) rc = launch_conv_gemm(c, a, "sinc0");
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL((k_pool_norm<80, 96, true, false>), dim3((unsigned)CB), dim3(PN_T), 0, st, c0, L0, P0, S.in_w[0], S.in_b[0], p0, nullptr, nullptr, 0);
+        KCHECK(c);
     }
-    hipLaunchKernelGGL((k_pool_norm<80, 96, true>), dim3((unsigned)CB), dim3(PN_T), 0, st, c0, L0, P0, S.in_w[0], S.in_b[0], p0);
-    KCHECK(c);
     {
         ConvArgs a; memset(&a, 0, sizeof(a));
         a.X = p0; a.x_ld = 96; a.W = S.conv1.W; a.bias = S.conv1.bias; a.Y = c1; a.y_ld = 60;
@@ -279,7 +333,7 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
         if ((rc = launch_conv_narrow(c, a, "sinc1")) == 1) rc = launch_conv_gemm(c, a, "sinc1");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((k_pool_norm<60, 64, false>), dim3((unsigned)CB), dim3(PN_T), 0, st, c1, L1, P1, S.in_w[1], S.in_b[1], p1);
+    hipLaunchKernelGGL((k_pool_norm<60, 64, false, false>), dim3((unsigned)CB), dim3(PN_T), 0, st, c1, L1, P1, S.in_w[1], S.in_b[1], p1, nullptr, nullptr, 0);
     KCHECK(c);
     {
         ConvArgs a; memset(&a, 0, sizeof(a));
@@ -289,7 +343,7 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
         if ((rc = launch_conv_narrow(c, a, "sinc2")) == 1) rc = launch_conv_gemm(c, a, "sinc2");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((k_pool_norm<60, 64, false>), dim3((unsigned)CB), dim3(PN_T), 0, st, c2, L2, P2, S.in_w[2], S.in_b[2], p2);
+    hipLaunchKernelGGL((k_pool_norm<60, 64, false, false>), dim3((unsigned)CB), dim3(PN_T), 0, st, c2, L2, P2, S.in_w[2], S.in_b[2], p2, nullptr, nullptr, 0);
     KCHECK(c);
     // if P2 > 293 (cannot happen for L <= 80000) only the first F frames would be used
     const float* lin = p2; int lin_ld = 64; int lin_rows_per_chunk = P2;

@@ -210,6 +210,10 @@ int build_seg_weights(sd_ctx* c, const Pack& p)
         for (int o = 0; o < Cout; ++o) for (int k = 0; k < K; ++k) hw[(size_t)o * 256 + k] = w->data[(size_t)o * K + k];
         S.conv0.W = upload(c, hw);
         if (!S.conv0.W) return SD_ERR_HIP;
+        std::vector<float> ws((size_t)Cout);
+        for (int o = 0; o < Cout; ++o) { double a = 0.0; for (int k = 0; k < K; ++k) a += (double)w->data[(size_t)o * K + k]; ws[(size_t)o] = (float)a; }
+        S.conv0_wsum = upload(c, ws);
+        if (!S.conv0_wsum) return SD_ERR_HIP;
         S.conv0.Cin = K; S.conv0.CinPad = 256; S.conv0.Cout = Cout; S.conv0.KT = 1; S.conv0.dil = 1;
     }
     int rc;

@@ -43,6 +43,29 @@ def test_segmentation_parity(diarizer, weights, n):
         np.testing.assert_allclose(seg[i], ref, rtol=RTOL, atol=ATOL)
 
 
+def test_segmentation_shared_conv0_equals_per_chunk_conv0(diarizer, weights):
+    """SincNet conv0 applied once to the raw waveform + the chunk normalisation as an affine map (pyannet.hip, k_chunk_stats)
+    against one conv per normalised chunk: same scores to rounding, also with a DC offset, a loud and a nearly silent stretch
+    and a short last chunk; both within the oracle tolerance."""
+    n = 80000 + 8000 * 4 + 5000
+    rng = np.random.default_rng(77)
+    wav = (0.05 * rng.standard_normal(n)).astype(np.float32)
+    wav[:40000] = wav[:40000] * 8 + 0.3                 # loud, with a DC offset
+    wav[60000:90000] *= 1e-3                            # nearly silent
+    diarizer.set_option("seg_shared_conv0", 0)
+    per_chunk = diarizer.segment(wav)
+    diarizer.set_option("seg_shared_conv0", 1)
+    shared = diarizer.segment(wav)
+    assert np.abs(shared - per_chunk).max() <= 2e-5
+    nc, last = orc.num_chunks(n)
+    net = nn.PyanNetOracle(weights[2])
+    for i in range(nc):
+        y = net(wav[None, i * 8000:i * 8000 + 80000]).numpy()[0]
+        ref = np.zeros((293, 3), np.float32)
+        ref[:y.shape[0]] = y
+        np.testing.assert_allclose(shared[i], ref, rtol=RTOL, atol=ATOL)
+
+
 def test_segmentation_too_short_for_one_frame_is_zero(diarizer):
     # a (single) chunk too short for one output frame: frames are zero padded like sd.cpp:1473-1479
     wav = np.random.default_rng(0).standard_normal(200).astype(np.float32) * 0.1
