@@ -527,7 +527,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     __shared__ MinIdx sh[MWT_MAX / 64];
     __shared__ Cand shc[MWT_MAX / 64];
     __shared__ MinIdx s_part[KR][MWT_MAX / 64];
-    __shared__ unsigned s_words[MWT][SLOT_WORDS];      // this round's slots of all workgroups, as received
+    __shared__ unsigned s_words[MWT][SLOT_WORDS + 1];  // this round's slots of all workgroups, as received (+1: lane u reads word w of slot u -- a 128-byte row stride would put all lanes on two banks)
     __shared__ Cand s_cand[MWT + 1];        // published local bests of the G <= 256 workgroups (+ row y)
     __shared__ MinIdx s_row[KR];
     __shared__ int s_L[2][KR];
@@ -1010,7 +1010,7 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     if (G < 0) G = N >= 60000 ? 128 : N >= 8000 ? 64 : N >= 1500 ? 32 : 0;
     if (G > c->num_cu) G = c->num_cu;
     int TH = (int)c->linkage_threads;
-    if (TH <= 0) TH = auto_onex ? 256 : N >= 8000 ? 512 : 256;           // measured: 188 vs 195 ms at N = 12 602, 327 vs 337 ms at N = 21 573, 4.68 vs 4.85 s at N = 172 773
+    if (TH <= 0) TH = (N >= 8000 || auto_onex) ? 512 : 256;           // measured: 188 vs 195 ms at N = 12 602, 327 vs 337 ms at N = 21 573, 4.68 vs 4.85 s at N = 172 773
     TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : 256;
     if (G <= 1) return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
     if ((N + G - 1) / G > 4000) G = (int)((N + 3999) / 4000);      // active-row lists and bounds live in LDS: 24 B per owned row
