@@ -199,7 +199,8 @@ void sd_reset_stats(sd_ctx*);
  * clustering/Clustering.py:81-94: the local speakers of a chunk go to different clusters; applies to sd_clustering* and the whole path).
  * Kernel-tuning keys (defaults are the measured optimum; results do not depend on them): "conv_h256" / "conv_w256_f32" (256 x 256 tile for the
  * wide ECAPA layers in fp16 / f32), "conv_w256_kmin" (shortest contraction that tile takes), "conv_pn" / "conv_pn128" (column tiles per
- * super-block), "ecapa_ld_pad" (elements added to the activation rows, multiple of 8). An unknown key returns SD_ERR_ARG. */
+ * super-block), "ecapa_ld_pad" (elements added to the activation rows, multiple of 8), "seg_shared_conv0" (1 = SincNet's first convolution once over the
+ * waveform instead of once per overlapping chunk; scores equal within 2e-5). An unknown key returns SD_ERR_ARG. */
 int sd_set_option(sd_ctx*, const char* key, int64_t value);
 /* tuning hook (tools/tune_conv.py): time one conv_gemm shape on scratch data; dbg selects an ablation */
 int sd_bench_barrier(sd_ctx*, int workgroups, int iters, int dirty_doubles, double* us_per_barrier);
