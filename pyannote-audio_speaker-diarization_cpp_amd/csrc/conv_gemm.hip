@@ -432,6 +432,31 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                 }
             };
             using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+            // f32 fast path (Res2Net, LSTM projections, linear layers): full column tiles, every row live, no per-item bias, no second
+            // activation -- each accumulator register is one output row for 32 consecutive columns across a half-wave and is stored as it
+            // lies (128 B per row and instruction, row term in the scalar offset, rows >= M dropped by the descriptor range): no lane
+            // transposes, no per-row index arithmetic (conv_gemm_h.hip's epilogue).  Same values as the general path.
+            if (!F16 && DBG == 0 && wide && !a.item_bias && a.act2 == 0 && (a.Cout % BN) == 0 && (RT || a.T >= a.TpOut)) {
+                const int rows_left = a.M - m0c;
+                const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (size_t)m0c * a.y_ld), 0,
+                                                      (unsigned)((size_t)(rows_left < BM ? rows_left : BM) * a.y_ld * 4), 0x00020000);
+                const unsigned ybytes = (unsigned)a.y_ld * 4u;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const unsigned vo = (unsigned)(wr * 64 + i * 32 + 4 * lh) * ybytes + (unsigned)cco[j] * 4u;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[i][j][r] + cb_[j];
+                            acc[i][j][r] = 0.0f;
+                            v = fmaxf(v, v * slope);
+                            v = v * cs_[j] + ch_[j];
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rY, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * ybytes, 0);
+                        }
+                    }
+                }
+            } else
             if (a.item_bias) { if (a.act2 == 1) tile_out(std::true_type{}, T1{}); else if (a.act2 == 2) tile_out(std::true_type{}, T2{}); else tile_out(std::true_type{}, T0{}); }
             else { if (a.act2 == 1) tile_out(std::false_type{}, T1{}); else if (a.act2 == 2) tile_out(std::false_type{}, T2{}); else tile_out(std::false_type{}, T0{}); }
             q = next_sb(q);
