@@ -432,27 +432,31 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                 }
             };
             using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
-            // f32 fast path (Res2Net, LSTM projections, linear layers): full column tiles, every row live, no per-item bias, no second
+            // fast path (Res2Net, LSTM projections, linear layers): full column tiles, every row live, no per-item bias, no second
             // activation -- each accumulator register is one output row for 32 consecutive columns across a half-wave and is stored as it
             // lies (128 B per row and instruction, row term in the scalar offset, rows >= M dropped by the descriptor range): no lane
             // transposes, no per-row index arithmetic (conv_gemm_h.hip's epilogue).  Same values as the general path.
-            if (!F16 && DBG == 0 && wide && !a.item_bias && a.act2 == 0 && (a.Cout % BN) == 0 && (RT || a.T >= a.TpOut)) {
+            if (DBG == 0 && wide && !a.item_bias && a.act2 == 0 && (a.Cout % BN) == 0 && (RT || a.T >= a.TpOut)) {
+                const bool h16 = F16 && !a.y_f32;                    // fp16 mode: 2-byte elements (64 B per row and instruction)
+                const unsigned es = h16 ? 2u : 4u;
                 const int rows_left = a.M - m0c;
-                const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (size_t)m0c * a.y_ld), 0,
-                                                      (unsigned)((size_t)(rows_left < BM ? rows_left : BM) * a.y_ld * 4), 0x00020000);
-                const unsigned ybytes = (unsigned)a.y_ld * 4u;
+                const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.Y + (size_t)m0c * a.y_ld * es), 0,
+                                                      (unsigned)((size_t)(rows_left < BM ? rows_left : BM) * a.y_ld * es), 0x00020000);
+                const unsigned ybytes = (unsigned)a.y_ld * es;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const unsigned vo = (unsigned)(wr * 64 + i * 32 + 4 * lh) * ybytes + (unsigned)cco[j] * 4u;
+                        const unsigned vo = (unsigned)(wr * 64 + i * 32 + 4 * lh) * ybytes + (unsigned)cco[j] * es;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             float v = acc[i][j][r] + cb_[j];
                             acc[i][j][r] = 0.0f;
                             v = fmaxf(v, v * slope);
                             v = v * cs_[j] + ch_[j];
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rY, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * ybytes, 0);
+                            const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * ybytes;
+                            if (h16) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), rY, vo, so, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rY, vo, so, 0);
                         }
                     }
                 }
