@@ -371,12 +371,44 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
         const int64_t rows_all = rowoff[(size_t)n_active];
         WS(c, float, feats, "emb_feats", rows_all * SD_FEAT_LD);
         if ((rc = frontend_features(c, d_wav, n, first_item, n_active, true, nnorm, d_rowoff, feats))) return rc;
-        // batches by row budget: as many whole items as fit the activation workspaces of nb full-length items
+        // batches by row budget: whole items, at most what fits the activation workspaces of nb full-length items.  Within that the
+        // boundary is placed where the wide-tile launches of the batch waste the least: a launch over M rows runs
+        // ceil(ceil(M / 256) / 64) rounds of 64 row panels (8 XCDs x 8 panels per super-block) per group of column tiles, and the
+        // last round is only as full as M happens to leave it; the four row spaces have different M, so the best compromise is
+        // searched over the last few dozen items (results do not depend on the batching: every row's bits are placement-free).
         const int64_t cap_rows = nb * SD_TP;
-        for (int64_t a0 = 0; a0 < n_active;) {
-            int64_t a1 = a0;
-            while (a1 < n_active && a1 - a0 < ROWTAB_MAX_ITEMS && rowoff[(size_t)a1 + 1] - rowoff[(size_t)a0] <= cap_rows) ++a1;
-            if (a1 == a0) a1 = a0 + 1;
+        auto batch_efficiency = [&](int64_t a0, int64_t a1) -> double {
+            // (space, K, groups of 4 column tiles) of the 256 x 256 launches: block0, tdnn1 / tdnn2 of the three blocks, MFA, ASP conv
+            static const int L[9][3] = {{0, 400, 1}, {0, 1024, 1}, {1, 1024, 1}, {1, 1024, 1}, {2, 1024, 1}, {2, 1024, 1}, {3, 1024, 1}, {3, 3072, 3}, {3, 128, 2}};
+            double ideal = 0.0, actual = 0.0;
+            for (int l = 0; l < 9; ++l) {
+                const int64_t M = plan.off[L[l][0]][(size_t)a1] - plan.off[L[l][0]][(size_t)a0];
+                const int64_t tiles = (M + 255) / 256;
+                const double w = (double)L[l][1] * L[l][2];
+                ideal += w * (double)tiles / 64.0;
+                actual += w * (double)((tiles + 63) / 64);
+            }
+            return actual > 0.0 ? ideal / actual : 0.0;
+        };
+        const int64_t n_batches = (rows_all + cap_rows - 1) / cap_rows;
+        for (int64_t a0 = 0, k = 1; a0 < n_active; ++k) {
+            int64_t a_max = a0;                                   // the most the workspaces take
+            while (a_max < n_active && a_max - a0 < ROWTAB_MAX_ITEMS && rowoff[(size_t)a_max + 1] - rowoff[(size_t)a0] <= cap_rows) ++a_max;
+            if (a_max == a0) a_max = a0 + 1;
+            int64_t a1 = a_max;
+            if (a_max < n_active && c->skip_dead_rows) {
+                // aim at equal shares of what is left, then look for the best boundary among the 96 items in front of the aim
+                const int64_t left_batches = n_batches - k + 1 > 1 ? n_batches - k + 1 : 1;
+                const int64_t aim_rows = rowoff[(size_t)a0] + (rows_all - rowoff[(size_t)a0] + left_batches - 1) / left_batches;
+                int64_t aim = a0 + 1;
+                while (aim < a_max && rowoff[(size_t)aim + 1] <= aim_rows) ++aim;
+                if (aim + 48 < a_max) aim += 48; else aim = a_max;
+                double best = -1.0;
+                for (int64_t cand = aim; cand > a0 && cand + 96 > aim; --cand) {
+                    const double e = batch_efficiency(a0, cand);
+                    if (e > best) { best = e; a1 = cand; }
+                }
+            }
             if ((rc = run_ecapa(c, feats, nvalid, plan, a0, a1, emb_c))) return rc;
             a0 = a1;
         }
