@@ -378,15 +378,15 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
         // searched over the last few dozen items (results do not depend on the batching: every row's bits are placement-free).
         const int64_t cap_rows = nb * SD_TP;
         auto batch_efficiency = [&](int64_t a0, int64_t a1) -> double {
-            // (space, K, groups of 4 column tiles) of the 256 x 256 launches: block0, tdnn1 / tdnn2 of the three blocks, MFA, ASP conv
-            static const int L[9][3] = {{0, 400, 1}, {0, 1024, 1}, {1, 1024, 1}, {1, 1024, 1}, {2, 1024, 1}, {2, 1024, 1}, {3, 1024, 1}, {3, 3072, 3}, {3, 128, 2}};
+            // {row space, weight = K x groups of 4 column tiles} of the 256 x 256 launches: block0, tdnn1 / tdnn2 of the three blocks, MFA,
+            // ASP conv; 16 384 rows (64 panels) per round.  (Adding the 128 x 128 launches -- 65 536 rows per round -- to the model measured
+            // the same: their period is longer than the window searched.)
+            static const int L[9][2] = {{0, 400}, {0, 1024}, {1, 1024}, {1, 1024}, {2, 1024}, {2, 1024}, {3, 1024}, {3, 3 * 3072}, {3, 2 * 128}};
             double ideal = 0.0, actual = 0.0;
             for (int l = 0; l < 9; ++l) {
                 const int64_t M = plan.off[L[l][0]][(size_t)a1] - plan.off[L[l][0]][(size_t)a0];
-                const int64_t tiles = (M + 255) / 256;
-                const double w = (double)L[l][1] * L[l][2];
-                ideal += w * (double)tiles / 64.0;
-                actual += w * (double)((tiles + 63) / 64);
+                ideal += (double)L[l][1] * (double)M / 16384.0;
+                actual += (double)L[l][1] * (double)((M + 16383) / 16384);
             }
             return actual > 0.0 ? ideal / actual : 0.0;
         };
@@ -397,14 +397,14 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
             if (a_max == a0) a_max = a0 + 1;
             int64_t a1 = a_max;
             if (a_max < n_active && c->skip_dead_rows) {
-                // aim at equal shares of what is left, then look for the best boundary among the 96 items in front of the aim
+                // aim at equal shares of what is left, then look for the best boundary among 160 items around the aim
                 const int64_t left_batches = n_batches - k + 1 > 1 ? n_batches - k + 1 : 1;
                 const int64_t aim_rows = rowoff[(size_t)a0] + (rows_all - rowoff[(size_t)a0] + left_batches - 1) / left_batches;
                 int64_t aim = a0 + 1;
                 while (aim < a_max && rowoff[(size_t)aim + 1] <= aim_rows) ++aim;
-                if (aim + 48 < a_max) aim += 48; else aim = a_max;
+                if (aim + 80 < a_max) aim += 80; else aim = a_max;
                 double best = -1.0;
-                for (int64_t cand = aim; cand > a0 && cand + 96 > aim; --cand) {
+                for (int64_t cand = aim; cand > a0 && cand + 160 > aim; --cand) {
                     const double e = batch_efficiency(a0, cand);
                     if (e > best) { best = e; a1 = cand; }
                 }
