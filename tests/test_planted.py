@@ -169,6 +169,16 @@ def test_whole_path_with_planted_scores_and_real_embeddings(diarizer, weights):
     sub_masks = masks[3 * c0:3 * c0 + 96]
     e_gpu = diarizer.embed(sub_wav, sub_masks)
     assert np.array_equal(e_gpu, emb[3 * c0:3 * c0 + 96], equal_nan=True)   # batch placement does not change a row's bits
+    # ... nor does the batch size: with room for 96 full-length items per batch the same 960 items go through ~5 batches whose
+    # boundaries are placed by the wide-tile search of run_embed (ecapa.hip)
+    big_masks = masks[3 * c0:3 * c0 + 960]
+    big_wav = wav[c0 * 8000:(c0 + 319) * 8000 + 80000]
+    diarizer.set_option("emb_batch_items", 96)
+    try:
+        e_small_batches = diarizer.embed(big_wav, big_masks)
+    finally:
+        diarizer.set_option("emb_batch_items", 768)
+    assert np.array_equal(e_small_batches, emb[3 * c0:3 * c0 + 960], equal_nan=True)
     sigs = np.zeros((96, 80000), np.float32)
     cnts = np.zeros(96, np.int64)
     for i in range(96):
