@@ -89,6 +89,80 @@ def rank0_share_estimate(world, hours_per_gpu):
     return max(0.0, min(1.0 / world, s0 / t_inf))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` (no torchrun): start N ranks as child processes of this one, which never touches the GPU.
+    stdout of rank 0 is relayed (the JSON line); every rank's stderr goes to this process's stderr with a rank prefix.  The first
+    rank that exits non-zero ends the job: the others are terminated by their exact pids.  Returns the exit code."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    lines0 = []
+
+    def pump(r, stream, is_out):
+        for line in stream:
+            if is_out and r == 0:
+                lines0.append(line)
+            else:
+                sys.stderr.write("[rank %d] %s" % (r, line))
+                sys.stderr.flush()
+
+    threads = [threading.Thread(target=pump, args=(r, p.stdout, True), daemon=True) for r, p in enumerate(procs)]
+    threads += [threading.Thread(target=pump, args=(r, p.stderr, False), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    failed = None
+    live = set(range(n))
+    while live and failed is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        t_end = time.time() + 5.0                      # the others usually fail by themselves (their reasons are worth reading)
+        while time.time() < t_end and any(procs[r].poll() is None for r in live):
+            time.sleep(0.05)
+        for r in live:
+            if procs[r].poll() is None:
+                procs[r].kill()
+        for p in procs:
+            p.wait()
+    for t in threads:
+        t.join(timeout=5.0)
+    if failed is not None:
+        codes = [p.returncode for p in procs]
+        sys.stderr.write("bench.py --gpus %d: rank %d exited with code %s (all ranks: %s); no result line\n" % (n, failed[0], failed[1], codes))
+        return 1
+    out = [l for l in lines0 if l.strip().startswith("{")]
+    if len(out) != 1:
+        sys.stderr.write("bench.py --gpus %d: rank 0 printed %d result lines\n" % (n, len(out)))
+        return 1
+    try:
+        got = json.loads(out[0]).get("n_gpus")
+    except Exception:
+        got = None
+    if got != n:
+        sys.stderr.write("bench.py --gpus %d: the result line says n_gpus = %r; refused\n" % (n, got))
+        return 1
+    sys.stdout.write(out[0])
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,13 +183,25 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (sd_set_option), e.g. emb_batch_items=1536; tuning only")
     a = ap.parse_args()
 
+    # ---- N > 1 without a launcher: this process becomes the launcher.  It starts N fresh children (one rank per GPU) with
+    # RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, BEFORE anything here touches the GPU (no torch.cuda call above this line), relays
+    # rank 0's JSON line and exits non-zero if any rank does.  Nothing re-execs: the children are new processes.
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+    if world != a.gpus:
+        # a line whose n_gpus is not what was asked for would be mistaken for the N-GPU number
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to measure a different job than the one asked for" % (a.gpus, world))
+    ndev = torch.cuda.device_count()                 # (counting devices does not initialise the GPU)
+    if ndev <= 0:
+        raise SystemExit("bench.py rank %d: needs a GPU: libsdhip has no CPU fallback" % rank)
+    if local >= ndev:
+        raise SystemExit("bench.py rank %d: LOCAL_RANK %d but this node has %d GPU%s" % (rank, local, ndev, "" if ndev == 1 else "s"))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: libsdhip has no CPU fallback")
+        raise SystemExit("bench.py rank %d: needs a GPU: libsdhip has no CPU fallback" % rank)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or a.force_dist
@@ -287,7 +373,7 @@ def main():
             "metric": "real-time factor (audio-sec/wall-sec), %g h 16 kHz mono per GPU" % a.hours_per_gpu,
             "value": round(audio_s / (ms_per_step / 1e3), 2),
             "unit": "x real-time",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": world, "rccl_ranks": d.comm_info()[1], "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",

@@ -29,7 +29,8 @@ enum {
     SD_ERR_HIP = 2,      /* HIP runtime failure / no GPU                          */
     SD_ERR_MODEL = 3,    /* weight file missing or malformed (reference: Ort::Exception) */
     SD_ERR_SHORT = 4,    /* audio too short for one segmentation frame (reference: UB, sd.cpp:2997) */
-    SD_ERR_NUMERIC = 5   /* zero-norm centroid (reference throws, sd.cpp:493-495) */
+    SD_ERR_NUMERIC = 5,  /* zero-norm centroid (reference throws, sd.cpp:493-495) */
+    SD_ERR_COMM = 6      /* multi-GPU exchange failed or timed out; the communicator has been aborted */
 };
 
 /* fixed geometry of the reference */
@@ -143,21 +144,15 @@ int sd_comm_info(const sd_ctx*, int* rank, int* world /* 0 = no communicator */)
  * [lo*8000, min(n_total, (hi-1)*8000 + 80000)). */
 int sd_shard_plan(int64_t n_total, int world, int rank0_permille, int64_t* ranges /*[world][2]*/, int64_t* slot_chunks);
 /* collective: every rank passes the samples of its range (h_/d_pcm_shard[0] is sample first_sample of the recording).
- * Rank 0 receives the turns; the other ranks return *n_turns = 0 as soon as their all-gather is queued. */
+ * Rank 0 receives the turns; the other ranks return *n_turns = 0 once the exchange has completed (rank 0's clustering of this
+ * job then overlaps their inference of the next one).  Failure is collective: a rank that fails in its part still joins the
+ * exchange with a status record, and EVERY rank returns an error for that job; a rank that never arrives (crash) makes the
+ * others return SD_ERR_COMM after "comm_timeout_ms" with the communicator aborted.  After any non-OK return the job group must be
+ * torn down (sd_comm_destroy / exit) -- the ranks' job counters no longer agree. */
 int sd_diarize_sharded(sd_ctx*, const int16_t* h_pcm_shard, int64_t first_sample, int64_t shard_samples, int64_t n_total,
                        sd_turn** turns, int64_t* n_turns);
 int sd_diarize_sharded_dev(sd_ctx*, const int16_t* d_pcm_shard, int64_t first_sample, int64_t shard_samples, int64_t n_total,
                            sd_turn** turns, int64_t* n_turns);
-
-/* ---- planted workload (measurement / test hook, SURVEY 8d: "with synthetic weights force a deterministic activity
- * pattern for stage >= a4 (override sigmoid outputs from the schedule) so N is controlled").  With seeded random
- * weights PyanNet and ECAPA do not follow the talkers, so every stage after them would only ever see one degenerate
- * case (K = 1, one turn).  After this call sd_diarize* / sd_shard_infer_dev still run both networks at full cost, then
- * replace the segmentation scores of chunks [chunk_lo, chunk_lo + chunks) by d_scores [chunks][293][3] before
- * post-segmentation, and the embedding rows of those chunks that are not NaN by the reference's own rule
- * (sd.cpp:2479-2549) by d_emb [chunks*3][192] before the all-gather / clustering.  Either pointer may be NULL; the
- * buffers stay owned by the caller and must outlive the calls; chunks = 0 removes the hook.  Never set by the CLI. */
-int sd_set_planted(sd_ctx*, const float* d_scores, const float* d_emb, int64_t chunk_lo, int64_t chunks);
 
 /* ---- a1: wav::WavReader::Open (wav.h:62-126).  Returns malloc'd pcm (free with
  * sd_free_pcm); only 16-bit PCM is accepted (README.md:37), channels are read
@@ -185,26 +180,17 @@ int sd_last_confidence(const sd_ctx*, double* conf, int64_t cap, int64_t* n);
 /* ---- a18: the reference's output line (sd.cpp:3439) */
 int sd_format_turn(const sd_turn* t, char* buf, int cap);
 
-/* ---- measurement hooks (bench.py): per-stage wall ms of the last sd_diarize*
- * [0]=segmentation [1]=embedding [2]=clustering [3]=total (labels of sd.cpp:3028,
- * 3110, 3231, 3434); GPU time of named kernels measured with hipEvents on the
- * library's own stream. */
+/* ---- the reference's four stage timers (sd.cpp:53-60; labels of sd.cpp:3028, 3110, 3231, 3434): wall ms of the last
+ * sd_diarize* call, [0]=segmentation [1]=embedding [2]=clustering [3]=total */
 int sd_stage_ms(const sd_ctx*, double* ms4);
-int sd_kernel_stats(const sd_ctx*, const char* kernel, double* total_ms, int64_t* launches, double* flops, double* bytes);
-void sd_reset_stats(sd_ctx*);
-/* keys: "emb_batch_items", "seg_batch_chunks", "profile", "linkage_wgs" (-1 auto, 0 one workgroup), "linkage_threads", "linkage_one_xcd",
- * "skip_dead_rows", "num_clusters", "min_clusters", "max_clusters", "ecapa_precision" (0 = f32 MFMA, 1 = fp16 MFMA),
- * "rank0_permille" (sd_diarize_sharded: share of rank 0, -1 = equal), "virtual_world" (test mode: a communicator of ONE rank plays all W
- * ranks of the plan in turn, slot by slot, so plan + slot assembly of a W-GPU job run on a 1-GPU box), "constrained_assignment" (1 = constrained_argmax of
- * clustering/Clustering.py:81-94: the local speakers of a chunk go to different clusters; applies to sd_clustering* and the whole path).
- * Kernel-tuning keys (defaults are the measured optimum; results do not depend on them): "conv_h256" / "conv_w256_f32" (256 x 256 tile for the
- * wide ECAPA layers in fp16 / f32), "conv_w256_kmin" (shortest contraction that tile takes), "conv_pn" / "conv_pn128" (column tiles per
- * super-block), "ecapa_ld_pad" (elements added to the activation rows, multiple of 8), "seg_shared_conv0" (1 = SincNet's first convolution once over the
- * waveform instead of once per overlapping chunk; scores equal within 2e-5). An unknown key returns SD_ERR_ARG. */
+/* ---- options.  Product keys (the knobs clustering/Clustering.py and the multi-GPU path expose; the reference hard-codes them):
+ * "num_clusters", "min_clusters", "max_clusters" (-1 = unset; Clustering.py:21-43), "constrained_assignment" (1 = constrained_argmax of
+ * Clustering.py:81-94: the local speakers of a chunk go to different clusters; applies to sd_clustering* and the whole path),
+ * "ecapa_precision" (0 = f32 MFMA = the reference's ORT precision, 1 = fp16 MFMA with f32 accumulation),
+ * "rank0_permille" (sd_diarize_sharded: share of the chunks rank 0 infers itself, -1 = equal),
+ * "comm_timeout_ms" (deadline of the exchange step of a sharded job, default 600 000).
+ * Test and tuning keys are listed in sdhip_test.h.  An unknown key returns SD_ERR_ARG. */
 int sd_set_option(sd_ctx*, const char* key, int64_t value);
-/* tuning hook (tools/tune_conv.py): time one conv_gemm shape on scratch data; dbg selects an ablation */
-int sd_bench_barrier(sd_ctx*, int workgroups, int iters, int dirty_doubles, double* us_per_barrier);
-int sd_bench_conv(sd_ctx*, int64_t items, int Tp, int T, int Cin, int Cout, int KT, int dil, int has_x2, int dbg, int reps, double* ms_per_launch);
 
 #ifdef __cplusplus
 }

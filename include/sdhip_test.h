@@ -1,0 +1,44 @@
+/*
+ * sdhip_test.h -- test, measurement and tuning hooks of libsdhip.so.
+ *
+ * Nothing in this header replaces a reference interface: these entry points exist for tests/, bench.py and tools/ only (the
+ * drop-in boundary is sdhip.h, whose every entry cites the reference code it stands in for).  The symbols are exported by the
+ * same library; a host program that only diarizes never needs this file.
+ */
+#ifndef SDHIP_TEST_H
+#define SDHIP_TEST_H
+#include "sdhip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- planted workload (measurement / test hook, SURVEY 8d: "with synthetic weights force a deterministic activity
+ * pattern for stage >= a4 (override sigmoid outputs from the schedule) so N is controlled").  With seeded random
+ * weights PyanNet and ECAPA do not follow the talkers, so every stage after them would only ever see one degenerate
+ * case (K = 1, one turn).  After this call sd_diarize* / sd_shard_infer_dev still run both networks at full cost, then
+ * replace the segmentation scores of chunks [chunk_lo, chunk_lo + chunks) by d_scores [chunks][293][3] before
+ * post-segmentation, and the embedding rows of those chunks that are not NaN by the reference's own rule
+ * (sd.cpp:2479-2549) by d_emb [chunks*3][192] before the all-gather / clustering.  Either pointer may be NULL; the
+ * buffers stay owned by the caller and must outlive the calls; chunks = 0 removes the hook.  Never set by the CLI. */
+int sd_set_planted(sd_ctx*, const float* d_scores, const float* d_emb, int64_t chunk_lo, int64_t chunks);
+
+/* ---- measurement hooks (bench.py): GPU time of named kernels measured with hipEvents on the library's own stream
+ * (option "profile" = 1), with the algorithmic FLOPs / bytes the launcher bills them. */
+int sd_kernel_stats(const sd_ctx*, const char* kernel, double* total_ms, int64_t* launches, double* flops, double* bytes);
+void sd_reset_stats(sd_ctx*);
+/* test / tuning keys of sd_set_option (defaults are the measured optimum; results do not depend on the tuning keys):
+ * "profile", "emb_batch_items", "seg_batch_chunks", "linkage_wgs" (-1 auto, 0 one workgroup), "linkage_threads", "linkage_one_xcd",
+ * "skip_dead_rows", "virtual_world" (test mode: a communicator of ONE rank plays all W ranks of the plan in turn, slot by slot, so plan +
+ * slot assembly + status exchange of a W-GPU job run on a 1-GPU box), "inject_fail_rank" (test: that rank -- a played rank under
+ * virtual_world -- reports SD_ERR_ARG instead of inferring; every rank must then return an error for the job),
+ * "conv_h256" / "conv_w256_f32" (256 x 256 tile for the wide ECAPA layers in fp16 / f32), "conv_w256_kmin" (shortest contraction that tile
+ * takes), "conv_pn" / "conv_pn128" (column tiles per super-block), "ecapa_ld_pad" (elements added to the activation rows, multiple of 8),
+ * "seg_shared_conv0" (1 = SincNet's first convolution once over the waveform instead of once per overlapping chunk). */
+/* tuning hooks (tools/): time one conv_gemm shape on scratch data (dbg selects an ablation); time a grid barrier */
+int sd_bench_barrier(sd_ctx*, int workgroups, int iters, int dirty_doubles, double* us_per_barrier);
+int sd_bench_conv(sd_ctx*, int64_t items, int Tp, int T, int Cin, int Cout, int KT, int dil, int has_x2, int dbg, int reps, double* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -98,6 +98,8 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "ecapa_precision") { if (v != 0 && v != 1) SD_FAIL(c, SD_ERR_ARG, "ecapa_precision must be 0 (f32) or 1 (f16)"); c->ecapa_precision = (int)v; }
     else if (k == "rank0_permille") c->rank0_permille = (int)v;
     else if (k == "virtual_world") c->virtual_world = (int)v;
+    else if (k == "comm_timeout_ms") c->comm_timeout_ms = v;
+    else if (k == "inject_fail_rank") c->inject_fail_rank = (int)v;
     else if (k == "constrained_assignment") c->constrained_assignment = v != 0;
     else if (k == "num_clusters") c->num_clusters = (int)v;
     else if (k == "min_clusters") c->min_clusters = (int)v;

@@ -65,15 +65,17 @@ extern "C" int sd_comm_unique_id(void* id)
     return SD_OK;
 }
 
+static int wait_exchange(sd_ctx* c, const char* what);
+
 extern "C" int sd_comm_destroy(sd_ctx* c)
 {
     if (!c) return SD_ERR_ARG;
     if (c->comm) {
         (void)hipSetDevice(c->device);
-        (void)hipStreamSynchronize(c->stream);
-        (void)ncclCommDestroy((ncclComm_t)c->comm);
+        // every sharded call waits for its own exchange, so the stream holds no collective here unless a call failed half-way
+        if (wait_exchange(c, "draining the stream before ncclCommDestroy") == SD_OK && c->comm) (void)ncclCommDestroy((ncclComm_t)c->comm);
     }
-    c->comm = nullptr; c->rank = 0; c->world = 1;
+    c->comm = nullptr; c->rank = 0; c->world = 1; c->job_seq = 0;
     return SD_OK;
 }
 
@@ -94,7 +96,7 @@ extern "C" int sd_comm_init(sd_ctx* c, const void* id, int rank, int world)
     fflush(stdout);
     if (saved >= 0) { (void)dup2(saved, 1); close(saved); }
     NCCLCHK(c, ir);
-    c->comm = comm; c->rank = rank; c->world = world;
+    c->comm = comm; c->rank = rank; c->world = world; c->job_seq = 0;
     return SD_OK;
 }
 
@@ -111,12 +113,67 @@ int finalize(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t chunks, 
 int turns_out(sd_ctx* c, const std::vector<sd_turn>& v, sd_turn** turns, int64_t* n_turns);
 int pcm_to_wav(sd_ctx* c, const int16_t* d_pcm, int64_t n, float** d_wav);
 
+// ---- failure handling of the collective step
+// A rank that fails locally (bad samples, a HIP error in its inference) must not return before the all-gather: its peers would
+// block in the collective forever.  Every rank therefore ALWAYS reaches the exchange and contributes a status record
+// {its return code, job sequence number, n_total (two words)} that travels in the same RCCL group as the data; every rank then waits
+// for the exchange with a deadline (hipEventQuery + ncclCommGetAsyncError, option "comm_timeout_ms") and reads all records, so one
+// failing rank makes EVERY rank return an error for the SAME job.  A rank that disappears (crash, kill) is the deadline's case:
+// the communicator is aborted (ncclCommAbort), the context has no communicator afterwards, SD_ERR_COMM is returned.
+// Any non-OK return of a sharded call means the job group must be torn down (the peers' job counters no longer agree).
+#define SD_STATUS_WORDS 4
+
+static void comm_kill(sd_ctx* c)
+{
+    if (c->comm) (void)ncclCommAbort((ncclComm_t)c->comm);
+    c->comm = nullptr; c->world = 1; c->rank = 0;
+}
+
+// waits until everything queued on the library's stream (the exchange included) has run, but never longer than the deadline
+static int wait_exchange(sd_ctx* c, const char* what)
+{
+    hipEvent_t ev = nullptr;
+    HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t er = hipEventRecord(ev, c->stream);
+    if (er != hipSuccess) { (void)hipEventDestroy(ev); SD_FAIL(c, SD_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er)); }
+    const double t0 = now_ms();
+    const double limit = c->comm_timeout_ms > 0 ? (double)c->comm_timeout_ms : 600000.0;
+    int spins = 0;
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) {
+            (void)hipEventDestroy(ev); comm_kill(c);
+            SD_FAIL(c, SD_ERR_HIP, "%s: stream failed: %s", what, hipGetErrorString(q));
+        }
+        if (c->comm) {
+            ncclResult_t ar = ncclSuccess;
+            const ncclResult_t gr = ncclCommGetAsyncError((ncclComm_t)c->comm, &ar);
+            if (gr != ncclSuccess || (ar != ncclSuccess && ar != ncclInProgress)) {
+                const int rk = c->rank;
+                (void)hipEventDestroy(ev); comm_kill(c);
+                SD_FAIL(c, SD_ERR_COMM, "rank %d: %s: RCCL reports %s; communicator aborted", rk, what, ncclGetErrorString(gr != ncclSuccess ? gr : ar));
+            }
+        }
+        const double waited = now_ms() - t0;
+        if (waited > limit) {
+            const int rk = c->rank, wd = c->world;
+            (void)hipEventDestroy(ev); comm_kill(c);
+            SD_FAIL(c, SD_ERR_COMM, "rank %d of %d: %s did not complete within %.0f ms (a peer rank never reached it); communicator aborted", rk, wd, what, limit);
+        }
+        if (++spins > 2000) usleep(waited > 50.0 ? 200 : 20);       // the first microseconds spin: the common case is an exchange already done
+    }
+    (void)hipEventDestroy(ev);
+    return SD_OK;
+}
+
 extern "C" int sd_diarize_sharded_dev(sd_ctx* c, const int16_t* d_pcm_shard, int64_t first_sample, int64_t shard_samples, int64_t n,
                                       sd_turn** turns, int64_t* n_turns)
 {
     ENTER(c);
+    // argument errors every rank evaluates identically come first: they cannot split the group
     if (!c->comm) SD_FAIL(c, SD_ERR_ARG, "sd_diarize_sharded: no communicator (call sd_comm_init first)");
-    if (!turns || !n_turns || n <= 1 || first_sample < 0 || shard_samples < 0) SD_FAIL(c, SD_ERR_ARG, "sd_diarize_sharded: bad argument");
+    if (!turns || !n_turns || n <= 1) SD_FAIL(c, SD_ERR_ARG, "sd_diarize_sharded: bad argument");
     *turns = nullptr; *n_turns = 0;
     const double t0 = now_ms();
     const int64_t C = sd_num_chunks(n, nullptr);
@@ -135,32 +192,86 @@ extern "C" int sd_diarize_sharded_dev(sd_ctx* c, const int16_t* d_pcm_shard, int
     WS(c, float, s_emb, "mg_send_emb", emb_slot);
     WS(c, float, g_seg, "mg_gather_seg", seg_slot * W);
     WS(c, float, g_emb, "mg_gather_emb", emb_slot * W);
-    int rc;
+    WS(c, int32_t, s_st, "mg_send_status", SD_STATUS_WORDS);
+    WS(c, int32_t, g_st, "mg_gather_status", (size_t)SD_STATUS_WORDS * W);
+    c->job_seq++;
+    // ---- local part: from here on a failure is recorded, not returned, until the exchange has been queued
+    std::vector<int32_t> st((size_t)SD_STATUS_WORDS * (size_t)W, 0);          // virt: one record per played rank; else record 0 = mine
+    auto record = [&](int slot, int code) {
+        int32_t* r = &st[(size_t)slot * SD_STATUS_WORDS];
+        r[0] = code; r[1] = (int32_t)(c->job_seq & 0x7fffffff); r[2] = (int32_t)(n & 0xffffffffll); r[3] = (int32_t)(n >> 32);
+    };
+    int rc = SD_OK;
+    std::string my_err;
     if (myhi > mylo) {
         const int64_t need_lo = mylo * SD_HOP;
         int64_t need_hi = (myhi - 1) * SD_HOP + SD_CHUNK; if (need_hi > n) need_hi = n;
-        if (!d_pcm_shard || first_sample > need_lo || first_sample + shard_samples < need_hi)
-            SD_FAIL(c, SD_ERR_ARG, "rank %d: samples [%lld,%lld) do not cover chunks [%lld,%lld)", c->rank, (long long)first_sample,
-                    (long long)(first_sample + shard_samples), (long long)mylo, (long long)myhi);
         float* w = nullptr;
-        if ((rc = pcm_to_wav(c, d_pcm_shard, shard_samples, &w))) return rc;
-        c->wav_origin = first_sample;             // kernels index the recording with absolute sample positions
-        rc = SD_OK;
-        if (!virt) rc = shard_infer(c, w, n, mylo, myhi, s_seg, s_emb);
-        else for (int r = 0; r < W && !rc; ++r)
-            if (hi[(size_t)r] > lo[(size_t)r]) rc = shard_infer(c, w, n, lo[(size_t)r], hi[(size_t)r], g_seg + (size_t)r * seg_slot, g_emb + (size_t)r * emb_slot);
+        auto local = [&]() -> int {
+            if (!d_pcm_shard || first_sample < 0 || shard_samples < 0 || first_sample > need_lo || first_sample + shard_samples < need_hi)
+                SD_FAIL(c, SD_ERR_ARG, "rank %d: samples [%lld,%lld) do not cover chunks [%lld,%lld)", c->rank, (long long)first_sample,
+                        (long long)(first_sample + shard_samples), (long long)mylo, (long long)myhi);
+            int r;
+            if ((r = pcm_to_wav(c, d_pcm_shard, shard_samples, &w))) return r;
+            c->wav_origin = first_sample;             // kernels index the recording with absolute sample positions
+            r = SD_OK;
+            if (!virt) { if (c->inject_fail_rank == c->rank) SD_FAIL(c, SD_ERR_ARG, "rank %d: injected failure (option inject_fail_rank)", c->rank);
+                         r = shard_infer(c, w, n, mylo, myhi, s_seg, s_emb); }
+            else for (int q = 0; q < W; ++q) {
+                int rq = SD_OK;
+                if (q == c->inject_fail_rank) rq = SD_ERR_ARG;            // the played rank q "fails": what the real rank 0 would see of it
+                else if (hi[(size_t)q] > lo[(size_t)q] && !r) rq = shard_infer(c, w, n, lo[(size_t)q], hi[(size_t)q], g_seg + (size_t)q * seg_slot, g_emb + (size_t)q * emb_slot);
+                record(q, rq);
+                if (rq && !r && q != c->inject_fail_rank) r = rq;         // a real failure of the one physical rank
+            }
+            return r;
+        };
+        rc = local();
         c->wav_origin = 0;
-        if (rc) return rc;
+        if (rc) my_err = c->err;
+    } else if (virt) for (int q = 0; q < W; ++q) record(q, SD_OK);
+    if (!virt) record(0, rc);
+    // ---- the exchange: always reached
+    int xrc = SD_OK;
+    {
+        auto exchange = [&]() -> int {
+            if (virt) {
+                HIPCHK(c, hipMemcpyAsync(g_st, st.data(), st.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                return SD_OK;
+            }
+            HIPCHK(c, hipMemcpyAsync(s_st, st.data(), SD_STATUS_WORDS * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            ProfScope ps(c, "rccl_all_gather", 0, (double)(seg_slot + emb_slot) * sizeof(float) * c->world);
+            NCCLCHK(c, ncclGroupStart());
+            NCCLCHK(c, ncclAllGather(s_st, g_st, SD_STATUS_WORDS, ncclInt32, (ncclComm_t)c->comm, c->stream));
+            NCCLCHK(c, ncclAllGather(s_seg, g_seg, seg_slot, ncclFloat, (ncclComm_t)c->comm, c->stream));
+            NCCLCHK(c, ncclAllGather(s_emb, g_emb, emb_slot, ncclFloat, (ncclComm_t)c->comm, c->stream));
+            NCCLCHK(c, ncclGroupEnd());
+            return SD_OK;
+        };
+        xrc = exchange();
+        if (xrc) {                                   // could not even queue the exchange: the peers will run into their deadline
+            const std::string e = c->err; comm_kill(c);
+            SD_FAIL(c, xrc, "%s; communicator aborted", e.c_str());
+        }
     }
-    if (!virt) {
-        ProfScope ps(c, "rccl_all_gather", 0, (double)(seg_slot + emb_slot) * sizeof(float) * c->world);
-        NCCLCHK(c, ncclGroupStart());
-        NCCLCHK(c, ncclAllGather(s_seg, g_seg, seg_slot, ncclFloat, (ncclComm_t)c->comm, c->stream));
-        NCCLCHK(c, ncclAllGather(s_emb, g_emb, emb_slot, ncclFloat, (ncclComm_t)c->comm, c->stream));
-        NCCLCHK(c, ncclGroupEnd());
+    if ((xrc = wait_exchange(c, "all-gather of scores and embeddings"))) return xrc;
+    std::vector<int32_t> all((size_t)SD_STATUS_WORDS * (size_t)W);
+    HIPCHK(c, hipMemcpy(all.data(), g_st, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int r = 0; r < W; ++r) {
+        const int32_t* q = &all[(size_t)r * SD_STATUS_WORDS];
+        const int64_t n_r = (int64_t)(uint32_t)q[2] | ((int64_t)q[3] << 32);
+        if (q[0] != SD_OK) {
+            const int code = q[0] > 0 && q[0] <= SD_ERR_COMM ? q[0] : SD_ERR_HIP;
+            if (!my_err.empty() && (virt || r == c->rank)) SD_FAIL(c, code, "%s", my_err.c_str());
+            SD_FAIL(c, code, "rank %d of %d failed with code %d in its part of the job (its own sd_last_error has the reason); no turns", r, W, q[0]);
+        }
+        if (q[1] != (int32_t)(c->job_seq & 0x7fffffff) || n_r != n)
+            SD_FAIL(c, SD_ERR_COMM, "rank %d is in another job (its call #%d on %lld samples, this rank's call #%d on %lld samples): the ranks must make the same "
+                    "sequence of sd_diarize_sharded calls", r, (int)q[1], (long long)n_r, (int)(c->job_seq & 0x7fffffff), (long long)n);
     }
     if (c->rank != 0) {
-        // the send buffers are reused by the next job on the same stream: nothing to wait for here
+        // the send buffers are reused by the next job on the same stream: nothing else to wait for here.  Rank 0's finalize of this job
+        // overlaps this rank's inference of the next one.
         c->stage_ms[3] = now_ms() - t0;
         return SD_OK;
     }

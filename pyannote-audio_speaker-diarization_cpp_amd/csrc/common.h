@@ -7,7 +7,7 @@
 #include <map>
 #include <string>
 #include <vector>
-#include "../../include/sdhip.h"
+#include "../../include/sdhip_test.h"
 
 #define SD_T 501          // STFT frames per item (1 + 80000/160), sd.cpp:1980-2008
 #define SD_TP 501         // rows per item in activation buffers (= T: no padding rows; a 128-row tile may span two items)
@@ -135,6 +135,9 @@ struct sd_ctx {
     void* comm = nullptr;                       // ncclComm_t (comm.cpp), null = single GPU
     int rank = 0, world = 1;
     int virtual_world = 0;                      // test mode of sd_diarize_sharded on one rank (comm.cpp)
+    int64_t comm_timeout_ms = 600000;            // deadline of the exchange step of a sharded job (a peer that never arrives); then ncclCommAbort
+    int64_t job_seq = 0;                        // sharded jobs since sd_comm_init (travels in the status record: ranks in different jobs are detected)
+    int inject_fail_rank = -1;                  // test hook: this rank (a played rank under virtual_world) reports SD_ERR_ARG instead of inferring
     int rank0_permille = -1;                    // share of the chunks rank 0 infers itself (it also finalizes); -1 = equal shares
     const float* planted_scores = nullptr;      // sd_set_planted: measurement / test hook
     const float* planted_emb = nullptr;

@@ -67,8 +67,11 @@ static bool read_all(int fd, void* buf, size_t n)
     return true;
 }
 
-// one rank of the sharded job; id_rd = pipe this rank reads the rendezvous id from (ranks > 0), id_wr = the pipes rank 0 writes
-static int run_rank(const Args& a, int rank, int world, int id_rd, const std::vector<int>& id_wr)
+// one rank of the sharded job.  id_rd = pipe this rank reads the rendezvous id from (ranks > 0), id_wr = the pipes rank 0 writes it to;
+// ready_wr = pipe on which this rank (> 0) tells rank 0 that its wav and its context are in place, ready_rd = rank 0's ends.
+// Rank 0 mints the id only after EVERY rank has reported ready: a rank that cannot start (no such GPU, unreadable wav, bad model)
+// ends the job before anyone enters ncclCommInitRank, where a missing peer would mean waiting forever.
+static int run_rank(const Args& a, int rank, int world, int id_rd, const std::vector<int>& id_wr, int ready_wr, const std::vector<int>& ready_rd)
 {
     int16_t* pcm = nullptr; int64_t n = 0; int32_t sr = 0, ch = 0;
     if (sd_read_wav(a.wav, &pcm, &n, &sr, &ch) != SD_OK) {
@@ -79,9 +82,17 @@ static int run_rank(const Args& a, int rank, int world, int id_rd, const std::ve
     if (!ctx) { fprintf(stderr, "rank %d: sd_create failed: %s\n", rank, sd_create_error()); return 1; }
     unsigned char id[SD_COMM_ID_BYTES];
     if (rank == 0) {
+        for (size_t q = 0; q < ready_rd.size(); ++q) {
+            char ok = 0;
+            if (!read_all(ready_rd[q], &ok, 1) || ok != 1) { fprintf(stderr, "rank 0: rank %zu did not come up; no job\n", q + 1); return 1; }
+        }
         if (sd_comm_unique_id(id) != SD_OK) { fprintf(stderr, "rank 0: sd_comm_unique_id failed\n"); return 1; }
         for (int fd : id_wr) if (write(fd, id, sizeof(id)) != (ssize_t)sizeof(id)) { fprintf(stderr, "rank 0: cannot hand the rendezvous id over\n"); return 1; }
-    } else if (!read_all(id_rd, id, sizeof(id))) { fprintf(stderr, "rank %d: no rendezvous id from rank 0\n", rank); return 1; }
+    } else {
+        const char ok = 1;
+        if (write(ready_wr, &ok, 1) != 1) { fprintf(stderr, "rank %d: rank 0 is gone\n", rank); return 1; }
+        if (!read_all(id_rd, id, sizeof(id))) { fprintf(stderr, "rank %d: no rendezvous id from rank 0\n", rank); return 1; }
+    }
     if (sd_comm_init(ctx, id, rank, world) != SD_OK) { fprintf(stderr, "rank %d: sd_comm_init failed: %s\n", rank, sd_last_error(ctx)); return 1; }
     std::vector<int64_t> ranges((size_t)world * 2);
     sd_shard_plan(n, world, -1, ranges.data(), nullptr);
@@ -90,12 +101,13 @@ static int run_rank(const Args& a, int rank, int world, int id_rd, const std::ve
     if (s1 > n) s1 = n;
     if (s0 > n) s0 = n;
     sd_turn* turns = nullptr; int64_t nt = 0;
+    // collective failure: if any rank fails in its part, every rank gets a non-OK return here (comm.cpp) and exits 1
     const int rc = sd_diarize_sharded(ctx, pcm + s0, s0, s1 - s0, n, &turns, &nt);
     if (rc != SD_OK) { fprintf(stderr, "rank %d: diarization failed (%d): %s\n", rank, rc, sd_last_error(ctx)); return 1; }
     if (rank == 0) print_block(ctx, turns, nt, a);
     sd_free_turns(turns);
     sd_free_pcm(pcm);
-    sd_destroy(ctx);                       // (drains the stream: the all-gather of the non-zero ranks completes here)
+    sd_destroy(ctx);
     return 0;
 }
 
@@ -117,38 +129,64 @@ int main(int argc, char* argv[])
     a.seg = pos[0]; a.emb = pos[1]; a.wav = pos[2];
     if (a.gpus <= 1) return run_single(a);
 
-    // ---- launcher: nothing below touches HIP in this process.  pipes[r] carries the rendezvous id from rank 0 to rank r.
+    // ---- launcher: nothing below touches HIP in this process.  id pipes carry the rendezvous id from rank 0 to rank r,
+    // ready pipes one byte from rank r to rank 0.
     const int world = a.gpus;
-    std::vector<int> rd((size_t)world, -1), wr((size_t)world, -1);
+    std::vector<int> id_rd((size_t)world, -1), id_wr((size_t)world, -1), rdy_rd((size_t)world, -1), rdy_wr((size_t)world, -1);
     for (int r = 1; r < world; ++r) {
         int fd[2];
         if (pipe(fd) != 0) { perror("pipe"); return 1; }
-        rd[(size_t)r] = fd[0]; wr[(size_t)r] = fd[1];
+        id_rd[(size_t)r] = fd[0]; id_wr[(size_t)r] = fd[1];
+        if (pipe(fd) != 0) { perror("pipe"); return 1; }
+        rdy_rd[(size_t)r] = fd[0]; rdy_wr[(size_t)r] = fd[1];
     }
     fflush(stdout); fflush(stderr);
     std::vector<pid_t> kids;
     for (int r = 0; r < world; ++r) {
         const pid_t pid = fork();
-        if (pid < 0) { perror("fork"); return 1; }
+        if (pid < 0) { perror("fork"); for (pid_t k : kids) kill(k, SIGKILL); return 1; }
         if (pid == 0) {
             signal(SIGPIPE, SIG_IGN);           // a write to a dead rank's pipe is an error return, not a kill
             // keep only this rank's ends: a rank that dies closes its pipes, so nobody blocks on a read forever
-            std::vector<int> mine;
+            std::vector<int> my_id_wr, my_rdy_rd;
             for (int q = 1; q < world; ++q) {
-                if (r == 0) { close(rd[(size_t)q]); mine.push_back(wr[(size_t)q]); }
-                else { close(wr[(size_t)q]); if (q != r) close(rd[(size_t)q]); }
+                if (r == 0) { close(id_rd[(size_t)q]); close(rdy_wr[(size_t)q]); my_id_wr.push_back(id_wr[(size_t)q]); my_rdy_rd.push_back(rdy_rd[(size_t)q]); }
+                else { close(id_wr[(size_t)q]); close(rdy_rd[(size_t)q]); if (q != r) { close(id_rd[(size_t)q]); close(rdy_wr[(size_t)q]); } }
             }
-            const int rc = run_rank(a, r, world, r > 0 ? rd[(size_t)r] : -1, mine);
+            const int rc = run_rank(a, r, world, r > 0 ? id_rd[(size_t)r] : -1, my_id_wr, r > 0 ? rdy_wr[(size_t)r] : -1, my_rdy_rd);
             fflush(stdout); fflush(stderr);
             _exit(rc);
         }
         kids.push_back(pid);
     }
-    for (int r = 1; r < world; ++r) { close(rd[(size_t)r]); close(wr[(size_t)r]); }
+    for (int r = 1; r < world; ++r) { close(id_rd[(size_t)r]); close(id_wr[(size_t)r]); close(rdy_rd[(size_t)r]); close(rdy_wr[(size_t)r]); }
+    // reap in completion order; the first rank that ends badly ends the job: the others (which may be waiting for it inside RCCL)
+    // are killed by their exact pids and reaped
     int worst = 0;
-    for (pid_t pid : kids) {
+    size_t left = kids.size();
+    while (left > 0) {
         int st = 0;
-        if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) worst = 1;
+        const pid_t pid = waitpid(-1, &st, 0);
+        if (pid < 0) { worst = 1; break; }
+        size_t which = kids.size();
+        for (size_t i = 0; i < kids.size(); ++i) if (kids[i] == pid) which = i;
+        if (which == kids.size()) continue;
+        kids[which] = -1; --left;
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+            worst = 1;
+            fprintf(stderr, "launcher: rank %zu ended with %s %d; stopping the other ranks\n", which, WIFEXITED(st) ? "exit code" : "signal", WIFEXITED(st) ? WEXITSTATUS(st) : WTERMSIG(st));
+            // a rank whose own failure is collective (comm.cpp) exits by itself within moments: give the others a short grace period
+            // so that their reasons reach stderr, then kill what is left
+            for (int spin = 0; spin < 100 && left > 0; ++spin) {
+                int st2 = 0;
+                const pid_t p2 = waitpid(-1, &st2, WNOHANG);
+                if (p2 > 0) { for (size_t i = 0; i < kids.size(); ++i) if (kids[i] == p2) { kids[i] = -1; --left; } }
+                else usleep(20000);
+            }
+            for (size_t i = 0; i < kids.size(); ++i) if (kids[i] > 0) kill(kids[i], SIGKILL);
+            for (size_t i = 0; i < kids.size(); ++i) if (kids[i] > 0) { int st3 = 0; (void)waitpid(kids[i], &st3, 0); kids[i] = -1; }
+            left = 0;
+        }
     }
     return worst;
 }

@@ -14,11 +14,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = sdhip.lib()
-    hdr = open(os.path.join(ROOT, "include", "sdhip.h")).read()
-    declared = set(re.findall(r"\b(sd_[a-z0-9_]+)\s*\(", hdr))
+    decl = {}
+    for h in ("sdhip.h", "sdhip_test.h"):
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        decl[h] = set(re.findall(r"^(?:[a-z_0-9]+\*?\s+\*?)+(sd_[a-z0-9_]+)\s*\(", hdr, re.M))
+    declared = decl["sdhip.h"] | decl["sdhip_test.h"]
+    assert not (decl["sdhip.h"] & decl["sdhip_test.h"])
     assert declared == set(sdhip.EXPORTS), declared ^ set(sdhip.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
+    # the drop-in header holds reference-cited entries only: the test / bench / tuning hooks live in sdhip_test.h
+    assert decl["sdhip_test.h"] == {"sd_set_planted", "sd_kernel_stats", "sd_reset_stats", "sd_bench_barrier", "sd_bench_conv"}
 
 
 def test_create_fails_loudly_without_gpu_or_model(tmp_path):
@@ -84,6 +90,7 @@ def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
     src.write_text(r'''
 #include <stdio.h>
 #include "sdhip.h"
+#include "sdhip_test.h"
 int main(void) {
     int64_t last = 0, ranges[4], per = 0;
     int64_t c = sd_num_chunks(944000, &last);

@@ -214,6 +214,51 @@ def test_cli_multi_gpu_launcher_fails_cleanly_without_devices(golden_dir):
     assert "rank 0" in out.stderr and "rank 1" in out.stderr and "Speaker_" not in out.stdout
 
 
+def _run_bench(args, timeout, env_extra=None):
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    return out, time.time() - t0
+
+
+def test_bench_self_launches_n_ranks_and_fails_loudly_when_the_gpus_are_not_there():
+    """`python bench.py --gpus 2` without a launcher must not quietly measure one GPU: it starts 2 ranks itself (before any GPU call),
+    and on a box with fewer than 2 GPUs every rank says why, no result line is printed, the exit code is non-zero -- well within a minute
+    (a rank that waits for a dead peer in the rendezvous is stopped by the launcher)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    out, dt = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--hours-per-gpu", "0.02"], 120)
+    assert out.returncode != 0 and dt < 60, (out.returncode, dt)
+    assert "{" not in out.stdout                                            # no result line
+    assert "rank 1" in out.stderr and "GPU" in out.stderr and "no result line" in out.stderr
+    if torch.cuda.device_count() == 0:
+        assert "[rank 0]" in out.stderr and "[rank 1]" in out.stderr
+
+
+def test_bench_refuses_a_world_size_that_is_not_the_one_asked_for():
+    out, _ = _run_bench(["--gpus", "2"], 120, {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and "refusing" in out.stderr and "{" not in out.stdout
+    out, _ = _run_bench(["--gpus", "1"], 120, {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and "refusing" in out.stderr and "{" not in out.stdout
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_on_a_one_gpu_box_fails_within_a_minute():
+    """the same on the GPU box: rank 0 gets its GPU and waits in the rendezvous, rank 1 has no device; the launcher ends the job"""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one GPU")
+    out, dt = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--hours-per-gpu", "0.02"], 150)
+    assert out.returncode != 0 and dt < 60, (out.returncode, dt, out.stderr[-2000:])
+    assert "{" not in out.stdout and "[rank 1]" in out.stderr and "LOCAL_RANK 1 but this node has 1 GPU" in out.stderr
+
+
 # ------------------------------------------------------------------ f3: constrained_argmax (Clustering.py:81-94)
 def test_oracle_linear_sum_assignment_is_scipys():
     """the dependency behind constrained_argmax is scipy.optimize.linear_sum_assignment; the oracle restates its algorithm
@@ -350,8 +395,30 @@ def test_sharded_entry_point_through_rccl_world_of_one(diarizer):
             finally:
                 diarizer.set_option("virtual_world", 0)
                 diarizer.set_option("rank0_permille", -1)
-        with pytest.raises(sdhip.SdError):
+        with pytest.raises(sdhip.SdError) as e:
             diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 8000, n - 8000, n)       # samples do not cover the rank's chunks
+        assert "do not cover" in str(e.value)
+        # a failure in one rank's part is collective (comm.cpp): the failing rank still joins the exchange with a status record and
+        # every rank returns an error for the job -- here rank 1 of a 3-rank plan "fails" and rank 0 (this process) must report it
+        diarizer.set_option("virtual_world", 3)
+        diarizer.set_option("inject_fail_rank", 1)
+        try:
+            with pytest.raises(sdhip.SdError) as e:
+                diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 0, n, n)
+            assert e.value.code == 1 and "rank 1 of 3 failed" in str(e.value)
+        finally:
+            diarizer.set_option("virtual_world", 0)
+        # ... and the real exchange with the real rank failing: the all-gather still runs, the error is this rank's own
+        diarizer.set_option("inject_fail_rank", 0)
+        try:
+            before = diarizer.kernel_stats("rccl_all_gather")["launches"]
+            with pytest.raises(sdhip.SdError) as e:
+                diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 0, n, n)
+            assert "injected failure" in str(e.value)
+            assert diarizer.kernel_stats("rccl_all_gather")["launches"] == before + 1
+        finally:
+            diarizer.set_option("inject_fail_rank", -1)
+        assert diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 0, n, n) == whole     # the communicator of this single rank is still in step
     finally:
         diarizer.comm_destroy()
     assert diarizer.comm_info() == (0, 0)

@@ -244,3 +244,46 @@ def test_fp16_mode_embeddings_at_scale_stay_within_the_north_star_tolerance(diar
     assert np.median(rel) <= 1e-2 and rel.max() <= 1e-1, (np.median(rel), rel.max())
     assert turns16 == turns32 and len(turns16) > 60
     assert real16 == real32 and len(real16) >= 5
+
+
+@pytest.mark.gpu
+def test_eight_hour_job_as_eight_rank_plan_gives_the_single_call_turns(diarizer):
+    """BASELINE.json configs[3] on one GPU: 8 h of audio (57 591 chunks, ~100 000 live items) through sd_diarize_dev, and the same job as
+    the 8-rank plan of sd_diarize_sharded_dev (`virtual_world` = 8: every rank's 32-aligned chunk range inferred into the slot the RCCL
+    all-gather would put it in, status records, assembly with a reduced rank-0 share, finalize): identical turns, order included.
+    The audio is one synthetic hour repeated (its content cannot reach the output: the networks' outputs are replaced by the planted
+    ones); every hour has its own schedule, so the clustering sees the full 8-hour problem."""
+    import torch
+    import sdhip
+    hour = synth.make_pcm(3600.0, 1234)
+    pcm = np.tile(hour, 8)
+    n = len(pcm)
+    nc = synth.num_chunks(n)
+    assert nc == 57591                                                     # SURVEY 8 size table, configs[3]
+    sched = []
+    for h in range(8):
+        for (s, e, k, ov) in synth.with_duets(synth.schedule(3600.0, 1234 + h)):
+            sched.append((s + h * len(hour), e + h * len(hour), k, ov))
+    scores, assign = synth.planted_scores(sched, n, 0, nc)
+    emb = synth.planted_embeddings(assign)
+    dev = torch.device("cuda", 0)
+    d_pcm = torch.from_numpy(pcm).to(dev)
+    d_sc, d_em = torch.from_numpy(scores).to(dev), torch.from_numpy(emb).to(dev)
+    torch.cuda.synchronize()
+    diarizer.set_planted(d_sc.data_ptr(), d_em.data_ptr(), 0, nc)
+    diarizer.comm_init(sdhip.comm_unique_id(), 0, 1)
+    try:
+        diarizer.reset_stats()
+        whole = diarizer.diarize_dev(d_pcm.data_ptr(), n)
+        live = diarizer.kernel_stats("items_live")
+        diarizer.set_option("virtual_world", 8)
+        diarizer.set_option("rank0_permille", 60)
+        plan = diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 0, n, n)
+    finally:
+        diarizer.set_option("virtual_world", 0)
+        diarizer.set_option("rank0_permille", -1)
+        diarizer.comm_destroy()
+        diarizer.set_planted(0, 0, 0, 0)
+    assert len(whole) > 4000 and len({t[2] for t in whole}) == 4
+    assert plan == whole
+    assert live["flops"] / max(live["launches"], 1) > 90000                # N of the AHC: ~100 000 live embeddings
