@@ -74,6 +74,11 @@ def lib():
                                   C.c_long, C.c_void_p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.orc_to_annotation.restype = C.c_long
     L.orc_to_annotation.argtypes = [c_dp, C.c_long, C.c_int] + [C.c_double] * 7 + [C.POINTER(Turn), C.c_long]
+    L.orc_window_start.restype = C.c_double
+    L.orc_window_start.argtypes = [C.c_double, C.c_double, C.c_long, C.c_int]
+    L.orc_range_to_segment.argtypes = [C.c_double, C.c_double, C.c_double, C.c_long, C.c_long, c_dp]
+    L.orc_support.restype = C.c_long
+    L.orc_support.argtypes = [C.POINTER(Turn), C.c_long, C.c_double]
     L.orc_format_turn.restype = C.c_int
     L.orc_format_turn.argtypes = [C.POINTER(Turn), C.c_char_p, C.c_int]
     L.orc_read_wav.restype = C.c_void_p
@@ -343,6 +348,26 @@ def to_annotation(binary, start, step=FRAME_STEP, dur=FRAME_STEP, onset=0.5, off
     buf = (Turn * cap)()
     n = lib().orc_to_annotation(b, rows, K, start, step, dur, onset, offset, min_on, min_off, buf, cap)
     return [(buf[i].start, buf[i].end, buf[i].label) for i in range(n)]
+
+
+def window_start(pos, step=FRAME_STEP, dur=FRAME_STEP, num_samples=1 << 40):
+    """SlidingWindow::operator[](pos).start, sd.cpp:1092-1115 (accumulates `start += step` from 0.0)"""
+    return float(lib().orc_window_start(step, dur, num_samples, pos))
+
+
+def range_to_segment(i0, n, start=0.0, step=FRAME_STEP, dur=FRAME_STEP):
+    out = np.zeros(2)
+    lib().orc_range_to_segment(start, step, dur, i0, n, out)
+    return float(out[0]), float(out[1])
+
+
+def support(segs, collar=None):
+    """Track::support on start-sorted (start, end) pairs of one label"""
+    arr = (Turn * max(len(segs), 1))()
+    for i, (a, b) in enumerate(segs):
+        arr[i] = Turn(a, b, 0)
+    n = lib().orc_support(arr, len(segs), MIN_OFF_F32 if collar is None else collar)
+    return [(arr[i].start, arr[i].end) for i in range(n)]
 
 
 def format_turn(t):

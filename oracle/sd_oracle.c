@@ -771,7 +771,9 @@ void orc_mark_inactive(const double *bin, long c, int F, int S, int *hard)
 }
 
 /* SlidingWindow::operator[], sd.cpp:1092-1115 (walks from 0.0, may bail) */
-static double sw_index_start(double step, double dur, long num_samples, int pos)
+double orc_window_start(double step, double dur, long num_samples, int pos);
+static double sw_index_start(double step, double dur, long num_samples, int pos) { return orc_window_start(step, dur, num_samples, pos); }
+double orc_window_start(double step, double dur, long num_samples, int pos)
 {
     int window_size = (int)round(dur * 16000.0), step_size = (int)round(step * 16000.0);
     double start = 0.0; size_t cur = 0; int index = 0;
@@ -781,6 +783,17 @@ static double sw_index_start(double step, double dur, long num_samples, int pos)
         start += step; cur += (size_t)step_size; index++;
     }
     return 0.0;
+}
+
+/* SlidingWindow::range_to_segment as to_diarization uses it for the extents (sd.cpp:2691-2706, 1029-1083):
+ * start + (i0 - .5) * step + .5 * dur, end = that + n * step, and i0 == 0 extends the start to the window start
+ * (segment/utils.py:497-540).  out[0] = start, out[1] = end */
+void orc_range_to_segment(double w_start, double w_step, double w_dur, long i0, long n, double *out)
+{
+    double start = w_start + ((double)i0 - .5) * w_step + .5 * w_dur;
+    double end = start + (double)n * w_step;
+    if (i0 == 0) start = w_start;
+    out[0] = start; out[1] = end;
 }
 
 /* crop_segment index part, sd.cpp:2567-2618; returns rows [*r0,*r1) */
@@ -834,10 +847,11 @@ long orc_reconstruct(const float *seg, long c, int F, int S, const int *hard,
     orc_aggregate(cl, c, F, K, 0.0, 0.5, 5.0, fstep, fdur, 0.0, 1, act, nact);
     free(cl);
     /* extents, sd.cpp:2691-2706 ; activations window = (0.0, fstep, fdur) */
-    double a_start = 0.0;
-    double a_end = 0.0 + (0 - .5) * fstep + .5 * fdur + (double)nact * fstep;
-    double c_start = cwin[0];
-    double c_end = cwin[0] + (0 - .5) * cwin[1] + .5 * cwin[2] + (double)ncount * cwin[1];
+    double ext[2];
+    orc_range_to_segment(0.0, fstep, fdur, 0, nact, ext);
+    double a_start = ext[0], a_end = ext[1];
+    orc_range_to_segment(cwin[0], cwin[1], cwin[2], 0, ncount, ext);
+    double c_start = ext[0], c_end = ext[1];
     double f0 = a_start > c_start ? a_start : c_start;
     double f1 = a_end < c_end ? a_end : c_end;
     long ar0, ar1, cr0, cr1; float astart, cstart_unused;
@@ -867,6 +881,25 @@ long orc_reconstruct(const float *seg, long c, int F, int S, const int *hard,
 
 typedef struct { double start, end; int label; } orc_turn;
 void orc_final_sort(orc_turn *t, long n);            /* final_sort.cpp */
+
+/* Track::support, sd.cpp:911-941 with Segment::gap / ::merge (831-860): start-sorted segments of one label, merged in place
+ * while the gap to the running segment is < collar.  Returns the new count. */
+long orc_support(orc_turn *segs, long ns, double collar)
+{
+    if (ns <= 0) return 0;
+    long w = 0; orc_turn cur = segs[0];
+    for (long i = 1; i < ns; ++i) {
+        double gap;
+        if (cur.start < segs[i].start) gap = (cur.end >= segs[i].start) ? 0.0 : segs[i].start - cur.end;
+        else gap = (cur.start <= segs[i].end) ? 0.0 : cur.start - segs[i].end;
+        if (gap < collar) {
+            if (segs[i].start < cur.start) cur.start = segs[i].start;
+            if (segs[i].end > cur.end) cur.end = segs[i].end;
+        } else { segs[w++] = cur; cur = segs[i]; }
+    }
+    segs[w++] = cur;
+    return w;
+}
 
 static int cmp_seg(const void *a, const void *b)
 {
@@ -908,20 +941,7 @@ long orc_to_annotation(const double *scores, long rows, int K, double w_start,
         }
         if (active) { segs[ns].start = start; segs[ns].end = ts[rows - 1]; segs[ns].label = k; ns++; }
         if (ns == 0) continue;
-        if (min_off > 0.0) {                                        /* Track::support :911-941 */
-            /* segments are already start-sorted by construction */
-            long w = 0; orc_turn cur = segs[0];
-            for (long i = 1; i < ns; ++i) {
-                double gap;
-                if (cur.start < segs[i].start) gap = (cur.end >= segs[i].start) ? 0.0 : segs[i].start - cur.end;
-                else gap = (cur.start <= segs[i].end) ? 0.0 : cur.start - segs[i].end;
-                if (gap < min_off) {
-                    if (segs[i].start < cur.start) cur.start = segs[i].start;
-                    if (segs[i].end > cur.end) cur.end = segs[i].end;
-                } else { segs[w++] = cur; cur = segs[i]; }
-            }
-            segs[w++] = cur; ns = w;
-        }
+        if (min_off > 0.0) ns = orc_support(segs, ns, min_off);    /* Track::support :911-941; segments are start-sorted by construction */
         if (min_on > 0) {                                           /* removeShort skips index 0, :943-953 */
             long w = 1;
             for (long i = 1; i < ns; ++i) if (!((segs[i].end - segs[i].start) < min_on)) segs[w++] = segs[i];
