@@ -142,20 +142,48 @@ __device__ __forceinline__ MinIdx wave_min(MinIdx m)
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_row_nn(const double* __restrict__ D, int64_t n, int* __restrict__ nb, double* __restrict__ md)
+// Two smallest values of a set: the minimum with its index (same rules as MinIdx) and the smallest value among all OTHER elements
+// (equal to the minimum when it occurs twice).  The second value is what makes a row's bound robust: when the distance to its
+// neighbour grows but stays below every other entry of the row, the bound is still exact (see k_linkage_mw).
+struct Min2 { double v; int i; double v2; };
+__device__ __forceinline__ void min2_acc(Min2& m, double v, int j)       // sequential scan in ascending j
+{
+    if (v < m.v) { m.v2 = m.v; m.v = v; m.i = j; }
+    else if (v < m.v2) m.v2 = v;
+}
+__device__ __forceinline__ Min2 min2_merge(Min2 a, Min2 b)
+{
+    if (b.i < 0) return a;
+    if (a.i < 0) return b;
+    Min2 r;
+    const bool bw = b.v < a.v || (b.v == a.v && b.i < a.i);
+    r.v = bw ? b.v : a.v; r.i = bw ? b.i : a.i;
+    r.v2 = fmin(bw ? a.v : b.v, fmin(a.v2, b.v2));
+    return r;
+}
+__device__ __forceinline__ Min2 wave_min2(Min2 m)
+{
+    MinIdx q; q.v = m.v; q.i = m.i;
+    const MinIdx w = wave_min(q);
+    Min2 r; r.v = w.v; r.i = w.i; r.v2 = INFINITY;
+    if (w.i < 0) return r;
+    // every lane but the winner's contributes its own minimum, the winner's lane its second value
+    const bool win = m.i == w.i && m.i >= 0;
+    r.v2 = wave_min_d(win ? m.v2 : (m.i >= 0 ? m.v : (double)INFINITY));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_row_nn(const double* __restrict__ D, int64_t n, int* __restrict__ nb, double* __restrict__ md, double* __restrict__ md2)
 {
     const int lane = threadIdx.x & 63;
     const int64_t x = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (x >= n - 1) return;
     const double* row = D + cidx(n, x, x + 1);
     const int64_t cnt = n - 1 - x;
-    MinIdx m; m.v = INFINITY; m.i = -1;
-    for (int64_t t = lane; t < cnt; t += 64) {
-        const double v = row[t];
-        if (v < m.v) { m.v = v; m.i = (int)(x + 1 + t); }
-    }
-    m = wave_min(m);
-    if (lane == 0) { nb[x] = m.i; md[x] = (m.i < 0) ? INFINITY : m.v; }
+    Min2 m; m.v = INFINITY; m.i = -1; m.v2 = INFINITY;
+    for (int64_t t = lane; t < cnt; t += 64) min2_acc(m, row[t], (int)(x + 1 + t));
+    m = wave_min2(m);
+    if (lane == 0) { nb[x] = m.i; md[x] = (m.i < 0) ? INFINITY : m.v; if (md2) md2[x] = (m.i < 0) ? INFINITY : m.v2; }
 }
 
 
@@ -479,18 +507,18 @@ __device__ __forceinline__ Cand block_min_c(Cand m, Cand* sh, int nwaves)
     return wave_min_c(r);                // every wave folds the per-wave winners itself
 }
 // the two reductions of a merge round (NN(y) partial and local arg-min) through ONE LDS exchange
-__device__ __forceinline__ void block_min_qc(MinIdx& q, Cand& m, MinIdx* shq, Cand* shc, int nwaves)
+__device__ __forceinline__ void block_min_qc(Min2& q, Cand& m, Min2* shq, Cand* shc, int nwaves)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    q = wave_min(q);
+    q = wave_min2(q);
     m = wave_min_c(m);
     __syncthreads();
     if (lane == 0) { shq[w] = q; shc[w] = m; }
     __syncthreads();
-    MinIdx rq; rq.v = INFINITY; rq.i = -1;
+    Min2 rq; rq.v = INFINITY; rq.i = -1; rq.v2 = INFINITY;
     Cand r; r.v = INFINITY; r.i = -1; r.y = -1; r.fresh = 0;
     if (lane < nwaves) { rq = shq[lane]; r = shc[lane]; }
-    q = wave_min(rq);
+    q = wave_min2(rq);
     m = wave_min_c(r);
 }
 
@@ -502,34 +530,41 @@ __device__ __forceinline__ void block_min_qc(MinIdx& q, Cand& m, MinIdx* shq, Ca
 //    and each scans its share of the columns of every such row; the partial minima travel in the slots of the
 //    one barrier the round needs anyway.  Refreshing up to KR near-top stale rows per round needs ~5x fewer rounds
 //    than refreshing only the top one (measured 9.3 k vs 49 k rounds at N = 21 573).
-#define KR 8
+#define KR 4
 // A slot is SLOT_WORDS 8-byte granules {32-bit payload word, 32-bit round tag}: a reader that sees the tag of the round it
 // waits for has the payload of that round (8-byte stores are single transactions), so publishing needs no separate
 // "ready" flag and no counter -- the readers poll the granules themselves.  Words: 0-1 arg-min bound (double), 2 its row,
-// 3 its neighbour, 4 freshness, 5-6 NN(y) partial (double), 7 its row, 8+3r.. refreshed-row partial r (double, row).
+// 3 its neighbour, 4 freshness, 5-6 NN(y) partial (double), 7 its row; merge rounds: 8 "row x had a second pair at the merge height",
+// 9-10 second value of the NN(y) partial; retry rounds: 8+5r.. refreshed-row partial r (minimum double, its row, second value double).
 #define SLOT_WORDS 32
 typedef unsigned long long MwGran;
 
 template <bool ONEX>
-__global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* size_all, int* cid, int* nb, double* md,
+__global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* size_all, int* cid, int* nb, double* md, const double* md2_init,
                                                          double* Z, MwGran* gran /*[2][G][SLOT_WORDS], zeroed*/,
                                                          unsigned* sync, int cap /*owned rows per workgroup, upper bound*/, int G)
 {
     extern __shared__ __attribute__((aligned(16))) int dyn_lds[];
-    // per owned row, 24 B of LDS: the active list and, beside every entry, the row's lower bound / neighbour / freshness.  The
+    // per owned row, 32 B of LDS: the active list and, beside every entry, the row's lower bound / neighbour / freshness.  The
     // owner is the only reader of these in the hot loops (local arg-min, Lance-Williams pass), so they never leave the CU; the
     // global md / nb copies are still written (row y's old bound is read by everybody) but not read back by the owner.
+    // l_md2 is the second level of the bound: every active entry of the row OTHER than the neighbour's is >= l_md2.  While the
+    // neighbour's distance stays <= l_md2 the bound is exact whatever the merge did to it, and a row only goes stale (and costs a
+    // retry round when it reaches the top) after it has lost BOTH levels; with the reference's single lower bound (cl.cpp:323-339) a
+    // row went stale every time the distance to its neighbour grew -- about half the rows per merge on clustered data, 0.46 retry
+    // rounds per merge on the planted hour.  Same merges: the arg-min of exact values does not depend on how the bounds are kept.
     double* l_md = (double*)dyn_lds;                 // [cap] bound of act[p]
-    int* act = (int*)(l_md + cap);                   // [cap] owned active rows, unordered
+    double* l_md2 = l_md + cap;                      // [cap] lower bound of the row's entries other than the neighbour's
+    int* act = (int*)(l_md2 + cap);                  // [cap] owned active rows, unordered
     int* pos = act + cap;                            // [cap] pos[z / G] = index of owned row z in act
     int* l_nb = pos + cap;                           // [cap] neighbour of act[p]
     unsigned char* l_fr = (unsigned char*)(l_nb + cap);   // [cap] freshness of act[p]
-    __shared__ MinIdx sh[MWT_MAX / 64];
+    __shared__ Min2 sh[MWT_MAX / 64];
     __shared__ Cand shc[MWT_MAX / 64];
-    __shared__ MinIdx s_part[KR][MWT_MAX / 64];
+    __shared__ Min2 s_part[KR][MWT_MAX / 64];
     __shared__ unsigned s_words[MWT][SLOT_WORDS + 1];  // this round's slots of all workgroups, as received (+1: lane u reads word w of slot u -- a 128-byte row stride would put all lanes on two banks)
     __shared__ Cand s_cand[MWT + 1];        // published local bests of the G <= 256 workgroups (+ row y)
-    __shared__ MinIdx s_row[KR];
+    __shared__ Min2 s_row[KR];
     __shared__ int s_L[2][KR];
     __shared__ int s_nL[2];
     __shared__ int s_cnt;
@@ -609,14 +644,14 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         return block_min_c(m, shc, NW);
     };
     // this workgroup's share of the columns of the nL rows in L: wave tasks (row r, sub-slice s)
-    auto scan_rows = [&](int nL, const int* L, MinIdx* outv /*LDS [KR]*/) {
+    auto scan_rows = [&](int nL, const int* L, Min2* outv /*LDS [KR]*/) {
         if (nL <= 0) return;
         const int S = NW >= nL ? NW / nL : 1;
         for (int t = wv; t < nL * S; t += NW) {
             const int r = t % nL, sidx = t / nL;
             const int x = L[r];
             const double* row = D + cidx(N, x, (int64_t)x + 1) - (x + 1);
-            MinIdx q = none;
+            Min2 q; q.v = INFINITY; q.i = -1; q.v2 = INFINITY;
             const int64_t step = (int64_t)G * S * 64;
             for (int64_t j0 = (int64_t)x + 1 + ((int64_t)g * S + sidx) * 64 + lane; j0 < n; j0 += step * 4) {
                 double v[4]; int sz[4];
@@ -628,23 +663,23 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int64_t j = j0 + u * step;
-                    if (j < n && sz[u] != 0 && v[u] < q.v) { q.v = v[u]; q.i = (int)j; }
+                    if (j < n && sz[u] != 0) min2_acc(q, v[u], (int)j);
                 }
             }
-            q = wave_min(q);
+            q = wave_min2(q);
             if (lane == 0) s_part[r][sidx] = q;
         }
         __syncthreads();
         if (tid < nL) {
-            MinIdx q = s_part[tid][0];
-            for (int k2 = 1; k2 < S; ++k2) q = better(q, s_part[tid][k2]);
+            Min2 q = s_part[tid][0];
+            for (int k2 = 1; k2 < S; ++k2) q = min2_merge(q, s_part[tid][k2]);
             outv[tid] = q;
         }
         __syncthreads();
     };
     // publish this workgroup's slot for the next round.  Every wave first drains its write-through stores (distance
     // matrix, bounds): whoever sees the slot may read them.
-    auto publish = [&](MinIdx q, Cand m, int nL, const MinIdx* rows, int row_tie = 0) {
+    auto publish = [&](Min2 q, Cand m, int nL, const Min2* rows, int row_tie = 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         ++bar;
@@ -655,11 +690,16 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
             STX<ONEX>(&sl[0], tag | (unsigned)av); STX<ONEX>(&sl[1], tag | (unsigned)(av >> 32)); STX<ONEX>(&sl[2], tag | (unsigned)m.i);
             STX<ONEX>(&sl[3], tag | (unsigned)m.y); STX<ONEX>(&sl[4], tag | (unsigned)m.fresh);
             STX<ONEX>(&sl[5], tag | (unsigned)nv); STX<ONEX>(&sl[6], tag | (unsigned)(nv >> 32)); STX<ONEX>(&sl[7], tag | (unsigned)q.i);
-            if (nL == 0) STX<ONEX>(&sl[8], tag | (unsigned)row_tie);          // rounds without refreshed rows: word 8 = "row x had a second pair at the merge height"
+            if (nL == 0) {          // rounds without refreshed rows: word 8 = "row x had a second pair at the merge height", 9-10 = second value of the NN(y) partial
+                const unsigned long long sv = (unsigned long long)__double_as_longlong(q.v2);
+                STX<ONEX>(&sl[8], tag | (unsigned)row_tie); STX<ONEX>(&sl[9], tag | (unsigned)sv); STX<ONEX>(&sl[10], tag | (unsigned)(sv >> 32));
+            }
         }
         if (tid < nL) {
-            const unsigned long long pv = (unsigned long long)__double_as_longlong(rows[tid].v);
-            STX<ONEX>(&sl[8 + 3 * tid], tag | (unsigned)pv); STX<ONEX>(&sl[9 + 3 * tid], tag | (unsigned)(pv >> 32)); STX<ONEX>(&sl[10 + 3 * tid], tag | (unsigned)rows[tid].i);
+            const unsigned long long pv = (unsigned long long)__double_as_longlong(rows[tid].v), sv = (unsigned long long)__double_as_longlong(rows[tid].v2);
+            MwGran* rw = sl + 8 + 5 * tid;
+            STX<ONEX>(&rw[0], tag | (unsigned)pv); STX<ONEX>(&rw[1], tag | (unsigned)(pv >> 32)); STX<ONEX>(&rw[2], tag | (unsigned)rows[tid].i);
+            STX<ONEX>(&rw[3], tag | (unsigned)sv); STX<ONEX>(&rw[4], tag | (unsigned)(sv >> 32));
         }
     };
     auto word_d = [&](int sl, int wd) -> double {
@@ -667,28 +707,29 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     };
     // after consume(): every WAVE folds the G slots itself -- global best, NN(y), "row x had a second pair" -- so a merge round
     // needs no LDS broadcast and no workgroup barrier here; only a retry round (refreshed rows are folded one per wave) has two
-    Cand d_best; MinIdx d_nn; int d_rowtie = 0;
-    d_best.v = INFINITY; d_best.i = -1; d_best.y = -1; d_best.fresh = 0; d_nn = none;
+    Cand d_best; Min2 d_nn; int d_rowtie = 0;
+    const Min2 none2 = {INFINITY, -1, INFINITY};
+    d_best.v = INFINITY; d_best.i = -1; d_best.y = -1; d_best.fresh = 0; d_nn = none2;
     auto digest = [&](int nLprev, const int* Lprev, int yrow, bool with_nn) {
         if (tid < G) {          // kept for pick_stale (read there behind a barrier)
             Cand c; c.v = word_d(tid, 0); c.i = (int)s_words[tid][2]; c.y = (int)s_words[tid][3]; c.fresh = (int)s_words[tid][4]; s_cand[tid] = c;
         }
         if (nLprev > 0) {
             for (int r = wv; r < nLprev; r += NW) {          // refreshed rows: one wave folds the G partial minima of a row
-                MinIdx a = none;
-                for (int u = lane; u < G; u += 64) { MinIdx pq; pq.v = word_d(u, 8 + 3 * r); pq.i = (int)s_words[u][10 + 3 * r]; a = better(a, pq); }
-                a = wave_min(a);
+                Min2 a = none2;
+                for (int u = lane; u < G; u += 64) { Min2 pq; pq.v = word_d(u, 8 + 5 * r); pq.i = (int)s_words[u][10 + 5 * r]; pq.v2 = word_d(u, 11 + 5 * r); a = min2_merge(a, pq); }
+                a = wave_min2(a);
                 if (lane == 0) s_row[r] = a;
             }
             __syncthreads();
         }
         Cand b; b.v = INFINITY; b.i = -1; b.y = -1; b.fresh = 0;
-        MinIdx a = none;
+        Min2 a = none2;
         int rt = 0;
         for (int u = lane; u < G; u += 64) {
             Cand c; c.v = word_d(u, 0); c.i = (int)s_words[u][2]; c.y = (int)s_words[u][3]; c.fresh = (int)s_words[u][4];
             b = cbetter(b, c);
-            if (with_nn) { MinIdx pq; pq.v = word_d(u, 5); pq.i = (int)s_words[u][7]; a = better(a, pq); }
+            if (with_nn) { Min2 pq; pq.v = word_d(u, 5); pq.i = (int)s_words[u][7]; pq.v2 = word_d(u, 9); a = min2_merge(a, pq); }
             if (nLprev == 0) rt |= (int)s_words[u][8];
         }
         if (lane < nLprev) {           // the rows refreshed in this round are exact now
@@ -696,15 +737,15 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
             if (c.y >= 0) b = cbetter(b, c);
         }
         d_best = wave_min_c(b);
-        if (with_nn) d_nn = wave_min(a);
+        if (with_nn) d_nn = wave_min2(a);
         d_rowtie = (nLprev == 0 && __ballot(rt != 0) != 0ull) ? 1 : 0;
         if (nLprev > 0) {
             // owners store the refreshed rows (read back only by the owner's later arg-mins)
             if (tid < nLprev && (Lprev[tid] % G) == g) {
-                const int x = Lprev[tid]; const MinIdx q = s_row[tid];
+                const int x = Lprev[tid]; const Min2 q = s_row[tid];
                 const double qv = (q.i < 0) ? (double)INFINITY : q.v;
                 const int px = pos[x / G];
-                l_nb[px] = q.i; l_md[px] = qv; l_fr[px] = 1;
+                l_nb[px] = q.i; l_md[px] = qv; l_md2[px] = (q.i < 0) ? (double)INFINITY : q.v2; l_fr[px] = 1;
                 STX<ONEX>(&nb[x], q.i); STX<ONEX>(&md[x], qv);
             }
             __syncthreads();
@@ -760,15 +801,15 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     int cnt0 = 0;
     for (int z = g + G * tid, i2 = tid; z < n; z += G * T, i2 += T) {
         act[i2] = z; pos[i2] = i2;
-        l_md[i2] = z < n - 1 ? md[z] : (double)INFINITY; l_nb[i2] = z < n - 1 ? nb[z] : -1; l_fr[i2] = 1;
+        l_md[i2] = z < n - 1 ? md[z] : (double)INFINITY; l_md2[i2] = z < n - 1 ? md2_init[z] : (double)INFINITY; l_nb[i2] = z < n - 1 ? nb[z] : -1; l_fr[i2] = 1;
     }
     if (tid == 0) { cnt0 = (n - g + G - 1) / G; if (cnt0 < 0) cnt0 = 0; s_cnt = cnt0; s_nL[0] = 0; s_nL[1] = 0; }
     __syncthreads();
     {
         Cand m0 = local_argmin(0, s_L[0]);
-        publish(none, m0, 0, s_row);
+        publish(none2, m0, 0, s_row);
     }
-    if (!consume(9)) return;
+    if (!consume(11)) return;
     digest(0, s_L[0], -1, false);
     par ^= 1;
     Cand best = d_best;
@@ -801,9 +842,9 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
             scan_rows(nL, L, s_row);
             STAMP2(0);
             Cand m = local_argmin(nL, L);
-            publish(none, m, nL, s_row);
+            publish(none2, m, nL, s_row);
             STAMP2(1);
-            if (!consume(nL > 0 ? 8 + 3 * nL : 9)) return;
+            if (!consume(nL > 0 ? 8 + 5 * nL : 11)) return;
             STAMP2(2);
             digest(nL, L, -1, false);
             par ^= 1;
@@ -818,14 +859,10 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         if (tie_stop(best.fresh)) return;
         // ---- merge (x, y) at height dist
         const int nx = nx_pre, ny = ny_pre;
-        __syncthreads();
+        // No workgroup barrier in front of the pass: the pair is in every thread's registers, the pass skips x and y by value, and x
+        // leaves its owner's active list -- and the pair's sizes change in this workgroup's private size[] -- only behind the pass
+        // (below): a slower wave may still be loading size[x] / size[y] in prefetch_pair when thread 0 gets here.
         if (tid == 0) {
-            size[x] = 0; size[y] = nx + ny;
-            if ((x % G) == g) {                               // owner drops x from its active list
-                const int p = pos[x / G], c2 = s_cnt - 1, last = act[c2];
-                act[p] = last; pos[last / G] = p; s_cnt = c2;
-                l_md[p] = l_md[c2]; l_nb[p] = l_nb[c2]; l_fr[p] = l_fr[c2];
-            }
             if (g == 0) {
                 int ix = cx_pre, iy = cy_pre;
                 if (ix > iy) { const int t = ix; ix = iy; iy = t; }
@@ -834,32 +871,31 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                 cid[y] = n + k;
             }
         }
-        __syncthreads();
         if (k == n - 2) break;
         // ---- one pass over the owned active rows: Lance-Williams update + neighbour patches (cl.cpp:361-392),
         // NN(y) partial from the fresh distances (cl.cpp:395-404), next local arg-min
         STAMP2(5);
-        MinIdx q = none;
+        Min2 q = none2;
         Cand m; m.v = INFINITY; m.i = -1; m.y = -1; m.fresh = 0;
         int row_tie = 0;
         const int cnt = s_cnt;
         int zdummy = 0;                                   // any valid row other than x and y (n >= 3 here)
         while (zdummy == x || zdummy == y) ++zdummy;
         for (int p0 = tid; p0 < cnt; p0 += T * 4) {
-            double dzx[4], dzy[4], mdz[4]; int zz[4], nbz[4], frz[4], pp[4]; int64_t izy[4];
+            double dzx[4], dzy[4], mdz[4], md2z[4]; int zz[4], nbz[4], frz[4], pp[4]; int64_t izy[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = p0 + u * T;
                 const int pc = p < cnt ? p : 0;
                 pp[u] = pc;
                 int z = p < cnt ? act[pc] : -1;
-                if (z == y) z = -1;
+                if (z == y || z == x) z = -1;
                 zz[u] = z;
                 const int zc = z >= 0 ? z : zdummy;
                 izy[u] = cidx(N, zc, y);
                 dzx[u] = LDG(&D[cidx(N, zc, x)]);
                 dzy[u] = LDG(&D[izy[u]]);
-                nbz[u] = l_nb[pc]; mdz[u] = l_md[pc]; frz[u] = l_fr[pc];
+                nbz[u] = l_nb[pc]; mdz[u] = l_md[pc]; md2z[u] = l_md2[pc]; frz[u] = l_fr[pc];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -870,39 +906,56 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                 if (z > x && dzx[u] == dist) row_tie = 1;         // row x had a second neighbour at exactly the merge height
                 double mz = (z < n - 1) ? mdz[u] : INFINITY; int nz = nbz[u], fz = frz[u];
                 if (z < y) {
-                    bool touch = false;
-                    if (z < x && nz == x) { nz = y; touch = true; }
-                    else if (nz == y) touch = true;
-                    if (nd < mz) { nz = y; mz = nd; fz = 1; l_md[pp[u]] = nd; l_nb[pp[u]] = y; l_fr[pp[u]] = 1; STX<ONEX>(&md[z], nd); STX<ONEX>(&nb[z], y); }
-                    else if (touch) { fz = (mz == nd); l_nb[pp[u]] = nz; l_fr[pp[u]] = (unsigned char)fz; STX<ONEX>(&nb[z], nz); }
-                } else if (nd < q.v || (nd == q.v && z < q.i)) { q.v = nd; q.i = z; }
+                    // row z's entries above the diagonal: x's is gone (if z < x), y's is nd now.  Invariants: mz <= every active entry of
+                    // the row (the reference's lower bound), m2 <= every active entry OTHER than the neighbour's.
+                    const double m2 = fmax(md2z[u], mz);
+                    if ((z < x && nz == x) || nz == y) {
+                        // the neighbour's entry is the one that changed (or went away: y takes over).  Exact while nd is still the row minimum.
+                        nz = y;
+                        if (nd <= m2) { mz = nd; fz = 1; } else { mz = m2; fz = 0; }
+                        l_md[pp[u]] = mz; l_md2[pp[u]] = m2; l_nb[pp[u]] = y; l_fr[pp[u]] = (unsigned char)fz; STX<ONEX>(&md[z], mz); STX<ONEX>(&nb[z], y);
+                    } else if (nd < mz) {
+                        // y becomes the neighbour; the old neighbour's entry (>= mz) joins the others, which are all >= mz
+                        l_md2[pp[u]] = mz;
+                        nz = y; mz = nd; fz = 1; l_md[pp[u]] = nd; l_nb[pp[u]] = y; l_fr[pp[u]] = 1; STX<ONEX>(&md[z], nd); STX<ONEX>(&nb[z], y);
+                    } else if (nd < m2) l_md2[pp[u]] = nd;
+                } else if (nd < q.v || (nd == q.v && z < q.i)) { q.v2 = q.v; q.v = nd; q.i = z; }
+                else if (nd < q.v2) q.v2 = nd;
                 if (z < n - 1) cand_acc(m, mz, z, nz, fz);
             }
         }
         STAMP2(6);
         block_min_qc(q, m, sh, shc, NW);
         row_tie = __syncthreads_or(row_tie);
+        if (tid == 0) { size[x] = 0; size[y] = nx + ny; }     // (every thread is past the pass and has used the old sizes)
+        if (tid == 0 && (x % G) == g) {                       // owner drops x from its active list
+            const int p = pos[x / G], c2 = s_cnt - 1, last = act[c2];
+            act[p] = last; pos[last / G] = p; s_cnt = c2;
+            l_md[p] = l_md[c2]; l_md2[p] = l_md2[c2]; l_nb[p] = l_nb[c2]; l_fr[p] = l_fr[c2];
+        }
         publish(q, m, 0, s_row, row_tie);
         STAMP2(7);
-        if (!consume(9)) return;
+        if (!consume(11)) return;
         STAMP2(2);
         digest(0, s_L[lp], y, true);
         STAMP2(3);
         par ^= 1;
         if (d_rowtie) { if (g == 0 && tid == 0) sync[5] = 1; return; }
         best = d_best;
-        const MinIdx nn = d_nn;
+        const Min2 nn = d_nn;
         // row y: exact by construction when it has an active neighbour above (cl.cpp:395-404), else its old (stale) bound
         Cand cy; cy.i = -1; cy.v = INFINITY; cy.y = -1; cy.fresh = 0;
         if (y < n - 1) {
             if (nn.i >= 0) {
                 cy.v = nn.v; cy.i = y; cy.y = nn.i; cy.fresh = 1;
-                if (tid == 0 && (y % G) == g) { const int py = pos[y / G]; l_nb[py] = nn.i; l_md[py] = nn.v; l_fr[py] = 1; STX<ONEX>(&nb[y], nn.i); STX<ONEX>(&md[y], nn.v); }
+                // (lane 0 of EVERY wave writes the same values: the next pass starts without a workgroup barrier, and a wave reads LDS behind its own writes)
+                if (lane == 0 && (y % G) == g) { const int py = pos[y / G]; l_nb[py] = nn.i; l_md[py] = nn.v; l_md2[py] = nn.v2; l_fr[py] = 1; if (tid == 0) { STX<ONEX>(&nb[y], nn.i); STX<ONEX>(&md[y], nn.v); } }
             } else {
                 cy.v = LDG(&md[y]); cy.i = y; cy.y = LDG(&nb[y]); cy.fresh = 0;
-                if (tid == 0 && (y % G) == g) l_fr[pos[y / G]] = 0;
+                if (lane == 0 && (y % G) == g) l_fr[pos[y / G]] = 0;
             }
             best = cbetter(best, cy);
+            __builtin_amdgcn_wave_barrier();       // keep the LDS stores above in front of the next pass's LDS loads in the instruction stream
         }
         lp ^= 1;
         if (!((best.fresh & 1) && best.y >= 0)) pick_stale(cy, lp);
@@ -955,7 +1008,7 @@ __global__ void k_fill_i32(int* p, int v, int64_t n, int iota)
 //   above: k_linkage_mw on G co-resident workgroups (cooperative launch: the runtime guarantees residency or refuses).  It
 //   takes a merge from its parallel arg-min only while the closest pair is unique; at the first exact tie (duplicate
 //   embeddings), on a refused launch or on a poll timeout the distance matrix is rebuilt and k_linkage_heap does the job.
-static int linkage_prepare(sd_ctx* c, const double* d_X, int64_t N, int d, double* D, int* size, int* cid, int* nb, double* md)
+static int linkage_prepare(sd_ctx* c, const double* d_X, int64_t N, int d, double* D, int* size, int* cid, int* nb, double* md, double* md2)
 {
     const int64_t m = N * (N - 1) / 2;
     const int tiles = (int)((N + PT - 1) / PT);
@@ -969,7 +1022,7 @@ static int linkage_prepare(sd_ctx* c, const double* d_X, int64_t N, int d, doubl
     KCHECK(c);
     {
         ProfScope ps(c, "row_nn", 0, (double)m * 8.0);
-        hipLaunchKernelGGL(k_row_nn, dim3((unsigned)((N - 1 + 3) / 4)), dim3(256), 0, c->stream, D, N, nb, md);
+        hipLaunchKernelGGL(k_row_nn, dim3((unsigned)((N - 1 + 3) / 4)), dim3(256), 0, c->stream, D, N, nb, md, md2);
         KCHECK(c);
     }
     return SD_OK;
@@ -1000,8 +1053,9 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     WS(c, int, cid, "cl_cid", N);
     WS(c, int, nb, "cl_nb", N);
     WS(c, double, md, "cl_md", N);
+    WS(c, double, md2, "cl_md2", N);
     int rc;
-    if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md))) return rc;
+    if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2))) return rc;
     int G = (int)c->linkage_wgs;
     // auto geometry (measured on clustered data, profiles/r01_linkage_scaling.txt, r02_linkage_stamps.txt): up to N = 30 000 the
     // one-XCD form with one workgroup on each of the XCD's 32 CUs (172 ms at N = 12 602; all XCDs: 188 ms with 64 x 512)
@@ -1010,10 +1064,10 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     if (G < 0) G = N >= 60000 ? 128 : N >= 8000 ? 64 : N >= 1500 ? 32 : 0;
     if (G > c->num_cu) G = c->num_cu;
     int TH = (int)c->linkage_threads;
-    if (TH <= 0) TH = (N >= 8000 || auto_onex) ? 512 : 256;           // measured: 188 vs 195 ms at N = 12 602, 327 vs 337 ms at N = 21 573, 4.68 vs 4.85 s at N = 172 773
-    TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : 256;
+    if (TH <= 0) TH = auto_onex ? 256 : N >= 8000 ? 512 : 256;        // measured (r03, two-level bounds): one XCD 32 x 256 75 ms, x 512 84 ms at N = 12 602; all XCDs 128 x 512 1.26 s at N = 100 174
+    TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : TH >= 256 ? 256 : 128;
     if (G <= 1) return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
-    if ((N + G - 1) / G > 4000) G = (int)((N + 3999) / 4000);      // active-row lists and bounds live in LDS: 24 B per owned row
+    if ((N + G - 1) / G > 3000) G = (int)((N + 2999) / 3000);      // active-row lists and bounds live in LDS: 32 B per owned row
     if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
     int cap = (int)((N + G - 1) / G) + 1;
     // one-XCD form while two workgroups per CU of one XCD (32 CUs) can hold the job; above, all XCDs' memory pipelines are worth more
@@ -1029,19 +1083,19 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     {
         ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
         int n_i = (int)N;
-        void* args[] = {&D, &n_i, &size_all, &cid, &nb, &md, &d_Z, &gran, &sync, &cap, &G};
+        void* args[] = {&D, &n_i, &size_all, &cid, &nb, &md, &md2, &d_Z, &gran, &sync, &cap, &G};
         // cooperative launch: all workgroups are resident together, or the launch is refused (they poll each other's slots)
         hipError_t le = hipErrorUnknown;
-        if ((size_t)cap * 24 > 48 * 1024) {          // the row lists of a hand-set geometry may pass the default dynamic-LDS limit
-            (void)hipFuncSetAttribute((const void*)k_linkage_mw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 24);
-            (void)hipFuncSetAttribute((const void*)k_linkage_mw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 24);
+        if ((size_t)cap * 32 > 48 * 1024) {          // the row lists of a hand-set geometry may pass the default dynamic-LDS limit
+            (void)hipFuncSetAttribute((const void*)k_linkage_mw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 32);
+            (void)hipFuncSetAttribute((const void*)k_linkage_mw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 32);
             (void)hipGetLastError();
         }
         if (onex) {
-            le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<true>, dim3(8 * G), dim3(TH), args, (size_t)cap * 24, c->stream);
+            le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<true>, dim3(8 * G), dim3(TH), args, (size_t)cap * 32, c->stream);
             if (le != hipSuccess) { (void)hipGetLastError(); onex = false; }
         }
-        if (!onex) le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<false>, dim3(G), dim3(TH), args, (size_t)cap * 24, c->stream);
+        if (!onex) le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<false>, dim3(G), dim3(TH), args, (size_t)cap * 32, c->stream);
         if (le != hipSuccess) { (void)hipGetLastError(); why = "cooperative launch refused"; }
     }
     unsigned h[16] = {0};
@@ -1065,7 +1119,7 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     if (!why) return SD_OK;
     c->stats["linkage_fallbacks"].launches += 1;
     if (c->profile_detail) fprintf(stderr, "linkage: %s at N = %lld -> k_linkage_heap\n", why, (long long)N);
-    if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md))) return rc;
+    if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2))) return rc;
     return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
 }
 

@@ -20,6 +20,9 @@ N = len(X)
 d = sdhip.Diarizer(None, None)
 d.set_option("profile", 1)
 Z0 = None
+if os.environ.get("REF"):          # REF=1: the single-workgroup kernel that replays the reference's heap (bit-identical to the oracle) is the yardstick
+    d.set_option("linkage_wgs", 0)
+    t0 = time.time(); Z0 = d.linkage(X); print("k_linkage_heap reference: %.1f s" % (time.time() - t0), flush=True)
 onex = int(os.environ.get("ONEX", "1"))
 d.set_option("linkage_one_xcd", onex)
 print("linkage_one_xcd", onex)
