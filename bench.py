@@ -76,17 +76,31 @@ def cpu_baseline(ws, we, seconds, planted, threads=None):
             "turns": len(turns)}
 
 
-def rank0_share_estimate(world, hours_per_gpu):
-    """share of the chunks for rank 0 such that its finalize + inference takes as long as the other ranks' inference.
-    Stage rates measured on MI355X on the planted workload (profiles/r02_*): inference ~1.36 s per hour of audio (f32), finalize ~0.18 s
-    at 1 h growing ~ h^1.3 (linkage).  A wrong estimate only unbalances the ranks."""
-    if world == 1:
-        return 1.0
-    total_h = world * hours_per_gpu
-    t_inf = 1.36 * total_h
-    t_fin = 0.18 * total_h ** 1.3 + 0.02
-    s0 = (t_inf - (world - 1) * t_fin) / world              # s0 + t_fin == (t_inf - s0) / (world - 1)
-    return max(0.0, min(1.0 / world, s0 / t_inf))
+def union_chunk_range(plan, n_total, world, rank, C):
+    """chunks rank `rank` can be given under any rank-0 share between 0 and 1 / world (plan = sdhip.shard_plan): the hull of its ranges
+    under the two extreme plans, widened by 32 * (world + 1) chunks: every range starts on a multiple of 32 chunks and the per-rank share
+    is rounded up to one, so rank r's bounds wander by up to 32 r chunks between neighbouring shares"""
+    lo_u, hi_u = None, None
+    for pm in (0, int(round(1000.0 / world))):
+        _, rg = plan(n_total, world, pm)
+        l, h = rg[rank]
+        if h > l:
+            lo_u = l if lo_u is None else min(lo_u, l)
+            hi_u = h if hi_u is None else max(hi_u, h)
+    if lo_u is None:
+        return 0, 0
+    return max(0, lo_u - 32 * (world + 1)), min(C, hi_u + 32 * (world + 1))
+
+
+def balanced_rank0_permille(infer_ms, chunks, finalize_ms, C, world):
+    """rank-0 share (per mille of the chunks) at which rank 0's inference + finalize takes as long as another rank's inference.
+    infer_ms[r] / chunks[r]: inference time and chunk count of rank r in a measured job; finalize_ms: rank 0's count + clustering +
+    reconstruction of the whole job.  With T = inference of all C chunks on one rank: s0 * T + F = (1 - s0) * T / (world - 1)."""
+    rate = sum(infer_ms) / max(sum(chunks), 1.0)
+    T = rate * C
+    s0 = (1.0 - (world - 1) * finalize_ms / max(T, 1e-9)) / world
+    s0 = max(0.0, min(1.0 / world, s0))
+    return int(round(1000 * s0)), rate
 
 
 def self_launch(n):
@@ -175,9 +189,11 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="f32 = the measured configuration (f32 MFMA); f16 = "
                     "BASELINE configs[4]: ECAPA conv layers on the fp16 MFMA with f32 accumulation (secondary, tolerance-checked mode)")
     ap.add_argument("--rank0-share", type=float, default=-1.0, help="fraction of the chunks rank 0 infers itself (it also finalizes: count / "
-                    "clustering / reconstruction).  The other ranks return from the sharded call as soon as their all-gather is queued, so rank 0's "
-                    "finalize(k) overlaps their inference(k+1); a smaller rank-0 share balances the two. -1 = from the measured stage rates "
-                    "(rank0_share_estimate), 1/N = equal shares, 0 = rank 0 only finalizes")
+                    "clustering / reconstruction).  The other ranks return from the sharded call once the exchange is done, so rank 0's "
+                    "finalize(k) overlaps their inference(k+1); a smaller rank-0 share balances the two. -1 = measured: the warm-up job runs with equal "
+                    "shares and its stage times give the balance point; 1/N = equal shares, 0 = rank 0 only finalizes")
+    ap.add_argument("--fp16-steps", type=int, default=3, help="N = 1, f32 run: also time this many steps in fp16 mode (BASELINE configs[4]) and put them, with the "
+                    "cosine distances of the fp16 embeddings to the f32 ones, into the `fp16` object of the result line (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL communicator inside the library, "
                     "all-gather, assembly) even with one rank")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (sd_set_option), e.g. emb_batch_items=1536; tuning only")
@@ -211,7 +227,8 @@ def main():
         # RCCL all-gather inside libsdhip.so
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
         import torch.distributed as dist
-        dist.init_process_group("gloo")
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))      # a rank that dies must not leave the others waiting for half an hour
 
     import sdhip
     import synth
@@ -226,12 +243,21 @@ def main():
     per_samples = int(round(a.hours_per_gpu * HOUR * SR))
     n_total = per_samples * world
     C, _ = sdhip.num_chunks(n_total)
-    share0 = a.rank0_share if a.rank0_share >= 0 else rank0_share_estimate(world, a.hours_per_gpu)
-    permille = int(round(1000 * share0)) if world > 1 else -1
+    # rank 0 also finalizes (count / clustering / reconstruction), so it is given a smaller share of the chunks.  The share is not a
+    # constant of this script: the first warm-up job runs with equal shares, its stage times (every rank's inference, rank 0's finalize)
+    # give the share that balances rank 0's inference + finalize against the others' inference, and the plan is changed before the
+    # timed region.  Every rank therefore synthesises the chunks it can be given under ANY share between 0 and 1 / N.
+    permille = -1
+    if world > 1:
+        permille = int(round(1000 * a.rank0_share)) if a.rank0_share >= 0 else int(round(1000.0 / world))
     per, ranges = sdhip.shard_plan(n_total, world, permille)
-    lo, hi = ranges[rank]
+    lo_u, hi_u = ranges[rank]
+    if world > 1 and a.rank0_share < 0:
+        ul, uh = union_chunk_range(sdhip.shard_plan, n_total, world, rank, C)
+        lo_u, hi_u = min(lo_u, ul), max(hi_u, uh)
+    lo, hi = lo_u, hi_u                       # chunks this rank holds samples and planted outputs for
     first, need_hi = sdhip.shard_sample_range(lo, hi, n_total)
-    # synthesise only what this rank reads: its own hour(s) + the 72 000-sample halo of the next one
+    # synthesise only what this rank can read: its own hour(s) + the 72 000-sample halo of the next one
     pieces, turns_sched, pos = [], [], first
     h_lo, h_hi = first // per_samples, max(first, need_hi - 1) // per_samples
     for h in range(h_lo, min(h_hi, world - 1) + 1):
@@ -273,12 +299,13 @@ def main():
             dist.broadcast_object_list(ident, src=0)
         d.set_option("rank0_permille", permille)
         d.comm_init(ident[0], rank, world)
+    my_lo, my_hi = ranges[rank]                # the rank's chunk range under the plan in force
 
     turns_box = [None]
 
     def step():
         if use_dist:
-            t = d.diarize_sharded_dev(d_pcm.data_ptr(), first, int(d_pcm.numel()) if hi > lo else 0, n_total)
+            t = d.diarize_sharded_dev(d_pcm.data_ptr() if hi > lo else 0, first, int(d_pcm.numel()) if hi > lo else 0, n_total)
             if rank == 0:
                 turns_box[0] = t
         else:
@@ -293,6 +320,30 @@ def main():
     step()
     fence()
     cold_ms = (time.perf_counter() - t_cold) * 1e3
+    share_note = None
+    if world > 1 and a.rank0_share < 0:
+        # the balance point from the job that just ran (equal shares): rank 0 spends s0 * T + F, the others (1 - s0) * T / (N - 1), where
+        # T = inference time of the whole recording on one rank and F = finalize; equal at s0 = (1 - (N - 1) * F / T) / N
+        step()                                   # a warm job with the equal shares: its stage times are the measurement
+        fence()
+        st = d.stage_ms()
+        mine = torch.tensor([st[0] + st[1], st[2] if rank == 0 else 0.0, float(my_hi - my_lo)], dtype=torch.float64)
+        allv = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        pm_new, rate = balanced_rank0_permille([float(v[0]) for v in allv], [float(v[2]) for v in allv], float(allv[0][1]), C, world)
+        per_new, ranges_new = sdhip.shard_plan(n_total, world, pm_new)
+        fits = torch.tensor([1.0 if (ranges_new[rank][1] <= ranges_new[rank][0] or (lo <= ranges_new[rank][0] and ranges_new[rank][1] <= hi)) else 0.0], dtype=torch.float64)
+        dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+        if float(fits.item()) > 0.5:
+            permille, per, ranges = pm_new, per_new, ranges_new
+            my_lo, my_hi = ranges[rank]
+            d.set_option("rank0_permille", permille)
+            share_note = ("measured on a warm job with equal shares: inference %.3f ms per chunk and rank, finalize %.1f ms -> rank 0 infers %.1f %% of the chunks"
+                          % (rate, float(allv[0][1]), permille / 10.0))
+            step()
+            fence()
+        else:
+            share_note = "balanced share %d per mille needs chunks outside what a rank synthesised: equal shares kept" % pm_new
     for _ in range(max(0, a.warmup - 1)):
         step()
     d.set_option("profile", 1)
@@ -323,8 +374,14 @@ def main():
         if s["launches"] == 0:
             continue
         extra[k] = {"ms_per_step": round(s["ms"] / max(a.steps, 1), 3), "launches_per_step": s["launches"] // max(a.steps, 1)}
-        if k == "stft_mel" and s["ms"] > 0:       # front end (north star: HBM GB/s for the STFT): algorithmic bytes of SURVEY 8(d), 481 492 B per live item
-            extra[k].update({"hbm_GBps_algorithmic": round(s["bytes"] / s["ms"] / 1e6, 1), "hbm_frac_of_8TBps": round(s["bytes"] / s["ms"] / 1e6 / 8000.0, 4)})
+        if k == "stft_mel" and s["ms"] > 0:
+            # front end (north star: HBM GB/s for the STFT).  Bytes = what the launch really touches by SURVEY 8(d)'s rule: the selected samples of the live
+            # items + their mask rows read, the stored frames x 96 floats written (a partial item reads fewer than 80 000 samples and stores fewer than 501
+            # rows).  The kernel is not HBM-bound: it is bound by VALU issue on the fp64 FFT the reference's precision asks for (1.9 G VALU
+            # wave-instructions per launch = more than 43 % of the chip's VALU issue slots for its whole duration).
+            extra[k].update({"hbm_GBps_algorithmic": round(s["bytes"] / s["ms"] / 1e6, 1), "hbm_frac_of_8TBps": round(s["bytes"] / s["ms"] / 1e6 / 8000.0, 4),
+                             "algorithmic_MB_per_launch": round(s["bytes"] / max(s["launches"], 1) / 1e6, 1), "GFLOPs_fft_fp64_plus_mel_f32": round(s["flops"] / s["ms"] / 1e6, 1),
+                             "bound": "fp64 VALU issue, not HBM"})
     kst = d.kernel_stats("clusters_K")
 
     # ---- one job at a time (no overlap between consecutive jobs): the latency a single recording sees on N GPUs
@@ -347,6 +404,59 @@ def main():
     else:
         live_total = live_local
 
+    # ---- N = 1 extras: the same job handed over as HOST PCM (sd_diarize: H2D copy inside the call), the cold first job, and the fp16 mode
+    extra_lines = {}
+    turns = turns_box[0] or []
+    if world == 1 and not use_dist:
+        d.set_option("profile", 0)
+        ts = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            th = d.diarize(pcm_host[:n_total])
+            ts.append(time.perf_counter() - t1)
+        extra_lines["value_host_pcm"] = {"value": round(audio_s / min(ts), 2), "ms": round(min(ts) * 1e3, 2), "same_turns": th == turns_box[0],
+                                         "what": "sd_diarize: int16 PCM in pageable host memory, the 2 * n byte H2D copy and its buffer inside the timed call"}
+        extra_lines["value_cold"] = {"value": round(audio_s / (cold_ms / 1e3), 2), "ms": round(cold_ms, 1),
+                                     "what": "what a one-shot user of the CLI sees: sd_create + PCM upload + first job with cold workspaces"}
+        if a.precision == "f32" and a.fp16_steps > 0:
+            d.set_option("ecapa_precision", 1)
+            d.set_option("profile", 1)
+            step()
+            d.reset_stats()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(a.fp16_steps):
+                step()
+            fence()
+            ms16 = (time.perf_counter() - t1) / a.fp16_steps * 1e3
+            turns16 = turns_box[0]
+            w16, all16 = d.kernel_stats("conv_w256_f16"), d.kernel_stats("conv_gemm_f16")
+            d.set_option("profile", 0)
+            cosd = None
+            if planted:
+                # accuracy on the REAL embeddings (the planted ones replace them in the timed jobs): scores planted, embeddings kept
+                d.set_planted(d_ps.data_ptr(), 0, lo, hi - lo)
+                step()
+                e16 = d.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192).astype(np.float64)
+                d.set_option("ecapa_precision", 0)
+                step()
+                e32 = d.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192).astype(np.float64)
+                d.set_planted(d_ps.data_ptr(), d_pe.data_ptr(), lo, hi - lo)
+                lv = ~np.isnan(e32[:, 0])
+                same_nan = bool(np.array_equal(np.isnan(e16[:, 0]), ~lv))
+                cd = 1.0 - (e16[lv] * e32[lv]).sum(1) / np.linalg.norm(e16[lv], axis=1) / np.linalg.norm(e32[lv], axis=1)
+                cosd = {"items": int(lv.sum()), "max": float("%.3g" % cd.max()), "q99": float("%.3g" % np.quantile(cd, 0.99)), "median": float("%.3g" % np.median(cd)),
+                        "above_1e-3": int((cd > 1e-3).sum()), "same_nan_rows": same_nan}
+            d.set_option("ecapa_precision", 0)
+            extra_lines["fp16"] = {"what": "BASELINE configs[4]: the same job with the per-frame ECAPA layers on the fp16 MFMA (fp16 weights and activations, f32 accumulation); "
+                                           "secondary mode, never the headline value",
+                                   "value": round(audio_s / (ms16 / 1e3), 2), "ms_per_step": round(ms16, 2), "steps": a.fp16_steps, "same_turns_as_f32": turns16 == turns,
+                                   "roofline": {"bound": "mfma", "kernel": "k_conv_gemm_w256<true> (v_mfma_f32_32x32x16_f16)", "achieved": round(w16["flops"] / max(w16["ms"], 1e-9) / 1e9, 1),
+                                                "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(w16["flops"] / max(w16["ms"], 1e-9) / 1e9 / F16_MFMA_PEAK_TFLOPS, 4),
+                                                "all_fp16_conv_launches_TFLOPs": round(all16["flops"] / max(all16["ms"], 1e-9) / 1e9, 1)},
+                                   "cosine_distance_to_f32_embeddings": cosd}
+
     if rank == 0:
         ach = cg["flops"] / max(cg["ms"], 1e-9) / 1e9      # TFLOP/s
         peak = F32_MFMA_PEAK_TFLOPS if a.precision == "f32" else F16_MFMA_PEAK_TFLOPS
@@ -368,7 +478,6 @@ def main():
                                 "current_blob": cur, "recorded_workload": pj.get("workload", "raw"), "recorded_hours_per_gpu": pj.get("hours_per_gpu", 1.0)}
             except Exception:
                 pass
-        turns = turns_box[0] or []
         out = {
             "metric": "real-time factor (audio-sec/wall-sec), %g h 16 kHz mono per GPU" % a.hours_per_gpu,
             "value": round(audio_s / (ms_per_step / 1e3), 2),
@@ -421,6 +530,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ws, we, a.cpu_seconds, planted)
         else:
             out["cpu_baseline"] = None
+        out["config"]["rank0_share"] = share_note
+        out.update(extra_lines)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)          # the JSON line stays the last thing on stdout: whatever a library printf()s at teardown goes to stderr
     d.close()

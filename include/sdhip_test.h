@@ -26,6 +26,9 @@ int sd_set_planted(sd_ctx*, const float* d_scores, const float* d_emb, int64_t c
  * (option "profile" = 1), with the algorithmic FLOPs / bytes the launcher bills them. */
 int sd_kernel_stats(const sd_ctx*, const char* kernel, double* total_ms, int64_t* launches, double* flops, double* bytes);
 void sd_reset_stats(sd_ctx*);
+/* copy `bytes` of the library's named device workspace (from byte `offset`) to the host: intermediate activations for the precision
+ * diagnostics under tools/ ("ec_x0", "ec_cat", "ec_mfa", "ec_pooled", ...) */
+int sd_debug_read_ws(sd_ctx*, const char* name, int64_t offset, void* h_out, int64_t bytes);
 /* test / tuning keys of sd_set_option (defaults are the measured optimum; results do not depend on the tuning keys):
  * "profile", "emb_batch_items", "seg_batch_chunks", "linkage_wgs" (-1 auto, 0 one workgroup), "linkage_threads", "linkage_one_xcd",
  * "skip_dead_rows", "virtual_world" (test mode: a communicator of ONE rank plays all W ranks of the plan in turn, slot by slot, so plan +

@@ -76,6 +76,17 @@ extern "C" int sd_kernel_stats(const sd_ctx* cc, const char* kernel, double* tot
     if (total_ms) *total_ms = s.ms; if (launches) *launches = s.launches; if (flops) *flops = s.flops; if (bytes) *bytes = s.bytes;
     return SD_OK;
 }
+// test hook: copy `bytes` of the named workspace (from `offset`) to the host -- intermediate activations for the precision diagnostics of tools/
+extern "C" int sd_debug_read_ws(sd_ctx* c, const char* name, int64_t offset, void* h_out, int64_t bytes)
+{
+    if (!c || !name || !h_out || offset < 0 || bytes < 0) return SD_ERR_ARG;
+    auto it = c->ws.find(name);
+    if (it == c->ws.end() || !it->second.p) SD_FAIL(c, SD_ERR_ARG, "no workspace named %s", name);
+    if ((size_t)(offset + bytes) > it->second.cap) SD_FAIL(c, SD_ERR_ARG, "workspace %s holds %zu bytes", name, it->second.cap);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h_out, (const char*)it->second.p + offset, (size_t)bytes, hipMemcpyDeviceToHost));
+    return SD_OK;
+}
 extern "C" void sd_reset_stats(sd_ctx* c) { if (!c) return; (void)hipStreamSynchronize(c->stream); sd_flush_profile(c); c->stats.clear(); }
 extern "C" int sd_stage_ms(const sd_ctx* c, double* ms4) { if (!c || !ms4) return SD_ERR_ARG; for (int i = 0; i < 4; ++i) ms4[i] = c->stage_ms[i]; return SD_OK; }
 extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
@@ -95,7 +106,9 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "seg_shared_conv0") c->seg_shared_conv0 = v != 0;
     else if (k == "conv_w256_kmin") c->conv_w256_kmin = (int)v;
     else if (k == "conv_pn128") c->conv_pn128 = (int)v;
-    else if (k == "ecapa_precision") { if (v != 0 && v != 1) SD_FAIL(c, SD_ERR_ARG, "ecapa_precision must be 0 (f32) or 1 (f16)"); c->ecapa_precision = (int)v; }
+    else if (k == "ecapa_precision") { if (v < 0 || v > 2) SD_FAIL(c, SD_ERR_ARG, "ecapa_precision must be 0 (f32), 1 (fp16) or 2 (fp16, hi + lo weight planes)"); c->ecapa_precision = (int)v; }
+    else if (k == "ecapa_f16_hp") c->ecapa_f16_hp = (int)v;
+    else if (k == "ecapa_keep_cat") c->ecapa_keep_cat = v != 0;
     else if (k == "rank0_permille") c->rank0_permille = (int)v;
     else if (k == "virtual_world") c->virtual_world = (int)v;
     else if (k == "comm_timeout_ms") c->comm_timeout_ms = v;

@@ -67,6 +67,7 @@ struct ConvArgs {
     const int2* rowtab;
     int in_rows;
     int y_f32;             // fp16 mode: Y is float all the same (the attention logits feed an exp)
+    int kt_real;           // fp16 split-weight mode: KT counts 2 * kt_real weight planes (hi, then lo) and tap kk shifts the rows like tap kk % kt_real; 0 = KT
     int prec;              // 0 = f32 (X, X2, W, Y are float), 1 = fp16 end to end (X, X2, W16, Y are _Float16; option ecapa_precision)
 };
 #define ROWTAB_T(y) ((y) & 1023)
@@ -115,7 +116,9 @@ struct sd_ctx {
     int64_t emb_batch_items = 768;             // multiple of 96
     int64_t seg_batch_chunks = 4096;           // 128 LSTM workgroups per direction: one full wave of CUs
     int num_clusters = -1, min_clusters = -1, max_clusters = -1;   // optional constraints for the whole-path entry points
-    int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation
+    int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation, 2 = the same with hi + lo fp16 weight planes
+    bool ecapa_keep_cat = false;                // diagnostics: f32 mode keeps the block outputs (the logits get their own buffer)
+    int ecapa_f16_hp = 0;                       // fp16 mode: bit 0 = MFA output / pooling inputs in f32, bit 1 = attention branch on the f32 MFMA
     bool conv_w256_f32 = true;                  // f32: the same 256 x 256 kernel for the wide, long-K ECAPA layers (TDNN, MFA)
     int conv_pn128 = 0;                         // 128 x 128 kernel: column tiles per super-block (0 = 8); tuning
     int ecapa_ld_pad = 0;                       // elements added to the leading dimensions of the ECAPA activation buffers (multiple of 8)
@@ -131,6 +134,7 @@ struct sd_ctx {
     int num_cu = 256;
     bool constrained_assignment = false;        // Clustering.py:81-94 (one cluster per local speaker of a chunk)
     std::vector<double> last_conf;               // per-turn confidence of the last finalize (sd_last_confidence)
+    int64_t fe_bill_samples = -1, fe_bill_frames = 0;   // profiling: selected samples / stored frames of the next k_stft_fbank launch (-1 = unknown)
     int64_t wav_origin = 0;                     // recording position of d_wav[0] for the current call (sharded entry points hold a slice)
     void* comm = nullptr;                       // ncclComm_t (comm.cpp), null = single GPU
     int rank = 0, world = 1;

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     constexpr int BKE = 128 / ES;       // elements per K-step: 128 bytes per row either way
     const int kcs = a.Cin / BKE;
     const int S = a.KT * kcs;
-    const int half = a.KT / 2;
+    const int ktr = a.kt_real > 0 ? a.kt_real : a.KT;      // taps that shift rows (split-weight mode: KT = 2 * ktr planes)
+    const int half = ktr / 2;
 
     // ---- load stream state (runs one K-step ahead of the compute stream) ----
     // All global reads are buffer loads: a per-tile resource descriptor in SGPRs, a per-lane byte offset that only
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         for (int p = 0; p < 4; ++p) {
             int qr;
             if (a.pad_mode == 0) {
-                qr = tt[p] + (kk - half) * a.dil;
+                qr = tt[p] + ((kk >= ktr ? kk - ktr : kk) - half) * a.dil;
                 if (qr < 0) qr = -qr;
                 if (qr >= a.Tin) qr = 2 * (a.Tin - 1) - qr;
                 if (qr < 0) qr = 0;
@@ -574,7 +575,8 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     const double rows = a.rowtab ? (double)a.M
                                  : (double)(a.M / a.TpOut) * a.T + (double)((a.M % a.TpOut) < a.T ? (a.M % a.TpOut) : a.T);
     const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
-    const double flops = 2.0 * rows * a.Cout * cin * a.KT;
+    const int kt_alg = a.kt_real > 0 ? a.kt_real : a.KT;          // algorithmic taps (the lo planes of the split-weight mode are overhead, not work)
+    const double flops = 2.0 * rows * a.Cout * cin * kt_alg;
     const double bytes = (f16 ? 2.0 : 4.0) * (rows * cin * (a.X2 ? 2 : 1) + rows * a.Cout + (double)a.Cout * cin * a.KT);
     ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
     ProfScope ps16(c, f16 ? "conv_gemm_f16" : "conv_gemm_f32", flops, bytes);        // per precision (bench: roofline of the fp16 instantiations alone)

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
 
     const int kcs = a.Cin / (128 / ES);
     const int S = a.KT * kcs;
-    const int half = a.KT / 2;
+    const int ktr = a.kt_real > 0 ? a.kt_real : a.KT;      // taps that shift rows (split-weight mode: KT = 2 * ktr planes)
+    const int half = ktr / 2;
     const size_t in_rows = (size_t)(a.in_rows > 0 ? a.in_rows : a.M);
 
     int rrel[4], tt[4], nd[4];
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
     auto set_tap = [&](int kk) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            int qr = tt[p] + (kk - half) * a.dil;
+            int qr = tt[p] + ((kk >= ktr ? kk - ktr : kk) - half) * a.dil;
             if (qr < 0) qr = -qr;
             if (qr >= a.Tin) qr = 2 * (a.Tin - 1) - qr;
             if (qr < 0) qr = 0;
@@ -336,7 +337,7 @@ int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& in, const char* tag)
         a.Cin % (h ? 64 : 32) != 0 || a.M < 8 * HM) return 1;
     // fp16: the shortest contraction (ASP conv, K = 128) stays on the 128 x 128 form (measured); f32 takes every wide layer since the
     // K-groups are pinned (block0 K = 400: 92 -> 102 TF, ASP conv K = 128: 95 -> 105 TF)
-    if ((int64_t)a.Cin * a.KT < (c->conv_w256_kmin > 0 ? c->conv_w256_kmin : (h ? 256 : 128))) return 1;
+    if ((int64_t)a.Cin * (a.kt_real > 0 ? a.kt_real : a.KT) < (c->conv_w256_kmin > 0 ? c->conv_w256_kmin : (h ? 256 : 128))) return 1;
     static bool attr_set = false;
     const size_t lds_bytes = (size_t)2 * (HM + HN) * HLDP * sizeof(float);
     if (!attr_set) {
@@ -353,7 +354,7 @@ int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& in, const char* tag)
     const int lx_max = ((a.m_tiles + 7) / 8) * a.n_tiles;
     if (grid / 8 > lx_max) grid = lx_max * 8;
     const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
-    const double flops = 2.0 * (double)a.M * a.Cout * cin * a.KT;
+    const double flops = 2.0 * (double)a.M * a.Cout * cin * (a.kt_real > 0 ? a.kt_real : a.KT);
     const double bytes = (h ? 2.0 : 4.0) * ((double)a.M * cin + (double)a.M * a.Cout + (double)a.Cout * cin * a.KT);
     {
         ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);

@@ -158,6 +158,14 @@ __global__ void k_feats_to_half(const float* __restrict__ f, _Float16* __restric
     h[idx] = (_Float16)(c < SD_FEAT_LD ? f[row * SD_FEAT_LD + c] : 0.0f);
 }
 
+// [rows][ld] f32 -> halves, same leading dimension (fp16 mode: the MFA output is kept in f32 for the pooling statistics and rounded once for the attention's MFMA)
+__global__ void k_rows_to_half(const float* __restrict__ f, _Float16* __restrict__ h, int64_t n4)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    st4(h + idx * 4, *(const float4*)(f + idx * 4));
+}
+
 // prec 0: f32 MFMA, float buffers.  prec 1 (ecapa_precision): fp16 MFMA, _Float16 buffers (X / Y leading dimensions in elements)
 static ConvArgs conv_args(const ConvLayer& L, const void* X, int x_ld, void* Y, int y_ld, int64_t M, bool per_item, int prec = 0)
 {
@@ -170,7 +178,8 @@ static ConvArgs conv_args(const ConvLayer& L, const void* X, int x_ld, void* Y, 
     else { a.TpIn = a.TpOut = (int)M; a.Tin = a.T = (int)M; }
     a.Cin = prec ? L.CinPad16 : L.CinPad; a.cin_real = L.Cin; a.Cout = L.Cout; a.KT = L.KT; a.dil = L.dil;
     a.w_ld = a.Cin;
-    a.pad_mode = 0; a.prec = prec;
+    a.pad_mode = 0; a.prec = prec ? 1 : 0;
+    if (prec == 2) { a.kt_real = L.KT; a.KT = 2 * L.KT; }       // hi + lo weight planes (weights.cpp)
     return a;
 }
 
@@ -199,7 +208,7 @@ int ecapa_need_rows(int nvalid, bool skip_dead_rows) { return ec_space_rows(nval
 template <class T>
 static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_all, const EcapaRowPlan& plan, int64_t a0, int64_t a1, float* d_emb_all)
 {
-    constexpr int P = sizeof(T) == 2 ? 1 : 0;                  // conv_gemm precision of the per-frame layers
+    const int P = sizeof(T) == 2 ? (c->ecapa_precision == 2 ? 2 : 1) : 0;      // conv_gemm precision of the per-frame layers (2 = fp16 MFMA, hi + lo weight planes)
     const EcapaWeights& E = c->ew;
     if (!E.loaded) SD_FAIL(c, SD_ERR_MODEL, "embedding model not loaded");
     const int64_t items = a1 - a0;
@@ -296,23 +305,45 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
     }
     // mfa: TDNNBlock(3C -> 3C, k1) over cat(x1,x2,x3)
     TAB(t31, 3, 1); TAB(t33, 3, 3);
-    { ConvArgs a = conv_args(E.mfa, cat, LD3, mfa, LD3, MN, true, P); a.act1 = 1; a.rowtab = t31; a.in_rows = (int)R[1]; if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc; }
+    // fp16 mode, option ecapa_f16_hp: bit 0 = the MFA output is stored in f32 (one rounding less in front of the pooling statistics, which
+    // are differences of large sums) and rounded once for the attention's fp16 MFMA; bit 1 = the attention branch (asp_tdnn, asp_conv: 4 % of
+    // the network's FLOPs, and the exponent of the softmax) on the f32 MFMA
+    const int hp = P ? c->ecapa_f16_hp : 0;
+    float* mfa32 = nullptr;
+    if (hp & 1) { WS(c, float, m32, "ec_mfa32", MN * LD3); mfa32 = m32; }
+    {
+        ConvArgs a = conv_args(E.mfa, cat, LD3, mfa32 ? (void*)mfa32 : (void*)mfa, LD3, MN, true, P);
+        a.act1 = 1; a.rowtab = t31; a.in_rows = (int)R[1]; a.y_f32 = mfa32 ? 1 : 0;
+        if ((rc = launch_conv_gemm(c, a, "mfa"))) return rc;
+    }
+    if (mfa32 && !(hp & 2)) {
+        hipLaunchKernelGGL(k_rows_to_half, GRID1(MN * LD3 / 4), 0, st, mfa32, (_Float16*)mfa, MN * LD3 / 4);
+        KCHECK(c);
+    }
     // ASP with global context: cat[x, mean, std] @ W == x @ Wx + (mean,std) @ Wms  (per-item bias)
     {
         ProfScope ps(c, "asp_stats", 0, (double)MN * C3 * 4.0);
-        hipLaunchKernelGGL(k_asp_stats<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, LD3, d_nvalid, ro[3], rbase[3], ms, C3);
+        if (mfa32) hipLaunchKernelGGL(k_asp_stats<float>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa32, LD3, d_nvalid, ro[3], rbase[3], ms, C3);
+        else hipLaunchKernelGGL(k_asp_stats<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, LD3, d_nvalid, ro[3], rbase[3], ms, C3);
         KCHECK(c);
     }
     { ConvArgs a = conv_args(E.asp_tdnn_ms, ms, 2 * C3, ib, 128, items, false); if ((rc = launch_conv_gemm(c, a, "asp_ms"))) return rc; }
-    { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, LD3, hid, 128, MN, true, P); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; a.rowtab = t33; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
     // attention logits stay f32 in either mode (they feed an exp: fp16's 3 decimal digits at |logit| ~ 30 would be percents of a weight).
     // f32 mode: cat is dead after mfa and large enough; fp16 mode: its own buffer
     float* logits;
-    if (P) { WS(c, float, lg, "ec_logits", MN * LD3); logits = lg; } else logits = (float*)cat;
-    { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, LD3, MN, true, P); a.rowtab = t33; a.y_f32 = 1; if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
+    if (P || c->ecapa_keep_cat) { WS(c, float, lg, "ec_logits", MN * LD3); logits = lg; } else logits = (float*)cat;
+    if (hp & 2) {
+        WS(c, float, hid32, "ec_hid32", MN * 128);
+        { ConvArgs a = conv_args(E.asp_tdnn_x, mfa32, LD3, hid32, 128, MN, true, 0); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; a.rowtab = t33; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
+        { ConvArgs a = conv_args(E.asp_conv, hid32, 128, logits, LD3, MN, true, 0); a.rowtab = t33; if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
+    } else {
+        { ConvArgs a = conv_args(E.asp_tdnn_x, mfa, LD3, hid, 128, MN, true, P); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; a.rowtab = t33; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
+        { ConvArgs a = conv_args(E.asp_conv, hid, 128, logits, LD3, MN, true, P); a.rowtab = t33; a.y_f32 = 1; if ((rc = launch_conv_gemm(c, a, "asp_conv"))) return rc; }
+    }
     {
         ProfScope ps(c, "asp_pool", 0, (double)MN * C3 * 8.0);
-        hipLaunchKernelGGL(k_asp_pool<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, LD3, d_nvalid, ro[3], rbase[3], pooled, C3);
+        if (mfa32) hipLaunchKernelGGL(k_asp_pool<float>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa32, logits, LD3, d_nvalid, ro[3], rbase[3], pooled, C3);
+        else hipLaunchKernelGGL(k_asp_pool<T>, dim3((C3 + 255) / 256, (unsigned)items), dim3(256), 0, st, mfa, logits, LD3, d_nvalid, ro[3], rbase[3], pooled, C3);
         KCHECK(c);
     }
     // asp_bn folded into fc
@@ -322,7 +353,7 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
 
 int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const EcapaRowPlan& plan, int64_t a0, int64_t a1, float* d_emb)
 {
-    if (c->ecapa_precision == 1) return run_ecapa_t<_Float16>(c, d_feats, d_nvalid, plan, a0, a1, d_emb);
+    if (c->ecapa_precision >= 1) return run_ecapa_t<_Float16>(c, d_feats, d_nvalid, plan, a0, a1, d_emb);
     return run_ecapa_t<float>(c, d_feats, d_nvalid, plan, a0, a1, d_emb);
 }
 
@@ -370,7 +401,20 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
         const std::vector<int>& rowoff = plan.off[0];
         const int64_t rows_all = rowoff[(size_t)n_active];
         WS(c, float, feats, "emb_feats", rows_all * SD_FEAT_LD);
-        if ((rc = frontend_features(c, d_wav, n, first_item, n_active, true, nnorm, d_rowoff, feats))) return rc;
+        c->fe_bill_samples = -1;
+        if (c->profile) {               // bill the front end what it really reads and writes: selected samples of the live items, stored frames
+            const int* d_counts = c->ws["fe_counts"].as<int>();
+            std::vector<int> h_cnt((size_t)items), h_cidx((size_t)items);
+            HIPCHK(c, hipMemcpyAsync(h_cnt.data(), d_counts, (size_t)items * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(h_cidx.data(), cidx, (size_t)items * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            int64_t tot = 0;
+            for (int64_t i = 0; i < items; ++i) if (h_cidx[(size_t)i] >= 0) tot += h_cnt[(size_t)i];
+            c->fe_bill_samples = tot; c->fe_bill_frames = rows_all;
+        }
+        rc = frontend_features(c, d_wav, n, first_item, n_active, true, nnorm, d_rowoff, feats);
+        c->fe_bill_samples = -1;
+        if (rc) return rc;
         // batches by row budget: whole items, at most what fits the activation workspaces of nb full-length items.  Within that the
         // boundary is placed where the wide-tile launches of the batch waste the least: a launch over M rows runs
         // ceil(ceil(M / 256) / 64) rounds of 64 row panels (8 XCDs x 8 panels per super-block) per group of column tiles, and the

@@ -322,8 +322,14 @@ int frontend_features(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_it
     if (grid > run_items) grid = (int)run_items;
     WS(c, float, d_scratch, "fe_db", (size_t)grid * SD_T * SD_NMELS);
     {
-        // algorithmic bytes per item: 80000*4 + 293*4 read, 501*80*4 written; ~15 kFLOP fp64 per frame (FFT) + 16 kFLOP mel
-        ProfScope ps(c, "stft_mel", (double)run_items * SD_T * (15000.0 + 201.0 * 80 * 2), (double)run_items * (321172.0 + 160320.0));
+        // algorithmic bytes (SURVEY 8d's per-item rule on what this launch really touches): the selected samples of every live item
+        // + its 293 mask values read, its stored frames x 96 floats written; ~15 kFLOP fp64 per frame (FFT) + 32 kFLOP mel.  Callers
+        // that know the launch's sample / frame totals leave them in the context (run_embed, profiling only); otherwise the
+        // full-length figure of 8d is billed (321 172 B read + 160 320 B written per item).
+        const double by = c->fe_bill_samples >= 0 ? (double)c->fe_bill_samples * 4.0 + (double)run_items * 293.0 * 4.0 + (double)c->fe_bill_frames * SD_FEAT_LD * 4.0
+                                                  : (double)run_items * (321172.0 + 160320.0);
+        const double fr = c->fe_bill_samples >= 0 ? (double)c->fe_bill_frames : (double)run_items * SD_T;
+        ProfScope ps(c, "stft_mel", fr * (15000.0 + 201.0 * 80 * 2), by);
         hipLaunchKernelGGL(k_stft_fbank, dim3(grid), dim3(256), 0, c->stream, d_wav, c->wav_origin, n, d_prefix, d_counts, first_item, E.window, E.tw_cos, E.tw_nsin,
                            E.mel_w, E.mel_lo, E.mel_cnt, E.mel_off, E.mel_nnz, alist, d_rowoff, d_nnorm, (int)run_items, d_scratch, d_feats);
         KCHECK(c);

@@ -96,10 +96,17 @@ static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const s
     L.W16 = nullptr;
     L.CinPad16 = (cin + 63) / 64 * 64;
     if (want16) {                          // fp16 copy (round to nearest even), rows padded to a multiple of 64 input channels
-        std::vector<_Float16> h16((size_t)K * Cout * L.CinPad16, (_Float16)0.0f);
+        // planes [0, K): W rounded to fp16; planes [K, 2K): the rounding residue W - (float)hi, again in fp16 (mode ecapa_precision = 2
+        // runs every tap twice, once against each plane: fp16 MFMA with 22-bit weights)
+        std::vector<_Float16> h16((size_t)2 * K * Cout * L.CinPad16, (_Float16)0.0f);
         for (int k = 0; k < K; ++k)
             for (int o = 0; o < Cout; ++o)
-                for (int i = 0; i < cin; ++i) h16[((size_t)k * Cout + o) * L.CinPad16 + i] = (_Float16)hw[((size_t)k * Cout + o) * CinPad + i];
+                for (int i = 0; i < cin; ++i) {
+                    const float v = hw[((size_t)k * Cout + o) * CinPad + i];
+                    const _Float16 hi = (_Float16)v;
+                    h16[((size_t)k * Cout + o) * L.CinPad16 + i] = hi;
+                    h16[((size_t)(K + k) * Cout + o) * L.CinPad16 + i] = (_Float16)(v - (float)hi);
+                }
         L.W16 = upload(c, h16);
         if (!L.W16) return SD_ERR_HIP;
     }

@@ -37,6 +37,7 @@ EXPORTS = [
     "sd_reset_stats", "sd_set_option", "sd_bench_conv", "sd_bench_barrier", "sd_convert_onnx", "sd_convert_error", "sd_read_wav_f32", "sd_free_wav", "sd_diarize_f32",
     "sd_write_rttm", "sd_set_planted", "sd_comm_unique_id", "sd_comm_init", "sd_comm_destroy", "sd_comm_info", "sd_shard_plan",
     "sd_diarize_sharded", "sd_diarize_sharded_dev", "sd_write_rttm_ex", "sd_relabel_turns", "sd_relabel_turns_ex", "sd_last_confidence",
+    "sd_debug_read_ws",
 ]
 COMM_ID_BYTES = 128
 
@@ -102,6 +103,7 @@ def lib():
     L.sd_set_option.argtypes = [vp, C.c_char_p, i64]
     L.sd_convert_onnx.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
     L.sd_convert_error.restype = C.c_char_p
+    L.sd_debug_read_ws.argtypes = [vp, C.c_char_p, i64, vp, i64]
     L.sd_bench_barrier.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(dbl)]
     L.sd_bench_conv.argtypes = [vp, i64] + [C.c_int] * 9 + [C.POINTER(dbl)]
     _lib = L
@@ -434,6 +436,12 @@ class Diarizer:
         ms = C.c_double(0)
         self._chk(lib().sd_bench_conv(self._h, items, Tp, T, Cin, Cout, KT, dil, has_x2, dbg, reps, C.byref(ms)))
         return ms.value
+
+    def read_ws(self, name, dtype, count, offset=0):
+        """test hook: `count` elements of the named device workspace"""
+        out = np.zeros(count, dtype)
+        self._chk(lib().sd_debug_read_ws(self._h, name.encode(), offset, _ptr(out), out.nbytes))
+        return out
 
     def reset_stats(self):
         lib().sd_reset_stats(self._h)

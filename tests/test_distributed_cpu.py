@@ -111,3 +111,41 @@ def test_shard_plan_properties():
             assert hi == lo or (lo * 3) % 32 == 0          # every non-empty shard starts on a reference batch boundary
             s0, s1 = sdhip.shard_sample_range(lo, hi, n_total)
             assert 0 <= s0 <= s1 <= n_total
+
+
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_ranks_hold_every_range_a_measured_rank0_share_can_give_them():
+    """bench.py --gpus N measures the rank-0 share on a warm-up job and re-plans; every rank synthesises the hull of its ranges under
+    the two extreme shares up front, and whatever share the measurement gives must fall inside it (else the first 8-GPU run would
+    find out)"""
+    bm = _bench_module()
+    for world in (2, 3, 4, 8):
+        n_total = 57600000 * world
+        C, _ = sdhip.num_chunks(n_total)
+        for rank in range(world):
+            lo, hi = bm.union_chunk_range(sdhip.shard_plan, n_total, world, rank, C)
+            for pm in range(0, int(round(1000.0 / world)) + 1):
+                _, rg = sdhip.shard_plan(n_total, world, pm)
+                l, h = rg[rank]
+                assert h <= l or (lo <= l and h <= hi), (world, rank, pm, (l, h), (lo, hi))
+            assert hi - lo <= 2.2 * C / world + 64 * (world + 2)                      # at most about two shares of audio per rank
+
+
+def test_bench_balanced_rank0_share():
+    bm = _bench_module()
+    C = 57591
+    # no finalize cost -> equal shares; finalize as long as a rank's inference -> rank 0 only finalizes
+    assert bm.balanced_rank0_permille([1200.0] * 8, [C / 8.0] * 8, 0.0, C, 8)[0] == 125
+    assert bm.balanced_rank0_permille([1200.0] * 8, [C / 8.0] * 8, 1500.0, C, 8)[0] == 0
+    pm, rate = bm.balanced_rank0_permille([1200.0] * 8, [C / 8.0] * 8, 600.0, C, 8)
+    s0, T = pm / 1000.0, 9600.0
+    assert abs((s0 * T + 600.0) - (1 - s0) * T / 7) < 0.02 * T / 8 and abs(rate - 9600.0 / C) < 1e-9
+    assert bm.balanced_rank0_permille([1200.0, 1200.0], [C / 2.0] * 2, 135.0, C, 2)[0] == 472

@@ -23,6 +23,13 @@ for w in worst: print("item",idx[w],"count",counts[idx[w]],"cosd %.2e"%cd[w], "n
 for lo,hi in [(0,2000),(2000,10000),(10000,40000),(40000,80001)]:
     m=(counts[idx]>=lo)&(counts[idx]<hi)
     if m.any(): print("count [%d,%d): n=%d max %.2e median %.2e"%(lo,hi,m.sum(),cd[m].max(),np.median(cd[m])))
+for hp in (1, 3):
+    d.set_option("ecapa_f16_hp", hp); cdh = cosd(d.embed(wav, masks))
+    print("ecapa_f16_hp=%d: max %.2e  q99 %.2e q90 %.2e median %.2e  items > 1e-3: %d" % (hp, cdh.max(), np.quantile(cdh, .99), np.quantile(cdh, .9), np.median(cdh), (cdh > 1e-3).sum()))
+d.set_option("ecapa_f16_hp", 0)
+d.set_option("ecapa_precision", 2); cd22 = cosd(d.embed(wav, masks)); d.set_option("ecapa_precision", 1)
+print("ecapa_precision=2 (hi + lo weight planes): max %.2e  q99 %.2e q90 %.2e median %.2e  items > 1e-3: %d" % (cd22.max(), np.quantile(cd22, .99), np.quantile(cd22, .9), np.median(cd22), (cd22 > 1e-3).sum()))
+print("default: items > 1e-3: %d of %d" % ((cd > 1e-3).sum(), len(cd)))
 d.set_option("conv_h256",0); cd2=cosd(d.embed(wav,masks)); print("no h256: max %.2e"%cd2.max()); d.set_option("conv_h256",1)
 d.set_option("skip_dead_rows",0); cd3=cosd(d.embed(wav,masks)); print("no skip: max %.2e"%cd3.max()); d.set_option("skip_dead_rows",1)
 import torch
