@@ -1201,27 +1201,37 @@ __global__ void k_cluster_means(const double* __restrict__ X, int d, const int* 
 }
 
 // cosine distance with the reference's sequential sums (sd.cpp:476-498); soft = 2 - d; argmax first-max-wins
+#define ASSIGN_TILE 1024
 __global__ __launch_bounds__(64) void k_assign(const double* __restrict__ E, int64_t M, int d, const double* __restrict__ cen, int K,
                                                int* __restrict__ hard, int* __restrict__ err, double* __restrict__ soft_out /*[M][K] or null*/,
                                                double* __restrict__ best_out /*[M] or null*/)
 {
-    extern __shared__ double soft[];
+    // arg-max over the K clusters in tiles of ASSIGN_TILE scores (any number of clusters fits the fixed LDS tile); first maximum wins,
+    // as Helper::argmax does (sd.cpp:293-316): tiles in ascending k, strict > inside and across tiles
+    __shared__ double soft[ASSIGN_TILE];
     const int64_t row = blockIdx.x;
     const double* e = E + (size_t)row * d;
-    for (int k = threadIdx.x; k < K; k += 64) {
-        const double* cc = cen + (size_t)k * d;
-        double dot = 0.0, m1 = 0.0, m2 = 0.0;
-        for (int i = 0; i < d; ++i) { dot += e[i] * cc[i]; m1 += e[i] * e[i]; m2 += cc[i] * cc[i]; }
-        if (m1 == 0.0 || m2 == 0.0) { *err = 1; soft[k] = NAN; }
-        else soft[k] = 2.0 - (1.0 - (dot / (sqrt(m1) * sqrt(m2))));
-        if (soft_out) soft_out[(size_t)row * K + k] = soft[k];
+    int best = 0; double mv = -DBL_MAX, sb = NAN; bool first = true;
+    for (int k0 = 0; k0 < K; k0 += ASSIGN_TILE) {
+        const int kn = K - k0 < ASSIGN_TILE ? K - k0 : ASSIGN_TILE;
+        for (int k = threadIdx.x; k < kn; k += 64) {
+            const double* cc = cen + (size_t)(k0 + k) * d;
+            double dot = 0.0, m1 = 0.0, m2 = 0.0;
+            for (int i = 0; i < d; ++i) { dot += e[i] * cc[i]; m1 += e[i] * e[i]; m2 += cc[i] * cc[i]; }
+            if (m1 == 0.0 || m2 == 0.0) { *err = 1; soft[k] = NAN; }
+            else soft[k] = 2.0 - (1.0 - (dot / (sqrt(m1) * sqrt(m2))));
+            if (soft_out) soft_out[(size_t)row * K + k0 + k] = soft[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (first) { sb = soft[0]; first = false; }             // best stays 0 when no score compares greater (NaN row -> cluster 0)
+            for (int k = 0; k < kn; ++k) if (soft[k] > mv) { mv = soft[k]; best = k0 + k; sb = soft[k]; }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        int best = 0; double mv = -DBL_MAX;
-        for (int k = 0; k < K; ++k) if (soft[k] > mv) { mv = soft[k]; best = k; }
         hard[row] = best;
-        if (best_out) best_out[row] = soft[best];                  // NaN for rows without an embedding
+        if (best_out) best_out[row] = sb;                          // NaN for rows without an embedding
     }
 }
 
@@ -1464,13 +1474,11 @@ int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector
     hipLaunchKernelGGL(k_cluster_means, dim3(nl), dim3(((d + 63) / 64) * 64), 0, c->stream, X, d, d_order2, d_off2, d_cen2);
     KCHECK(c);
     const bool constrained_assign = c->constrained_assignment && (M % SD_SPEAKERS) == 0;
+    // the full [M][K] score table only for the constrained assignment (it needs every score); the confidence needs the best score alone
     double* d_soft = nullptr; double* d_best = nullptr;
-    if (constrained_assign || soft_best) {
-        WS(c, double, t_soft, "cl_soft", (size_t)M * nl);
-        WS(c, double, t_best, "cl_best", M);
-        d_soft = t_soft; d_best = t_best;
-    }
-    hipLaunchKernelGGL(k_assign, dim3((unsigned)M), dim3(64), (size_t)nl * sizeof(double), c->stream, d_emb, M, d, d_cen2, nl, d_hard, d_err, d_soft, d_best);
+    if (constrained_assign) { WS(c, double, t_soft, "cl_soft", (size_t)M * nl); d_soft = t_soft; }
+    if (constrained_assign || soft_best) { WS(c, double, t_best, "cl_best", M); d_best = t_best; }
+    hipLaunchKernelGGL(k_assign, dim3((unsigned)M), dim3(64), 0, c->stream, d_emb, M, d, d_cen2, nl, d_hard, d_err, d_soft, d_best);
     KCHECK(c);
     int herr = 0;
     HIPCHK(c, hipMemcpyAsync(hard.data(), d_hard, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -116,6 +116,19 @@ bool parse_graph(PB pb, OGraph& g)
 // parameters and the Linear weights by Transpose): a node whose inputs are all constants becomes a constant itself.
 // Only data movement is evaluated -- no arithmetic -- so the extracted weights stay the exporter's bits.
 int64_t numel(const OTensor& t) { int64_t n = 1; for (auto d : t.dims) n *= d; return n; }
+// a tensor the constant folder may touch: non-negative dimensions, a bounded element count (no overflow, no giant resize) and exactly
+// that many stored elements -- a malformed model is skipped here and reported by the layer extraction ("... is not a constant")
+bool sane(const OTensor& t)
+{
+    int64_t n = 1;
+    for (auto d : t.dims) {
+        if (d < 0 || d > (int64_t)1 << 31) return false;
+        if (d != 0 && n > ((int64_t)1 << 31) / d) return false;
+        n *= d;
+    }
+    const int64_t have = (int64_t)(!t.i64.empty() ? t.i64.size() : t.f.size());
+    return have == n;
+}
 bool is_int(const OTensor& t) { return !t.i64.empty() || t.dtype == 7 || t.dtype == 6; }
 // copy a strided N-d view: out[idx] = in[sum (start_a + idx_a * step_a) * stride_a]
 void gather_nd(const OTensor& in, const std::vector<int64_t>& odims, const std::vector<int64_t>& start, const std::vector<int64_t>& step,
@@ -156,7 +169,9 @@ void fold_constants(OGraph& g)
         }
         if (!all || !in[0]) continue;
         const OTensor& x = *in[0];
-        if ((int64_t)(is_int(x) ? x.i64.size() : x.f.size()) != numel(x)) continue;
+        bool in_ok = true;
+        for (auto* t : in) if (t && !sane(*t)) in_ok = false;          // every input, not only the first: Concat copies from all of them
+        if (!in_ok) continue;
         OTensor y; y.name = n.out[0]; y.dtype = x.dtype;
         const int R = (int)x.dims.size();
         auto ints_of = [&](size_t k, const char* attr) -> std::vector<int64_t> {
@@ -171,13 +186,16 @@ void fold_constants(OGraph& g)
             if (n.op == "Unsqueeze") {
                 const int Ro = R + (int)axes.size();
                 std::vector<int64_t> od((size_t)Ro, -1);
-                for (auto a : axes) { if (a < 0) a += Ro; if (a < 0 || a >= Ro) { od.clear(); break; } od[(size_t)a] = 1; }
+                for (auto a : axes) { if (a < 0) a += Ro; if (a < 0 || a >= Ro || od[(size_t)a] == 1) { od.clear(); break; } od[(size_t)a] = 1; }   // out of range or duplicated axis
                 if (od.empty()) continue;
                 size_t q = 0;
                 for (auto& d : od) if (d == -1) d = x.dims[q++];
                 y.dims = od;
             } else {
                 std::vector<int64_t> od;
+                bool sq_ok = true;
+                for (auto ax : axes) { const int64_t a2 = ax < 0 ? ax + R : ax; if (a2 < 0 || a2 >= R || x.dims[(size_t)a2] != 1) sq_ok = false; }
+                if (!sq_ok) continue;
                 for (int a = 0; a < R; ++a) {
                     bool drop = axes.empty() ? x.dims[(size_t)a] == 1 : false;
                     for (auto ax : axes) if ((ax < 0 ? ax + R : ax) == a) drop = true;
@@ -189,15 +207,26 @@ void fold_constants(OGraph& g)
             if (in.size() < 2 || !in[1]) continue;
             std::vector<int64_t> od = in[1]->i64;
             int64_t known_n = 1; int neg = -1;
-            for (size_t a = 0; a < od.size(); ++a) { if (od[a] == 0 && a < x.dims.size()) od[a] = x.dims[a]; if (od[a] == -1) neg = (int)a; else known_n *= od[a]; }
-            if (neg >= 0) { if (known_n == 0) continue; od[(size_t)neg] = numel(x) / known_n; }
+            bool rs_ok = od.size() <= 8;
+            for (size_t a = 0; a < od.size() && rs_ok; ++a) {
+                if (od[a] == 0 && a < x.dims.size()) od[a] = x.dims[a];
+                if (od[a] == -1) { if (neg >= 0) rs_ok = false; neg = (int)a; }
+                else if (od[a] < 0 || od[a] > numel(x) || (od[a] > 0 && known_n > ((int64_t)1 << 40) / od[a])) rs_ok = false;
+                else known_n *= od[a];
+            }
+            if (!rs_ok) continue;
+            if (neg >= 0) { if (known_n == 0 || numel(x) % known_n) continue; od[(size_t)neg] = numel(x) / known_n; }
             y = x; y.name = n.out[0]; y.dims = od;
-            if (numel(y) != numel(x)) continue;
+            if (!sane(y)) continue;
         } else if (n.op == "Transpose") {
             const OAttr* pa = n.attr("perm");
             std::vector<int64_t> perm = pa ? pa->ints : std::vector<int64_t>();
             if (perm.empty()) for (int a = R - 1; a >= 0; --a) perm.push_back(a);
             if ((int)perm.size() != R) continue;
+            std::vector<char> seen((size_t)R, 0);
+            bool pm_ok = true;
+            for (auto q : perm) { if (q < 0 || q >= R || seen[(size_t)q]) { pm_ok = false; break; } seen[(size_t)q] = 1; }      // a permutation of 0..R-1
+            if (!pm_ok) continue;
             const std::vector<int64_t> xs = strides_of(x.dims);
             std::vector<int64_t> od((size_t)R), st((size_t)R, 0), sp((size_t)R, 1), is((size_t)R);
             for (int a = 0; a < R; ++a) { od[(size_t)a] = x.dims[(size_t)perm[(size_t)a]]; is[(size_t)a] = xs[(size_t)perm[(size_t)a]]; }
@@ -207,6 +236,7 @@ void fold_constants(OGraph& g)
             if (starts.size() != ends.size() || starts.empty()) continue;
             if (axes.empty()) for (size_t a = 0; a < starts.size(); ++a) axes.push_back((int64_t)a);
             if (steps.empty()) steps.assign(starts.size(), 1);
+            if (axes.size() != starts.size() || steps.size() != starts.size()) continue;
             std::vector<int64_t> od = x.dims, st((size_t)R, 0), sp((size_t)R, 1);
             bool ok = true;
             for (size_t k = 0; k < axes.size(); ++k) {

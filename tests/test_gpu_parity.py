@@ -66,6 +66,28 @@ def test_segmentation_shared_conv0_equals_per_chunk_conv0(diarizer, weights):
         np.testing.assert_allclose(shared[i], ref, rtol=RTOL, atol=ATOL)
 
 
+def test_segmentation_shared_conv0_with_a_dc_offset_on_near_silence(diarizer, weights):
+    """the hard case for the shared first convolution: a recording with a DC offset whose chunks are nearly silent -- the chunk
+    normalisation then multiplies by rstd up to 316 and the DC term of conv0(x) has to cancel against mean * sum(W).  Scores of the
+    shared form against the per-chunk form and against the oracle, and the binarised decisions (hysteresis at 0.4442) of the two forms"""
+    n = 80000 + 8000 * 6
+    rng = np.random.default_rng(78)
+    wav = (2e-4 * rng.standard_normal(n) + 0.05).astype(np.float32)             # DC / sigma = 250
+    wav[30000:50000] += (0.02 * rng.standard_normal(20000)).astype(np.float32)     # a burst, so that the chunks differ
+    wav[100000:] = (1e-3 * rng.standard_normal(n - 100000) - 0.2).astype(np.float32)   # another offset, DC / sigma = 200
+    diarizer.set_option("seg_shared_conv0", 0)
+    per_chunk = diarizer.segment(wav)
+    diarizer.set_option("seg_shared_conv0", 1)
+    shared = diarizer.segment(wav)
+    nc, last = orc.num_chunks(n)
+    net = nn.PyanNetOracle(weights[2])
+    ref = np.stack([net(wav[None, i * 8000:i * 8000 + 80000]).numpy()[0] for i in range(nc)])
+    print("shared vs per-chunk %.2e, shared vs oracle %.2e, per-chunk vs oracle %.2e" % (np.abs(shared - per_chunk).max(), np.abs(shared - ref).max(), np.abs(per_chunk - ref).max()))
+    np.testing.assert_allclose(shared, ref, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(per_chunk, ref, rtol=RTOL, atol=ATOL)
+    assert np.abs(shared - per_chunk).max() <= 5e-5
+
+
 def test_segmentation_too_short_for_one_frame_is_zero(diarizer):
     # a (single) chunk too short for one output frame: frames are zero padded like sd.cpp:1473-1479
     wav = np.random.default_rng(0).standard_normal(200).astype(np.float32) * 0.1

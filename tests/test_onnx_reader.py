@@ -71,6 +71,18 @@ def test_onnx_models_give_identical_results(onnx_files, diarizer):
     masks = (np.random.default_rng(1).random((33, 293)) > 0.3).astype(np.float32)
     np.testing.assert_allclose(d2.embed(wav, masks), diarizer.embed(wav, masks), rtol=1e-3, atol=1e-4 * 300, equal_nan=True)
     assert d2.diarize(pcm) == diarizer.diarize(pcm)
+    # ... and the ONNX-loaded context against the ORACLE (not against another libsdhip context): the weights that came out of the graphs
+    # drive the HIP path to the oracle's numbers
+    from oracle import orc
+    nc, _ = orc.num_chunks(len(wav))
+    ws, we = nn.synth_segmentation_weights(), nn.synth_embedding_weights()
+    seg_ref = nn.PyanNetOracle(ws)(np.stack([orc.crop(wav, i * 8000) for i in range(nc)])).numpy()
+    assert np.allclose(d2.segment(wav), seg_ref, rtol=1e-3, atol=1e-4)
+    feats, lens = d2.frontend(wav, masks[:6])
+    e_ref = nn.EcapaOracle(we)(feats, lens).numpy()
+    e_hip = d2.ecapa(feats, lens)
+    cos = (e_hip.astype(np.float64) * e_ref).sum(1) / np.linalg.norm(e_hip.astype(np.float64), axis=1) / np.linalg.norm(e_ref, axis=1)
+    assert (1 - cos).max() < 1e-5
     d2.close()
 
 
@@ -201,3 +213,214 @@ def test_embedding_reader_on_constant_node_variant(onnx_files, weights, tmp_path
     p = nn.load_pack(out)
     for k in p:
         assert np.array_equal(p[k], weights[3][k]), k
+
+
+# ------------------------------------------------------------------ a module tree nested and named like speechbrain 0.5.14's (embeddings/threeModel.py:181-227)
+class _SBConv1d(torch.nn.Module):
+    """speechbrain.nnet.CNN.Conv1d (skip_transpose=True, padding="same", padding_mode="reflect"): explicit F.pad, then `self.conv`"""
+    def __init__(self, cin, cout, k, dil=1):
+        super().__init__()
+        self.k, self.dil = k, dil
+        self.conv = torch.nn.Conv1d(cin, cout, k, dilation=dil, padding=0)
+
+    def forward(self, x):
+        pad = self.dil * (self.k - 1) // 2
+        if pad:
+            x = torch.nn.functional.pad(x, (pad, pad), mode="reflect")
+        return self.conv(x)
+
+
+class _SBBatchNorm1d(torch.nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.norm = torch.nn.BatchNorm1d(c)
+
+    def forward(self, x):
+        return self.norm(x)
+
+
+class _SBTDNN(torch.nn.Module):
+    def __init__(self, cin, cout, k, dil):
+        super().__init__()
+        self.conv, self.activation, self.norm = _SBConv1d(cin, cout, k, dil), torch.nn.ReLU(), _SBBatchNorm1d(cout)
+
+    def forward(self, x):
+        return self.norm(self.activation(self.conv(x)))
+
+
+class _SBRes2Net(torch.nn.Module):
+    def __init__(self, c, dil):
+        super().__init__()
+        self.blocks = torch.nn.ModuleList([_SBTDNN(c // 8, c // 8, 3, dil) for _ in range(7)])
+
+    def forward(self, x):
+        y, ys = None, []
+        for i, xi in enumerate(torch.chunk(x, 8, dim=1)):
+            y = xi if i == 0 else (self.blocks[i - 1](xi) if i == 1 else self.blocks[i - 1](xi + y))
+            ys.append(y)
+        return torch.cat(ys, dim=1)
+
+
+class _SBSE(torch.nn.Module):
+    def __init__(self, c, s):
+        super().__init__()
+        self.conv1, self.relu, self.conv2, self.sigmoid = _SBConv1d(c, s, 1), torch.nn.ReLU(), _SBConv1d(s, c, 1), torch.nn.Sigmoid()
+
+    def forward(self, x, mask):
+        s = (x * mask).sum(dim=2, keepdim=True) / mask.sum(dim=2, keepdim=True)
+        return self.sigmoid(self.conv2(self.relu(self.conv1(s)))) * x
+
+
+class _SBSERes2Net(torch.nn.Module):
+    def __init__(self, c, dil):
+        super().__init__()
+        self.tdnn1, self.res2net_block, self.tdnn2, self.se_block = _SBTDNN(c, c, 1, 1), _SBRes2Net(c, dil), _SBTDNN(c, c, 1, 1), _SBSE(c, 128)
+
+    def forward(self, x, mask):
+        return self.se_block(self.tdnn2(self.res2net_block(self.tdnn1(x))), mask) + x
+
+
+class _SBASP(torch.nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.tdnn, self.tanh, self.conv = _SBTDNN(3 * c, 128, 1, 1), torch.nn.Tanh(), _SBConv1d(128, c, 1)
+
+    def forward(self, x, mask):
+        L = x.shape[-1]
+        mw = mask / mask.sum(dim=2, keepdim=True)
+        mean = (mw * x).sum(2)
+        std = torch.sqrt((mw * (x - mean.unsqueeze(2)).pow(2)).sum(2).clamp(1e-12))
+        attn = torch.cat([x, mean.unsqueeze(2).repeat(1, 1, L), std.unsqueeze(2).repeat(1, 1, L)], dim=1)
+        attn = torch.nn.functional.softmax(self.conv(self.tanh(self.tdnn(attn))).masked_fill(mask == 0, float("-inf")), dim=2)
+        mean = (attn * x).sum(2)
+        std = torch.sqrt((attn * (x - mean.unsqueeze(2)).pow(2)).sum(2).clamp(1e-12))
+        return torch.cat((mean, std), dim=1).unsqueeze(2)
+
+
+class _SBEcapa(torch.nn.Module):
+    def __init__(self, C=1024):
+        super().__init__()
+        self.blocks = torch.nn.ModuleList([_SBTDNN(80, C, 5, 1)] + [_SBSERes2Net(C, d) for d in (2, 3, 4)])
+        self.mfa, self.asp, self.asp_bn, self.fc = _SBTDNN(3 * C, 3 * C, 1, 1), _SBASP(3 * C), _SBBatchNorm1d(6 * C), _SBConv1d(6 * C, 192, 1)
+
+    def forward(self, x, lengths):
+        x = x.transpose(1, 2)
+        L = x.shape[-1]
+        mask = (torch.arange(L)[None, :] < (lengths * L)[:, None]).float()[:, None, :]
+        xl = []
+        for i, layer in enumerate(self.blocks):
+            x = layer(x) if i == 0 else layer(x, mask)
+            xl.append(x)
+        x = self.mfa(torch.cat(xl[1:], dim=1))
+        return self.fc(self.asp_bn(self.asp(x, mask))).transpose(1, 2)
+
+
+class _SBEncoder(torch.nn.Module):
+    """the exported object of embeddings/export3.py: spectral_magnitude -> Filterbank -> MyNormalization -> mods.embedding_model"""
+    def __init__(self, w):
+        super().__init__()
+        self.register_buffer("mel", torch.from_numpy(np.asarray(w["fbank.matrix"])))
+        self.mods = torch.nn.ModuleDict(dict(embedding_model=_SBEcapa()))
+        sd = {}
+        for k, v in w.items():
+            if k in ("fbank.matrix", "stft.window"):
+                continue
+            parts = k.split(".")
+            leaf = parts[-1]
+            body = ".".join(parts[:-1]).replace(".res2net.", ".res2net_block.blocks.").replace(".se.", ".se_block.")
+            inner = "norm" if (body.endswith(".norm") or body == "asp_bn") else "conv"
+            sd["mods.embedding_model.%s.%s.%s" % (body, inner, leaf)] = torch.from_numpy(np.asarray(v))
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd and not k.endswith("num_batches_tracked") and k != "mel"]
+        assert not missing, missing[:5]
+        self.load_state_dict({**{k: v for k, v in own.items() if k not in sd}, **sd})
+
+    def forward(self, feats, wav_lens):
+        fb = torch.matmul(feats.pow(2).sum(-1), self.mel)
+        x_db = 10.0 * torch.log10(torch.clamp(fb, min=1e-10))
+        x_db = torch.max(x_db, (x_db.amax(dim=(-2, -1)) - 80.0).view(-1, 1, 1))
+        T = x_db.size(1)
+        rows = []
+        for i in range(x_db.size(0)):
+            n = torch.round(wav_lens[i] * T).long()
+            rows.append(x_db[i] - x_db[i, 0:n].mean(dim=0))
+        return self.mods["embedding_model"](torch.stack(rows), wav_lens)
+
+
+def test_embedding_reader_on_a_speechbrain_shaped_module_tree(weights, tmp_path):
+    """the reader takes the layers in execution order by operator type, never by name: a module tree nested and named the way
+    speechbrain 0.5.14 builds ECAPA_TDNN (Conv1d / BatchNorm1d wrappers with an inner `.conv` / `.norm`, explicit reflect Pad in front
+    of every k > 1 convolution, `mods.embedding_model.blocks.N.res2net_block.blocks.M`, `se_block`, `asp`) must give the same pack"""
+    m = _SBEncoder(weights[3])
+    st = nn.stft_ref((0.1 * np.random.default_rng(0).standard_normal((2, 80000))).astype(np.float32))
+    ref = nm.EmbeddingModule(weights[3]).eval()
+    with torch.no_grad():
+        assert torch.equal(m.eval()(st, torch.tensor([1.0, 0.7])), ref(st, torch.tensor([1.0, 0.7])))
+    path = str(tmp_path / "sb.onnx")
+    _export(m, (st, torch.tensor([1.0, 0.7])), path, ["feats", "wav_lens"], ["embedding"], do_constant_folding=True)
+    raw = open(path, "rb").read()
+    assert b"mods.embedding_model.blocks.1.res2net_block.blocks.0.conv.conv.weight" in raw or b"onnx::Conv" in raw
+    out = str(tmp_path / "sb.sdw")
+    sdhip.convert_onnx(path, "embedding", out)
+    p = nn.load_pack(out)
+    assert set(p) == set(weights[3]) - {"stft.window"}
+    for k in p:
+        assert np.array_equal(p[k], weights[3][k]), k
+
+
+# ------------------------------------------------------------------ malformed constant-folding inputs (header: "malformed models are reported ... nothing is guessed")
+def _tensor(name, dims, floats=None, ints=None):
+    t = b"".join(_emit(1, 0, _varint(d)) for d in dims)
+    if floats is not None:
+        t += _emit(2, 0, _varint(1)) + _emit(9, 2, np.asarray(floats, np.float32).tobytes())
+    else:
+        t += _emit(2, 0, _varint(7)) + _emit(9, 2, np.asarray(ints, np.int64).tobytes())
+    return t + _emit(8, 2, name)
+
+
+def _node(op, ins, outs, attrs=b""):
+    return b"".join(_emit(1, 2, i) for i in ins) + b"".join(_emit(2, 2, o) for o in outs) + _emit(4, 2, op) + attrs
+
+
+def _ints_attr(name, vals):
+    return _emit(5, 2, _emit(1, 2, name) + b"".join(_emit(8, 0, _varint(v & 0xFFFFFFFFFFFFFFFF)) for v in vals) + _emit(20, 0, _varint(7)))
+
+
+def _model(nodes, inits):
+    g = b"".join(_emit(1, 2, n) for n in nodes) + _emit(2, 2, b"g") + b"".join(_emit(5, 2, t) for t in inits)
+    return _emit(1, 0, _varint(8)) + _emit(7, 2, g)
+
+
+@pytest.mark.parametrize("case", ["transpose_perm_out_of_range", "transpose_perm_duplicate", "unsqueeze_duplicate_axes", "concat_short_second_input",
+                                  "numel_overflow", "reshape_two_minus_ones", "squeeze_axis_out_of_range"])
+def test_constant_folder_survives_malformed_nodes(tmp_path, case):
+    """graphs whose weight-shuffling nodes are malformed (perm outside [0, R), duplicated axes, an input holding fewer elements than its
+    dims say, dims whose product overflows): the folder must skip them -- no out-of-bounds read, no giant allocation -- and the
+    conversion must end with SD_ERR_MODEL and a reason"""
+    x = _tensor(b"x", [2, 3], floats=np.arange(6))
+    nodes, inits = [], [x]
+    if case == "transpose_perm_out_of_range":
+        nodes = [_node(b"Transpose", [b"x"], [b"y"], _ints_attr(b"perm", [0, 5]))]
+    elif case == "transpose_perm_duplicate":
+        nodes = [_node(b"Transpose", [b"x"], [b"y"], _ints_attr(b"perm", [1, 1]))]
+    elif case == "unsqueeze_duplicate_axes":
+        inits.append(_tensor(b"ax", [3], ints=[0, 0, 1]))
+        nodes = [_node(b"Unsqueeze", [b"x", b"ax"], [b"y"])]
+    elif case == "concat_short_second_input":
+        inits.append(_tensor(b"z", [2, 300000], floats=np.arange(4)))           # says 600 000 elements, holds 4
+        nodes = [_node(b"Concat", [b"x", b"z"], [b"y"], _emit(5, 2, _emit(1, 2, b"axis") + _emit(3, 0, _varint(1)) + _emit(20, 0, _varint(2))))]
+    elif case == "numel_overflow":
+        inits = [_tensor(b"x", [1 << 40, 1 << 40], floats=np.arange(6))]
+        nodes = [_node(b"Identity", [b"x"], [b"y"])]
+    elif case == "reshape_two_minus_ones":
+        inits.append(_tensor(b"sh", [2], ints=[-1, -1]))
+        nodes = [_node(b"Reshape", [b"x", b"sh"], [b"y"])]
+    elif case == "squeeze_axis_out_of_range":
+        inits.append(_tensor(b"ax", [1], ints=[7]))
+        nodes = [_node(b"Squeeze", [b"x", b"ax"], [b"y"])]
+    path = tmp_path / (case + ".onnx")
+    path.write_bytes(_model(nodes, inits))
+    for kind in ("segmentation", "embedding"):
+        with pytest.raises(sdhip.SdError) as e:
+            sdhip.convert_onnx(str(path), kind, str(tmp_path / "x.sdw"))
+        assert e.value.code == 3 and ("expected" in str(e.value) or "no MatMul" in str(e.value))        # SD_ERR_MODEL with a reason

@@ -204,10 +204,14 @@ def test_whole_path_with_planted_scores_and_real_embeddings(diarizer, weights):
 @pytest.mark.gpu
 def test_fp16_mode_embeddings_at_scale_stay_within_the_north_star_tolerance(diarizer):
     """BASELINE.json configs[4] at the 10-min size: the real embeddings of the planted masks (partial lengths, compact rows, narrow
-    MFA space, 256 x 256 and 128 x 128 fp16 kernels) in fp16 mode against the f32 path.  Tolerance of the mode at this size, with the
-    seeded random weights (whose attentive pooling is close to one-hot for about 1 % of the items, so that a 5e-4 perturbation of the
-    logits moves the pooled vector): cosine distance median <= 1e-4, 99th percentile <= 1e-3 (the north-star bar), maximum <= 5e-3;
-    the same rows NaN; identical turns, with the real embeddings and with the planted ones of the bench"""
+    MFA space, 256 x 256 and 128 x 128 fp16 kernels) in fp16 mode against the f32 path of the UNQUANTISED model.  What separates the two
+    is, almost entirely, the rounding of the WEIGHTS to fp16 (test_fp16_weight_rounding_alone... shows 1.9e-3 for item 2 509 in exact
+    arithmetic; the kernels and the fp16 activations add < 3e-4, test_fp16_mode_against_the_f32_reference_of_the_same_fp16_weights):
+    a weight error is the same linear map in every frame, does not average out in the SE statistics, and the seeded random network's
+    saturated SE gates amplify it (tools/diag_fp16_layers.py, profiles/r03_fp16_error_by_layer.txt).  So the distribution is asserted:
+    median <= 1e-4, 99th percentile <= 1e-3 (the north-star bar), at most 1 % of the items above it, maximum <= 5e-3; the same rows NaN;
+    identical turns, with the real embeddings and with the planted ones of the bench.  Mode 2 (hi + lo fp16 weight planes, 22-bit
+    weights on the fp16 MFMA) removes the weight term: median <= 1e-5, 99th percentile <= 5e-4, at most 5 items above 1e-3."""
     import torch
     seconds = 600.0
     pcm, scores, assign, emb_planted = planted_case(seconds, 1234)
@@ -215,8 +219,10 @@ def test_fp16_mode_embeddings_at_scale_stay_within_the_north_star_tolerance(diar
     b, masks, counts, bad = nan_rule(scores)
     wav = pcm.astype(np.float32) / np.float32(32768.0)
     e32 = diarizer.embed(wav, masks)
-    diarizer.set_option("ecapa_precision", 1)
+    diarizer.set_option("ecapa_precision", 2)
     try:
+        e16x2 = diarizer.embed(wav, masks)
+        diarizer.set_option("ecapa_precision", 1)
         e16 = diarizer.embed(wav, masks)
         dev = torch.device("cuda", 0)
         d_pcm = torch.from_numpy(pcm).to(dev)
@@ -240,10 +246,90 @@ def test_fp16_mode_embeddings_at_scale_stay_within_the_north_star_tolerance(diar
     cos = (a * c).sum(1) / np.linalg.norm(a, axis=1) / np.linalg.norm(c, axis=1)
     cd = 1 - cos
     assert np.median(cd) <= 1e-4 and np.quantile(cd, 0.99) <= 1e-3 and cd.max() <= 5e-3, (np.median(cd), np.quantile(cd, 0.99), cd.max())
+    assert (cd > 1e-3).mean() <= 0.01
+    a2 = e16x2[live].astype(np.float64)
+    cd2 = 1 - (a2 * c).sum(1) / np.linalg.norm(a2, axis=1) / np.linalg.norm(c, axis=1)
+    assert np.array_equal(np.isnan(e16x2[:, 0]), bad)
+    assert np.median(cd2) <= 1e-5 and np.quantile(cd2, 0.99) <= 5e-4 and (cd2 > 1e-3).sum() <= 5 and cd2.max() <= 2e-3, (np.median(cd2), np.quantile(cd2, 0.99), cd2.max())
     rel = np.linalg.norm(a - c, axis=1) / np.linalg.norm(c, axis=1)
     assert np.median(rel) <= 1e-2 and rel.max() <= 1e-1, (np.median(rel), rel.max())
     assert turns16 == turns32 and len(turns16) > 60
     assert real16 == real32 and len(real16) >= 5
+
+
+def _fp16_weights(w):
+    """the weights the fp16 mode multiplies with: every per-frame conv layer rounded to fp16 (SE and fc stay f32, csrc/weights.cpp)"""
+    out = dict(w)
+    for k, v in w.items():
+        if k.endswith("conv.weight") and ".se." not in k and not k.startswith("fc"):
+            out[k] = np.asarray(v, np.float32).astype(np.float16).astype(np.float32)
+    return out
+
+
+def _cosd(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return 1 - (a * b).sum(1) / np.linalg.norm(a, axis=1) / np.linalg.norm(b, axis=1)
+
+
+def test_fp16_weight_rounding_alone_exceeds_the_bar_on_the_seeded_model():
+    """CPU, exact f32 arithmetic: rounding the conv weights of the seeded synthetic ECAPA to fp16 -- nothing else -- moves item 2 509 of
+    the planted 10-min set by a cosine distance of 1.9e-3.  BASELINE configs[4] ("fp16 ECAPA-TDNN weights") therefore cannot hold 1e-3
+    against the unquantised f32 model on every item, whatever the kernels do; the kernels' own share is checked against the f32
+    reference of the SAME fp16 weights (next test)."""
+    pcm, scores, assign, emb_planted = planted_case(600.0, 1234)
+    b, masks, counts, bad = nan_rule(scores)
+    wav = pcm.astype(np.float32) / np.float32(32768.0)
+    we = nn.synth_embedding_weights()
+    items = [i for i in range(2496, 2528)]
+    sig = np.zeros((32, 80000), np.float32)
+    cn = np.zeros(32, np.int64)
+    for j, i in enumerate(items):
+        sig[j], cn[j] = orc.mask_compact(orc.crop(wav, (i // 3) * 8000), masks[i])
+    lens, ts, an = orc.wav_lens(cn)
+    assert np.array_equal(ts | an, bad[2496:2528])
+    feats = nn.fbank_norm_ref(nn.stft_ref(sig, we.get("stft.window")), lens, we["fbank.matrix"])
+    e0 = nn.EcapaOracle(we)(feats, lens).numpy()
+    eq = nn.EcapaOracle(_fp16_weights(we))(feats, lens).numpy()
+    cd = _cosd(eq, e0)
+    live = ~(ts | an)
+    assert 1.5e-3 < cd[13] == cd[live].max() < 2.5e-3                       # item 2 509
+    assert np.median(cd[live]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_fp16_mode_against_the_f32_reference_of_the_same_fp16_weights(diarizer, weights):
+    """BASELINE configs[4], the tolerance check proper: the fp16 HIP path (fp16 weights, fp16 activations, f32 accumulation) against
+    the torch f32 oracle running the SAME fp16-rounded weights, on the three 32-item batches of the planted 10-min set that hold the
+    worst items of the mode: every embedding within 1e-3 (measured <= 2.7e-4).  Beside it, on the same items: the f32 HIP path against
+    the unquantised oracle (<= 1e-6), and the distance the weight rounding alone creates (the oracle against itself: > 1e-3 on the worst
+    item of every batch) -- the part of the distance to the unquantised model that no kernel can remove."""
+    pcm, scores, assign, emb_planted = planted_case(600.0, 1234)
+    b, masks, counts, bad = nan_rule(scores)
+    wav = pcm.astype(np.float32) / np.float32(32768.0)
+    we = weights[3]
+    wq = _fp16_weights(we)
+    feats, lens = diarizer.frontend(wav, masks)
+    n_items = 0
+    for w0 in (2509, 3240, 3315):
+        b0 = (w0 // 32) * 32
+        idx = np.array([i for i in range(b0, b0 + 32) if not bad[i]])
+        f, l = np.ascontiguousarray(feats[idx]), np.ascontiguousarray(lens[idx])
+        e_exact = nn.EcapaOracle(we)(f, l).numpy()
+        e_q = nn.EcapaOracle(wq)(f, l).numpy()
+        e32 = diarizer.ecapa(f, l)
+        try:
+            diarizer.set_option("ecapa_precision", 1)
+            e16 = diarizer.ecapa(f, l)
+            diarizer.set_option("ecapa_precision", 2)
+            e16x2 = diarizer.ecapa(f, l)
+        finally:
+            diarizer.set_option("ecapa_precision", 0)
+        assert _cosd(e32, e_exact).max() < 1e-6
+        assert _cosd(e16, e_q).max() < 1e-3                                   # the north-star bar, against the f32 reference of the model that runs
+        assert _cosd(e_q, e_exact).max() > 1e-3                               # ... which the weight rounding alone puts beyond 1e-3 of the unquantised one
+        assert _cosd(e16x2, e_exact).max() < 2e-3 and np.median(_cosd(e16x2, e_exact)) < 2e-5
+        n_items += len(idx)
+    assert n_items >= 64
 
 
 @pytest.mark.gpu
