@@ -98,6 +98,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "linkage_wgs") c->linkage_wgs = v;
     else if (k == "linkage_threads") c->linkage_threads = v;
     else if (k == "linkage_one_xcd") c->linkage_one_xcd = v;
+    else if (k == "linkage_square") c->linkage_square = v;
     else if (k == "skip_dead_rows") c->skip_dead_rows = v != 0;
     else if (k == "conv_h256") c->conv_h256 = v != 0;
     else if (k == "conv_w256_f32") c->conv_w256_f32 = v != 0;

@@ -88,6 +88,59 @@ __global__ __launch_bounds__(256) void k_pdist(const double* __restrict__ X, int
         }
 }
 
+// the same distances as the full N x N square (k_linkage_mw<*, true>): tile (ti, tj), ti <= tj, is computed once and written twice, the
+// mirror through an LDS transpose so that both writes are row-contiguous.  D[i][j] and D[j][i] are the same bits; the diagonal is 0.
+__global__ __launch_bounds__(256) void k_pdist_sq(const double* __restrict__ X, int64_t N, int d, double* __restrict__ D)
+{
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj < ti) return;
+    __shared__ double Xi[PT][33], Xj[PT][33];
+    __shared__ double Tt[PT][PT + 1];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+    for (int q0 = 0; q0 < d; q0 += 32) {
+        for (int e = tid; e < PT * 32; e += 256) {
+            const int r = e >> 5, q = e & 31;
+            int64_t gi = (int64_t)ti * PT + r; if (gi > N - 1) gi = N - 1;
+            int64_t gj = (int64_t)tj * PT + r; if (gj > N - 1) gj = N - 1;
+            const bool in = (q0 + q) < d;
+            Xi[r][q] = in ? X[(size_t)gi * d + q0 + q] : 0.0;
+            Xj[r][q] = in ? X[(size_t)gj * d + q0 + q] : 0.0;
+        }
+        __syncthreads();
+        for (int q = 0; q < 32; ++q) {          // sequential in q: same summation order as the reference (and as k_pdist)
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = Xi[ty + 16 * u][q]; b[u] = Xj[tx + 16 * u][q]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { const double df = a[u] - b[v]; acc[u][v] += df * df; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int li = ty + 16 * u, lj = tx + 16 * v;
+            const int64_t i = (int64_t)ti * PT + li, j = (int64_t)tj * PT + lj;
+            const double dv = (i == j) ? 0.0 : sqrt(acc[u][v]);
+            Tt[li][lj] = dv;
+            if (i < N && j < N && (ti != tj || i <= j)) D[(size_t)i * N + j] = dv;
+        }
+    __syncthreads();
+    for (int e = tid; e < PT * PT; e += 256) {
+        const int lj = e >> 6, li = e & 63;                 // consecutive threads: consecutive i = consecutive addresses of row j
+        const int64_t i = (int64_t)ti * PT + li, j = (int64_t)tj * PT + lj;
+        if (i < N && j < N && i < j) D[(size_t)j * N + i] = Tt[li][lj];
+    }
+}
+
 // ---------------------------------------------------------------- nearest active neighbour above a row (cl.cpp:259-276)
 struct MinIdx { double v; int i; };
 __device__ __forceinline__ MinIdx better(MinIdx a, MinIdx b)
@@ -173,12 +226,12 @@ __device__ __forceinline__ Min2 wave_min2(Min2 m)
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_row_nn(const double* __restrict__ D, int64_t n, int* __restrict__ nb, double* __restrict__ md, double* __restrict__ md2)
+__global__ __launch_bounds__(256) void k_row_nn(const double* __restrict__ D, int64_t n, int* __restrict__ nb, double* __restrict__ md, double* __restrict__ md2, int square)
 {
     const int lane = threadIdx.x & 63;
     const int64_t x = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (x >= n - 1) return;
-    const double* row = D + cidx(n, x, x + 1);
+    const double* row = D + (square ? x * n + x + 1 : cidx(n, x, x + 1));
     const int64_t cnt = n - 1 - x;
     Min2 m; m.v = INFINITY; m.i = -1; m.v2 = INFINITY;
     for (int64_t t = lane; t < cnt; t += 64) min2_acc(m, row[t], (int)(x + 1 + t));
@@ -539,7 +592,15 @@ __device__ __forceinline__ void block_min_qc(Min2& q, Cand& m, Min2* shq, Cand* 
 #define SLOT_WORDS 32
 typedef unsigned long long MwGran;
 
-template <bool ONEX>
+// SQ form (k_linkage_mw<*, true>): the distance matrix is the full N x N square and a workgroup owns a contiguous range of COLUMNS.
+// Only rows are ever read or written in bulk: a merge (x, y) reads rows x and y and writes row y, every workgroup its own column range,
+// coalesced (the condensed form touches one 64-byte line per entry for the half of the entries that lie in a column: 150 000 scattered
+// transactions per merge at N = 100 000, tools/tlb_probe2.hip).  Row y is NOT mirrored into column y.  Instead every cluster carries the
+// index ty of the last merge that rewrote its row (-1: never), and the entry {a, b} is read from the row of the cluster with the larger
+// ty -- the one written last, which holds the current value; with equal ty (two clusters that never were a merge's y) both rows still
+// hold the pdist value.  A merge that involves a cluster older than a bystander z reads that one entry from row z (scattered); on
+// clustered data (one growing cluster per speaker swallowing singletons) that is a handful of entries per merge.
+template <bool ONEX, bool SQ>
 __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* size_all, int* cid, int* nb, double* md, const double* md2_init,
                                                          double* Z, MwGran* gran /*[2][G][SLOT_WORDS], zeroed*/,
                                                          unsigned* sync, int cap /*owned rows per workgroup, upper bound*/, int G)
@@ -555,7 +616,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     // rounds per merge on the planted hour.  Same merges: the arg-min of exact values does not depend on how the bounds are kept.
     double* l_md = (double*)dyn_lds;                 // [cap] bound of act[p]
     double* l_md2 = l_md + cap;                      // [cap] lower bound of the row's entries other than the neighbour's
-    int* act = (int*)(l_md2 + cap);                  // [cap] owned active rows, unordered
+    int* act = (int*)(l_md2 + cap);                  // [cap] owned active rows, unordered.  SQ: l_ty[s] = ty of owned column z0 + s
     int* pos = act + cap;                            // [cap] pos[z / G] = index of owned row z in act
     int* l_nb = pos + cap;                           // [cap] neighbour of act[p]
     unsigned char* l_fr = (unsigned char*)(l_nb + cap);   // [cap] freshness of act[p]
@@ -585,7 +646,14 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         if (g < 0 || g >= G) return;
     }
     const int64_t N = n;
-    int* size = size_all + (size_t)g * n;
+    int* size = size_all + (size_t)g * n * (SQ ? 2 : 1);       // this workgroup's private copy of the cluster sizes (SQ: followed by its copy of ty)
+    int* tyv = size + n;                                       // SQ only
+    int* l_ty = act;                                           // SQ only
+    const int colsB = cap - 1;                                 // SQ: columns per workgroup; z0 = first owned column, nown = how many exist
+    const int z0 = SQ ? g * colsB : 0;
+    const int nown = SQ ? (n - z0 < colsB ? (n - z0 > 0 ? n - z0 : 0) : colsB) : 0;
+    auto own = [&](int z) -> bool { return SQ ? (z >= z0 && z < z0 + colsB) : ((z % G) == g); };
+    auto slot = [&](int z) -> int { return SQ ? z - z0 : pos[z / G]; };
     unsigned bar = 0;
     int par = 0, lp = 0;             // slot parity, refresh-list parity
     // receive round `bar` of every workgroup's slot (nw words each) into s_words; returns false on timeout
@@ -620,17 +688,18 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
 #pragma unroll
         for (int r = 0; r < KR; ++r) ex[r] = r < nL ? L[r] : -1;
         Cand m; m.v = INFINITY; m.i = -1; m.y = -1; m.fresh = 0;
-        const int cnt = s_cnt;
+        const int cnt = SQ ? nown : s_cnt;
         for (int p0 = tid; p0 < cnt; p0 += T * 4) {
             double v[4]; int zz[4], ny_[4]; unsigned char fr[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = p0 + u * T;
                 const int pc = p < cnt ? p : 0;
-                int z = p < cnt ? act[pc] : -1;
+                fr[u] = l_fr[pc];
+                int z = p < cnt ? (SQ ? ((fr[u] & 2) ? -1 : z0 + pc) : act[pc]) : -1;
                 if (z >= n - 1) z = -1;
                 zz[u] = z;
-                v[u] = l_md[pc]; ny_[u] = l_nb[pc]; fr[u] = l_fr[pc];
+                v[u] = l_md[pc]; ny_[u] = l_nb[pc];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -650,8 +719,28 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         for (int t = wv; t < nL * S; t += NW) {
             const int r = t % nL, sidx = t / nL;
             const int x = L[r];
-            const double* row = D + cidx(N, x, (int64_t)x + 1) - (x + 1);
             Min2 q; q.v = INFINITY; q.i = -1; q.v2 = INFINITY;
+            if constexpr (SQ) {
+                // this workgroup's own columns above x: entry {x, j} from the row written last
+                const int txr = tyv[x];
+                const int64_t jend = (int64_t)z0 + nown, step = (int64_t)S * 64;
+                for (int64_t j0 = (x + 1 > z0 ? x + 1 : z0) + (int64_t)sidx * 64 + lane; j0 < jend; j0 += step * 4) {
+                    double v[4]; bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t j = j0 + u * step; const int64_t jc = j < jend ? j : jend - 1;
+                        const int sj = (int)(jc - z0);
+                        ok[u] = j < jend && !(l_fr[sj] & 2);
+                        v[u] = LDG(txr >= l_ty[sj] ? &D[(int64_t)x * N + jc] : &D[jc * N + x]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (ok[u]) min2_acc(q, v[u], (int)(j0 + u * step));
+                }
+                q = wave_min2(q);
+                if (lane == 0) s_part[r][sidx] = q;
+                continue;
+            }
+            const double* row = D + cidx(N, x, (int64_t)x + 1) - (x + 1);
             const int64_t step = (int64_t)G * S * 64;
             for (int64_t j0 = (int64_t)x + 1 + ((int64_t)g * S + sidx) * 64 + lane; j0 < n; j0 += step * 4) {
                 double v[4]; int sz[4];
@@ -741,10 +830,10 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         d_rowtie = (nLprev == 0 && __ballot(rt != 0) != 0ull) ? 1 : 0;
         if (nLprev > 0) {
             // owners store the refreshed rows (read back only by the owner's later arg-mins)
-            if (tid < nLprev && (Lprev[tid] % G) == g) {
+            if (tid < nLprev && own(Lprev[tid])) {
                 const int x = Lprev[tid]; const Min2 q = s_row[tid];
                 const double qv = (q.i < 0) ? (double)INFINITY : q.v;
-                const int px = pos[x / G];
+                const int px = slot(x);
                 l_nb[px] = q.i; l_md[px] = qv; l_md2[px] = (q.i < 0) ? (double)INFINITY : q.v2; l_fr[px] = 1;
                 STX<ONEX>(&nb[x], q.i); STX<ONEX>(&md[x], qv);
             }
@@ -799,6 +888,13 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
 
     // ---- initial state: exact bounds from k_row_nn; owned rows g, g+G, ...
     int cnt0 = 0;
+    if constexpr (SQ) {
+        for (int i2 = tid; i2 < nown; i2 += T) {
+            const int z = z0 + i2;
+            l_ty[i2] = -1;
+            l_md[i2] = z < n - 1 ? md[z] : (double)INFINITY; l_md2[i2] = z < n - 1 ? md2_init[z] : (double)INFINITY; l_nb[i2] = z < n - 1 ? nb[z] : -1; l_fr[i2] = 1;
+        }
+    } else
     for (int z = g + G * tid, i2 = tid; z < n; z += G * T, i2 += T) {
         act[i2] = z; pos[i2] = i2;
         l_md[i2] = z < n - 1 ? md[z] : (double)INFINITY; l_md2[i2] = z < n - 1 ? md2_init[z] : (double)INFINITY; l_nb[i2] = z < n - 1 ? nb[z] : -1; l_fr[i2] = 1;
@@ -817,9 +913,11 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     int x = best.i, y = best.y; double dist = best.v; bool fresh = (best.fresh & 1) != 0;
     // cluster sizes of the pair about to merge, requested as soon as the pair is known (an L2 round trip off the merge's serial path)
     int nx_pre = 0, ny_pre = 0, cx_pre = 0, cy_pre = 0;            // (workgroup 0's first thread also needs the pair's dendrogram ids)
+    int tx_pre = -1, ty_pre = -1;                                  // SQ: last merge that rewrote row x / row y
     auto prefetch_pair = [&]() {
         if (fresh && y >= 0) {
             nx_pre = size[x]; ny_pre = size[y];
+            if constexpr (SQ) { tx_pre = tyv[x]; ty_pre = tyv[y]; }
             if (g == 0 && tid == 0) { cx_pre = cid[x]; cy_pre = cid[y]; }
         }
     };
@@ -862,25 +960,27 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         // No workgroup barrier in front of the pass: the pair is in every thread's registers, the pass skips x and y by value, and x
         // leaves its owner's active list -- and the pair's sizes change in this workgroup's private size[] -- only behind the pass
         // (below): a slower wave may still be loading size[x] / size[y] in prefetch_pair when thread 0 gets here.
-        if (tid == 0) {
-            if (g == 0) {
+        auto write_Z = [&]() {                             // (behind the pass: thread 0 must not wait for the pair's ids before it issues its loads)
+            if (tid == 0 && g == 0) {
                 int ix = cx_pre, iy = cy_pre;
                 if (ix > iy) { const int t = ix; ix = iy; iy = t; }
                 Z[(size_t)k * 4 + 0] = (double)ix; Z[(size_t)k * 4 + 1] = (double)iy;
                 Z[(size_t)k * 4 + 2] = dist;       Z[(size_t)k * 4 + 3] = (double)(nx + ny);
                 cid[y] = n + k;
             }
-        }
-        if (k == n - 2) break;
+        };
+        if (k == n - 2) { write_Z(); break; }
         // ---- one pass over the owned active rows: Lance-Williams update + neighbour patches (cl.cpp:361-392),
         // NN(y) partial from the fresh distances (cl.cpp:395-404), next local arg-min
         STAMP2(5);
         Min2 q = none2;
         Cand m; m.v = INFINITY; m.i = -1; m.y = -1; m.fresh = 0;
         int row_tie = 0;
-        const int cnt = s_cnt;
+        const int cnt = SQ ? nown : s_cnt;
+        const int txm = tx_pre, tym = ty_pre;             // SQ: ty of the pair before this merge
         int zdummy = 0;                                   // any valid row other than x and y (n >= 3 here)
         while (zdummy == x || zdummy == y) ++zdummy;
+        if (SQ) { zdummy = z0; while ((zdummy == x || zdummy == y) && zdummy + 1 < z0 + (nown > 0 ? nown : 1)) ++zdummy; }   // (an own column: its l_ty slot exists)
         for (int p0 = tid; p0 < cnt; p0 += T * 4) {
             double dzx[4], dzy[4], mdz[4], md2z[4]; int zz[4], nbz[4], frz[4], pp[4]; int64_t izy[4];
 #pragma unroll
@@ -888,14 +988,33 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                 const int p = p0 + u * T;
                 const int pc = p < cnt ? p : 0;
                 pp[u] = pc;
-                int z = p < cnt ? act[pc] : -1;
+                frz[u] = l_fr[pc];
+                int z = p < cnt ? (SQ ? ((frz[u] & 2) ? -1 : z0 + pc) : act[pc]) : -1;
                 if (z == y || z == x) z = -1;
                 zz[u] = z;
                 const int zc = z >= 0 ? z : zdummy;
-                izy[u] = cidx(N, zc, y);
-                dzx[u] = LDG(&D[cidx(N, zc, x)]);
-                dzy[u] = LDG(&D[izy[u]]);
-                nbz[u] = l_nb[pc]; mdz[u] = l_md[pc]; md2z[u] = l_md2[pc]; frz[u] = l_fr[pc];
+                if constexpr (SQ) {
+                    // the current value of {z, x} / {z, y} lives in the row of the cluster whose row was written last (row y is written
+                    // below).  The row copies are requested at once, before the pair's ty have arrived (prefetch_pair's loads are still
+                    // in flight): on clustered data they are the right ones for all but a handful of entries, fixed up below.
+                    izy[u] = (int64_t)y * N + zc;
+                    dzx[u] = LDG(&D[(int64_t)x * N + zc]);
+                    dzy[u] = LDG(&D[izy[u]]);
+                } else {
+                    izy[u] = cidx(N, zc, y);
+                    dzx[u] = LDG(&D[cidx(N, zc, x)]);
+                    dzy[u] = LDG(&D[izy[u]]);
+                }
+                nbz[u] = l_nb[pc]; mdz[u] = l_md[pc]; md2z[u] = l_md2[pc];
+            }
+            if constexpr (SQ) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (zz[u] < 0) continue;
+                    const int tz = l_ty[zz[u] - z0];
+                    if (txm < tz) dzx[u] = LDG(&D[(int64_t)zz[u] * N + x]);        // z's row was written after x's: the current {z, x} is there
+                    if (tym < tz) dzy[u] = LDG(&D[(int64_t)zz[u] * N + y]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -927,7 +1046,15 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         STAMP2(6);
         block_min_qc(q, m, sh, shc, NW);
         row_tie = __syncthreads_or(row_tie);
+        write_Z();
         if (tid == 0) { size[x] = 0; size[y] = nx + ny; }     // (every thread is past the pass and has used the old sizes)
+        if constexpr (SQ) {
+            if (tid == 0) {
+                tyv[y] = k;                                   // row y is the current copy of every {y, z} from now on
+                if (own(y)) l_ty[y - z0] = k;
+                if (own(x)) l_fr[x - z0] = 2;                 // column x is gone
+            }
+        } else
         if (tid == 0 && (x % G) == g) {                       // owner drops x from its active list
             const int p = pos[x / G], c2 = s_cnt - 1, last = act[c2];
             act[p] = last; pos[last / G] = p; s_cnt = c2;
@@ -949,10 +1076,10 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
             if (nn.i >= 0) {
                 cy.v = nn.v; cy.i = y; cy.y = nn.i; cy.fresh = 1;
                 // (lane 0 of EVERY wave writes the same values: the next pass starts without a workgroup barrier, and a wave reads LDS behind its own writes)
-                if (lane == 0 && (y % G) == g) { const int py = pos[y / G]; l_nb[py] = nn.i; l_md[py] = nn.v; l_md2[py] = nn.v2; l_fr[py] = 1; if (tid == 0) { STX<ONEX>(&nb[y], nn.i); STX<ONEX>(&md[y], nn.v); } }
+                if (lane == 0 && own(y)) { const int py = slot(y); l_nb[py] = nn.i; l_md[py] = nn.v; l_md2[py] = nn.v2; l_fr[py] = 1; if (tid == 0) { STX<ONEX>(&nb[y], nn.i); STX<ONEX>(&md[y], nn.v); } }
             } else {
                 cy.v = LDG(&md[y]); cy.i = y; cy.y = LDG(&nb[y]); cy.fresh = 0;
-                if (lane == 0 && (y % G) == g) l_fr[pos[y / G]] = 0;
+                if (lane == 0 && own(y)) l_fr[slot(y)] = 0;
             }
             best = cbetter(best, cy);
             __builtin_amdgcn_wave_barrier();       // keep the LDS stores above in front of the next pass's LDS loads in the instruction stream
@@ -1008,13 +1135,14 @@ __global__ void k_fill_i32(int* p, int v, int64_t n, int iota)
 //   above: k_linkage_mw on G co-resident workgroups (cooperative launch: the runtime guarantees residency or refuses).  It
 //   takes a merge from its parallel arg-min only while the closest pair is unique; at the first exact tie (duplicate
 //   embeddings), on a refused launch or on a poll timeout the distance matrix is rebuilt and k_linkage_heap does the job.
-static int linkage_prepare(sd_ctx* c, const double* d_X, int64_t N, int d, double* D, int* size, int* cid, int* nb, double* md, double* md2)
+static int linkage_prepare(sd_ctx* c, const double* d_X, int64_t N, int d, double* D, int* size, int* cid, int* nb, double* md, double* md2, bool square = false)
 {
     const int64_t m = N * (N - 1) / 2;
     const int tiles = (int)((N + PT - 1) / PT);
     {
-        ProfScope ps(c, "pdist", (double)m * d * 3.0, (double)m * 8.0 + (double)N * d * 8.0);
-        hipLaunchKernelGGL(k_pdist, dim3(tiles, tiles), dim3(256), 0, c->stream, d_X, N, d, D);
+        ProfScope ps(c, "pdist", (double)m * d * 3.0, (double)m * 8.0 * (square ? 2 : 1) + (double)N * d * 8.0);
+        if (square) hipLaunchKernelGGL(k_pdist_sq, dim3(tiles, tiles), dim3(256), 0, c->stream, d_X, N, d, D);
+        else hipLaunchKernelGGL(k_pdist, dim3(tiles, tiles), dim3(256), 0, c->stream, d_X, N, d, D);
         KCHECK(c);
     }
     hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, size, 1, N, 0);
@@ -1022,7 +1150,7 @@ static int linkage_prepare(sd_ctx* c, const double* d_X, int64_t N, int d, doubl
     KCHECK(c);
     {
         ProfScope ps(c, "row_nn", 0, (double)m * 8.0);
-        hipLaunchKernelGGL(k_row_nn, dim3((unsigned)((N - 1 + 3) / 4)), dim3(256), 0, c->stream, D, N, nb, md, md2);
+        hipLaunchKernelGGL(k_row_nn, dim3((unsigned)((N - 1 + 3) / 4)), dim3(256), 0, c->stream, D, N, nb, md, md2, square ? 1 : 0);
         KCHECK(c);
     }
     return SD_OK;
@@ -1043,39 +1171,54 @@ static int linkage_heap(sd_ctx* c, int64_t N, double* D, int* size, int* cid, in
     return SD_OK;
 }
 
+// per-workgroup private copies for k_linkage_mw: [G][n] sizes (all 1); square form: [G][2 n] = sizes (1) followed by ty (-1)
+__global__ void k_fill_size_ty(int* p, int64_t n, int64_t total, int with_ty)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) p[i] = (with_ty && ((i / n) & 1)) ? -1 : 1;
+}
+
 int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
 {
     if (N < 2) return SD_OK;
     const int64_t m = N * (N - 1) / 2;
     if (N > 0x7fffffff / 4 || (double)m * 8.0 > 230e9) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs a %.0f GB condensed matrix (limit 230 GB)", (long long)N, (double)m * 8e-9);
-    WS(c, double, D, "cl_D", m);
     WS(c, int, size, "cl_size", N);
     WS(c, int, cid, "cl_cid", N);
     WS(c, int, nb, "cl_nb", N);
     WS(c, double, md, "cl_md", N);
     WS(c, double, md2, "cl_md2", N);
     int rc;
-    if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2))) return rc;
     int G = (int)c->linkage_wgs;
-    // auto geometry (measured on clustered data, profiles/r01_linkage_scaling.txt, r02_linkage_stamps.txt): up to N = 30 000 the
-    // one-XCD form with one workgroup on each of the XCD's 32 CUs (172 ms at N = 12 602; all XCDs: 188 ms with 64 x 512)
+    // auto geometry (measured on clustered data, profiles/r01_linkage_scaling.txt, r02_linkage_stamps.txt, r03_linkage_*.txt): up to N = 30 000
+    // the one-XCD form with one workgroup on each of the XCD's 32 CUs; above, all XCDs
     const bool auto_onex = G < 0 && c->linkage_one_xcd != 0 && c->num_cu >= 256 && N >= 1500 && N < 30000;
     if (auto_onex) G = 32;
     if (G < 0) G = N >= 60000 ? 128 : N >= 8000 ? 64 : N >= 1500 ? 32 : 0;
     if (G > c->num_cu) G = c->num_cu;
     int TH = (int)c->linkage_threads;
-    if (TH <= 0) TH = auto_onex ? 256 : N >= 8000 ? 512 : 256;        // measured (r03, two-level bounds): one XCD 32 x 256 75 ms, x 512 84 ms at N = 12 602; all XCDs 128 x 512 1.26 s at N = 100 174
+    if (TH <= 0) TH = N >= 8000 ? 512 : 256;          // measured (r03, square form, three runs each): one XCD 32 x 512 77.2 ms, 32 x 256 82.7 ms at N = 12 602 (condensed: 80.5 / 86.8); all XCDs 128 x 512 0.99 s at N = 100 174
     TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : TH >= 256 ? 256 : 128;
-    if (G <= 1) return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
+    if (G <= 1) {
+        WS(c, double, D, "cl_D", m);
+        if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2))) return rc;
+        return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
+    }
     if ((N + G - 1) / G > 3000) G = (int)((N + 2999) / 3000);      // active-row lists and bounds live in LDS: 32 B per owned row
     if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
     int cap = (int)((N + G - 1) / G) + 1;
+    // square form (full N x N matrix, row-only bulk accesses) while the square fits beside everything else; the condensed form above that
+    const bool square = c->linkage_square < 0 ? (double)N * (double)N * 8.0 <= 170e9 : c->linkage_square != 0;
+    double* D = nullptr;
+    if (square) { WS(c, double, Dq, "cl_Dsq", N * N); D = Dq; } else { WS(c, double, Dc, "cl_D", m); D = Dc; }
+    if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2, square))) return rc;
     // one-XCD form while two workgroups per CU of one XCD (32 CUs) can hold the job; above, all XCDs' memory pipelines are worth more
     bool onex = c->linkage_one_xcd != 0 && G <= 32 && c->num_cu >= 256;
     WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * SLOT_WORDS);
     HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * SLOT_WORDS * sizeof(MwGran), c->stream));
-    WS(c, int, size_all, "cl_size_all", (int64_t)G * N);
-    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)(((int64_t)G * N + 255) / 256)), dim3(256), 0, c->stream, size_all, 1, (int64_t)G * N, 0);
+    const int64_t priv = (int64_t)G * N * (square ? 2 : 1);
+    WS(c, int, size_all, "cl_size_all", priv);
+    hipLaunchKernelGGL(k_fill_size_ty, dim3((unsigned)((priv + 255) / 256)), dim3(256), 0, c->stream, size_all, N, priv, square ? 1 : 0);
     KCHECK(c);
     WS(c, unsigned, sync, "cl_sync", 16);
     HIPCHK(c, hipMemsetAsync(sync, 0, 16 * sizeof(unsigned), c->stream));
@@ -1086,16 +1229,18 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         void* args[] = {&D, &n_i, &size_all, &cid, &nb, &md, &md2, &d_Z, &gran, &sync, &cap, &G};
         // cooperative launch: all workgroups are resident together, or the launch is refused (they poll each other's slots)
         hipError_t le = hipErrorUnknown;
+        const void* f_one = square ? (const void*)k_linkage_mw<true, true> : (const void*)k_linkage_mw<true, false>;
+        const void* f_all = square ? (const void*)k_linkage_mw<false, true> : (const void*)k_linkage_mw<false, false>;
         if ((size_t)cap * 32 > 48 * 1024) {          // the row lists of a hand-set geometry may pass the default dynamic-LDS limit
-            (void)hipFuncSetAttribute((const void*)k_linkage_mw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 32);
-            (void)hipFuncSetAttribute((const void*)k_linkage_mw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 32);
+            (void)hipFuncSetAttribute(f_one, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 32);
+            (void)hipFuncSetAttribute(f_all, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 32);
             (void)hipGetLastError();
         }
         if (onex) {
-            le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<true>, dim3(8 * G), dim3(TH), args, (size_t)cap * 32, c->stream);
+            le = hipLaunchCooperativeKernel(f_one, dim3(8 * G), dim3(TH), args, (size_t)cap * 32, c->stream);
             if (le != hipSuccess) { (void)hipGetLastError(); onex = false; }
         }
-        if (!onex) le = hipLaunchCooperativeKernel((const void*)k_linkage_mw<false>, dim3(G), dim3(TH), args, (size_t)cap * 32, c->stream);
+        if (!onex) le = hipLaunchCooperativeKernel(f_all, dim3(G), dim3(TH), args, (size_t)cap * 32, c->stream);
         if (le != hipSuccess) { (void)hipGetLastError(); why = "cooperative launch refused"; }
     }
     unsigned h[16] = {0};
@@ -1119,8 +1264,9 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     if (!why) return SD_OK;
     c->stats["linkage_fallbacks"].launches += 1;
     if (c->profile_detail) fprintf(stderr, "linkage: %s at N = %lld -> k_linkage_heap\n", why, (long long)N);
-    if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2))) return rc;
-    return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
+    WS(c, double, Dh, "cl_D", m);                          // the heap kernel works on the condensed matrix
+    if ((rc = linkage_prepare(c, d_X, N, d, Dh, size, cid, nb, md, md2))) return rc;
+    return linkage_heap(c, N, Dh, size, cid, nb, md, d_Z);
 }
 
 // fcluster(criterion="distance"), cl.cpp:121-232 + 442-457.  Node ids grow with merge order, so the

@@ -25,7 +25,9 @@ if os.environ.get("REF"):          # REF=1: the single-workgroup kernel that rep
     t0 = time.time(); Z0 = d.linkage(X); print("k_linkage_heap reference: %.1f s" % (time.time() - t0), flush=True)
 onex = int(os.environ.get("ONEX", "1"))
 d.set_option("linkage_one_xcd", onex)
-print("linkage_one_xcd", onex)
+sq = int(os.environ.get("SQ", "-1"))
+d.set_option("linkage_square", sq)
+print("linkage_one_xcd", onex, "linkage_square", sq)
 for G, T in combos:
     d.set_option("linkage_wgs", G); d.set_option("linkage_threads", T)
     d.reset_stats()
