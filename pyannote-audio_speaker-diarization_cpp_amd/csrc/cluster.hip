@@ -1204,7 +1204,7 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2))) return rc;
         return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
     }
-    if ((N + G - 1) / G > 3000) G = (int)((N + 2999) / 3000);      // active-row lists and bounds live in LDS: 32 B per owned row
+    if ((N + G - 1) / G > 3400) G = (int)((N + 3399) / 3400);      // active-row lists and bounds live in LDS: 32 B per owned row (109 KB + 43 KB static)
     if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
     int cap = (int)((N + G - 1) / G) + 1;
     // square form (full N x N matrix, row-only bulk accesses) while the square fits beside everything else; the condensed form above that
