@@ -103,6 +103,79 @@ def balanced_rank0_permille(infer_ms, chunks, finalize_ms, C, world):
     return int(round(1000 * s0)), rate
 
 
+class ControlPlaneStandIn:
+    """`--dry-run-control-plane`: stands in for sdhip.Diarizer so that everything AROUND the library in a multi-rank run -- self-launch,
+    rendezvous, the union of chunk ranges, the measured rank-0 share and the re-plan, barriers, max over ranks, assembly of the result line --
+    can run on a box without GPUs (tests/test_distributed_cpu.py).  It does no diarization: a call checks, exactly as the library does, that
+    the samples it is handed cover the rank's chunk range under the plan in force (the real sd_shard_plan), sleeps for a time proportional to
+    its chunks (rank 0 also for a finalize that grows with the job), and meets the other ranks in a gloo all-reduce where the library has its
+    RCCL all-gather.  The line it leads to says "dry-run" in `metric` and `data` and can never be mistaken for a measurement."""
+
+    def __init__(self, rank, world, dist, plan, num_chunks):
+        self.rank, self.world, self.dist, self.plan, self.num_chunks = rank, world, dist, plan, num_chunks
+        self.opt = {"rank0_permille": -1}
+        self.st = [0.0, 0.0, 0.0, 0.0]
+        self.jobs = 0
+        self.comm = 0
+
+    def set_option(self, k, v):
+        self.opt[k] = int(v)
+
+    def set_planted(self, *a):
+        pass
+
+    def comm_init(self, ident, rank, world):
+        assert len(ident) == 128 and rank == self.rank and world == self.world
+        self.comm = world
+
+    def comm_info(self):
+        return self.rank, self.comm
+
+    def diarize_sharded_dev(self, ptr, first, samples, n_total):
+        import torch
+        C, _ = self.num_chunks(n_total)
+        per, ranges = self.plan(n_total, self.world, self.opt["rank0_permille"])
+        lo, hi = ranges[self.rank]
+        t0 = time.perf_counter()
+        if hi > lo:
+            need_lo, need_hi = lo * 8000, min(n_total, (hi - 1) * 8000 + 80000)
+            if not ptr or first > need_lo or first + samples < need_hi:
+                raise RuntimeError("rank %d: samples [%d,%d) do not cover chunks [%d,%d)" % (self.rank, first, first + samples, lo, hi))
+            time.sleep(2e-5 * (hi - lo))
+        t1 = time.perf_counter()
+        flag = torch.zeros(1, dtype=torch.float64)
+        if self.world > 1:
+            self.dist.all_reduce(flag)                       # where the library has its all-gather
+        fin = 0.0
+        if self.rank == 0:
+            time.sleep(4e-6 * C)
+            fin = 4e-3 * C
+        self.st = [0.3 * (t1 - t0) * 1e3, 0.7 * (t1 - t0) * 1e3, fin, (time.perf_counter() - t0) * 1e3]
+        self.jobs += 1
+        return [(0.5, 1.5, 0), (2.0, 3.0, 1)] if self.rank == 0 else []
+
+    def diarize_dev(self, ptr, n_total):
+        return self.diarize_sharded_dev(ptr, 0, n_total, n_total)
+
+    def diarize(self, pcm):
+        return self.diarize_sharded_dev(1, 0, len(pcm), len(pcm))
+
+    def stage_ms(self):
+        return list(self.st)
+
+    def kernel_stats(self, name):
+        return {"ms": 1.0 * self.jobs, "launches": self.jobs, "flops": 1e9 * self.jobs, "bytes": 1e6 * self.jobs}
+
+    def reset_stats(self):
+        self.jobs = 0
+
+    def read_ws(self, name, dtype, count, offset=0):
+        return np.ones(count, dtype)
+
+    def close(self):
+        pass
+
+
 def self_launch(n):
     """`python bench.py --gpus N` (no torchrun): start N ranks as child processes of this one, which never touches the GPU.
     stdout of rank 0 is relayed (the JSON line); every rank's stderr goes to this process's stderr with a rank prefix.  The first
@@ -194,6 +267,8 @@ def main():
                     "shares and its stage times give the balance point; 1/N = equal shares, 0 = rank 0 only finalizes")
     ap.add_argument("--fp16-steps", type=int, default=3, help="N = 1, f32 run: also time this many steps in fp16 mode (BASELINE configs[4]) and put them, with the "
                     "cosine distances of the fp16 embeddings to the f32 ones, into the `fp16` object of the result line (0 = skip)")
+    ap.add_argument("--dry-run-control-plane", action="store_true", help="no GPU work: a stand-in for the library (ControlPlaneStandIn) lets the multi-rank control "
+                    "flow of this script run on a box without GPUs; the line says dry-run and is not a measurement")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL communicator inside the library, "
                     "all-gather, assembly) even with one rank")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (sd_set_option), e.g. emb_batch_items=1536; tuning only")
@@ -211,15 +286,21 @@ def main():
     if world != a.gpus:
         # a line whose n_gpus is not what was asked for would be mistaken for the N-GPU number
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to measure a different job than the one asked for" % (a.gpus, world))
-    ndev = torch.cuda.device_count()                 # (counting devices does not initialise the GPU)
-    if ndev <= 0:
-        raise SystemExit("bench.py rank %d: needs a GPU: libsdhip has no CPU fallback" % rank)
-    if local >= ndev:
-        raise SystemExit("bench.py rank %d: LOCAL_RANK %d but this node has %d GPU%s" % (rank, local, ndev, "" if ndev == 1 else "s"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py rank %d: needs a GPU: libsdhip has no CPU fallback" % rank)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dry = a.dry_run_control_plane
+    gpu_sync = (lambda: None) if dry else torch.cuda.synchronize
+    if dry:
+        dev = torch.device("cpu")
+        a.cpu_seconds, a.fp16_steps = 0, 0
+    else:
+        ndev = torch.cuda.device_count()                 # (counting devices does not initialise the GPU)
+        if ndev <= 0:
+            raise SystemExit("bench.py rank %d: needs a GPU: libsdhip has no CPU fallback" % rank)
+        if local >= ndev:
+            raise SystemExit("bench.py rank %d: LOCAL_RANK %d but this node has %d GPU%s" % (rank, local, ndev, "" if ndev == 1 else "s"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py rank %d: needs a GPU: libsdhip has no CPU fallback" % rank)
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     use_dist = world > 1 or a.force_dist
     dist = None
     if world > 1:
@@ -278,21 +359,22 @@ def main():
         d_ps, d_pe = torch.from_numpy(p_scores).to(dev), torch.from_numpy(p_emb).to(dev)
 
     # ---- cold start: context creation (weights -> HBM), PCM upload, first job with cold workspaces
-    torch.cuda.synchronize()
+    gpu_sync()
     t_cold = time.perf_counter()
-    d = sdhip.Diarizer(os.path.join(tmp, "segment.sdw"), os.path.join(tmp, "embedding.sdw"), local)
+    d = (ControlPlaneStandIn(rank, world, dist, sdhip.shard_plan, sdhip.num_chunks) if dry else
+         sdhip.Diarizer(os.path.join(tmp, "segment.sdw"), os.path.join(tmp, "embedding.sdw"), local))
     if a.precision == "f16":
         d.set_option("ecapa_precision", 1)
     for kv in a.opt:
         k, v = kv.split("=")
         d.set_option(k, int(v))
     d_pcm = torch.from_numpy(pcm_host).to(dev)
-    torch.cuda.synchronize()
+    gpu_sync()
     if planted and hi > lo:
         d.set_planted(d_ps.data_ptr(), d_pe.data_ptr(), lo, hi - lo)
     if use_dist:
         if rank == 0:
-            ident = [sdhip.comm_unique_id()]
+            ident = [bytes(128) if dry else sdhip.comm_unique_id()]
         else:
             ident = [None]
         if world > 1:
@@ -312,10 +394,10 @@ def main():
             turns_box[0] = d.diarize_dev(d_pcm.data_ptr(), n_total)
 
     def fence():
-        torch.cuda.synchronize()
+        gpu_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        gpu_sync()
 
     step()
     fence()
@@ -411,7 +493,7 @@ def main():
         d.set_option("profile", 0)
         ts = []
         for _ in range(2):
-            torch.cuda.synchronize()
+            gpu_sync()
             t1 = time.perf_counter()
             th = d.diarize(pcm_host[:n_total])
             ts.append(time.perf_counter() - t1)
@@ -479,13 +561,13 @@ def main():
             except Exception:
                 pass
         out = {
-            "metric": "real-time factor (audio-sec/wall-sec), %g h 16 kHz mono per GPU" % a.hours_per_gpu,
+            "metric": ("DRY-RUN of the control plane, not a measurement: " if dry else "") + "real-time factor (audio-sec/wall-sec), %g h 16 kHz mono per GPU" % a.hours_per_gpu,
             "value": round(audio_s / (ms_per_step / 1e3), 2),
             "unit": "x real-time",
             "n_gpus": world, "rccl_ranks": d.comm_info()[1], "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.precision, "data": "synthetic",
+            "dtype": a.precision, "data": "dry-run (stand-in for the library, no GPU work)" if dry else "synthetic",
             "config": {"workload": "%g h synthetic 16 kHz mono per GPU (%g h total), full pipeline: PyanNet segmentation + post-seg + STFT/fbank + "
                                    "ECAPA-TDNN + centroid AHC + reconstruction; %s" % (a.hours_per_gpu, audio_s / HOUR,
                                    "planted multi-speaker workload (SURVEY 8d): both networks run at full cost, then their outputs are replaced by the scores / "

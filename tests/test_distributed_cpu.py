@@ -149,3 +149,29 @@ def test_bench_balanced_rank0_share():
     s0, T = pm / 1000.0, 9600.0
     assert abs((s0 * T + 600.0) - (1 - s0) * T / 7) < 0.02 * T / 8 and abs(rate - 9600.0 / C) < 1e-9
     assert bm.balanced_rank0_permille([1200.0, 1200.0], [C / 2.0] * 2, 135.0, C, 2)[0] == 472
+
+
+def test_bench_multi_rank_control_flow_dry_run():
+    """everything AROUND the library in a `bench.py --gpus N` run -- self-launch of N ranks, gloo rendezvous, the hull of chunk ranges every
+    rank synthesises, the rank-0 share measured on a warm job and the re-plan (with the library's own sd_shard_plan and its coverage check),
+    barriers, max over ranks, the single-job pass, assembly and relay of the one result line -- runs here without GPUs against a stand-in for
+    the library (bench.py --dry-run-control-plane).  No 8-GPU box was available to the builder: this is what protects the first real run
+    from a mistake in that code.  The line is marked as a dry run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for n, extra in ((3, []), (2, ["--rank0-share", "0.25"])):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--dry-run-control-plane", "--hours-per-gpu", "0.05",
+                              "--steps", "2", "--warmup", "1"] + extra, capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == n and j["rccl_ranks"] == n and j["metric"].startswith("DRY-RUN") and "dry-run" in j["data"]
+        assert j["config"]["single_job_ms"] > 0 and j["value"] > 0 and j["scaling"] == "weak"
+        if not extra:
+            assert "measured on a warm job" in j["config"]["rank0_share"]
+        else:
+            assert j["config"]["rank0_share"] is None and "[(0, 192), (192, 711)]" in j["config"]["sharding"]     # 25 % of 711 chunks, rounded to 32
