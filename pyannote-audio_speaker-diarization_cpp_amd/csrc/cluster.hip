@@ -1208,9 +1208,13 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
     int cap = (int)((N + G - 1) / G) + 1;
     // square form (full N x N matrix, row-only bulk accesses) while the square fits beside everything else; the condensed form above that
-    const bool square = c->linkage_square < 0 ? (double)N * (double)N * 8.0 <= 170e9 : c->linkage_square != 0;
+    bool square = c->linkage_square < 0 ? (double)N * (double)N * 8.0 <= 170e9 : c->linkage_square != 0;
     double* D = nullptr;
-    if (square) { WS(c, double, Dq, "cl_Dsq", N * N); D = Dq; } else { WS(c, double, Dc, "cl_D", m); D = Dc; }
+    if (square) {
+        D = ws_get<double>(c, "cl_Dsq", (size_t)N * N);
+        if (!D) { (void)hipGetLastError(); square = false; c->stats["linkage_square_alloc_failed"].launches += 1; }      // no room for the square: the condensed form needs half
+    }
+    if (!square) { WS(c, double, Dc, "cl_D", m); D = Dc; }
     if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2, square))) return rc;
     // one-XCD form while two workgroups per CU of one XCD (32 CUs) can hold the job; above, all XCDs' memory pipelines are worth more
     bool onex = c->linkage_one_xcd != 0 && G <= 32 && c->num_cu >= 256;
