@@ -64,17 +64,6 @@ template <class T> __global__ void k_se_apply(const T* __restrict__ t2, int t2_l
     st4(y + orow * y_ld + c, o);
 }
 
-// copy a channel slice [rows][w] between strided buffers (Res2Net first sub-band is identity)
-template <class T> __global__ void k_copy_slice(const T* __restrict__ src, int src_ld, T* __restrict__ dst, int dst_ld, int w, int64_t rows)
-{
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int w4 = w / 4;
-    if (idx >= rows * w4) return;
-    const int64_t row = idx / w4;
-    const int c = (int)(idx - row * w4) * 4;
-    *(typename Vec4<T>::type*)(dst + row * dst_ld + c) = *(const typename Vec4<T>::type*)(src + row * src_ld + c);
-}
-
 // ASP global-context statistics: mean / std over valid frames -> ms[item][2C]
 // one pass (Welford) with 4 rows in flight per thread: the tensor is read once
 template <class T> __global__ void k_asp_stats(const T* __restrict__ x, int ld, const int* __restrict__ nvalid, const int* __restrict__ rowoff, int row_base,
@@ -230,8 +219,12 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
     const int64_t M = R[0], MN = R[3];
     if (M > 0x7fffffff / 2) SD_FAIL(c, SD_ERR_ARG, "ecapa batch too large");
     WS(c, T, x0, "ec_x0", M * LD);
-    WS(c, T, t1, "ec_t1", M * LD);
-    WS(c, T, rr, "ec_r", M * LD);
+    // tdnn1 output and Res2Net chain of a block in ONE row: [t1 sub-bands 1..7 | t1 sub-band 0 | r1 .. r7] (tdnn1's output channels are
+    // rotated by one sub-band at weight-build time, weights.cpp).  Res2Net conv i reads t1_i at (i-1)*S and r_(i-1) at C + (i-2)*S and
+    // writes r_i at C + (i-1)*S; tdnn2's input -- sub-band 0 of tdnn1 as it is, then r1..r7 (the Res2Net block's identity branch) -- is the
+    // K-contiguous slice at C - S: no copy of the identity sub-band.
+    const int LDT = 2 * C - C / 8 + c->ecapa_ld_pad;
+    WS(c, T, tr, "ec_tr", M * LDT);
     WS(c, T, t2, "ec_t2", R[1] * LD);
     WS(c, T, cat, "ec_cat", R[1] * LD3);
     WS(c, T, mfa, "ec_mfa", MN * LD3);
@@ -274,18 +267,16 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
         const T* xin = (b == 0) ? x0 : cat + (size_t)(b - 1) * C;
         const int xin_ld = (b == 0) ? LD : LD3;
         TAB(t_in, cs, is); TAB(t_cc, cs, cs); TAB(t_oc, os, cs);
-        { ConvArgs a = conv_args(B.tdnn1, xin, xin_ld, t1, LD, Mc, true, P); a.act1 = 1; a.rowtab = t_in; a.in_rows = (int)R[is]; if ((rc = launch_conv_gemm(c, a, "tdnn1"))) return rc; }
+        { ConvArgs a = conv_args(B.tdnn1, xin, xin_ld, tr, LDT, Mc, true, P); a.act1 = 1; a.rowtab = t_in; a.in_rows = (int)R[is]; if ((rc = launch_conv_gemm(c, a, "tdnn1"))) return rc; }
         const int S = C / 8;
-        hipLaunchKernelGGL(k_copy_slice<T>, GRID1(Mc * (S / 4)), 0, st, t1, LD, rr, LD, S, Mc);
-        KCHECK(c);
         for (int i = 1; i < 8; ++i) {
-            ConvArgs a = conv_args(B.res[i - 1], t1 + i * S, LD, rr + i * S, LD, Mc, true, P);
+            ConvArgs a = conv_args(B.res[i - 1], tr + (i - 1) * S, LDT, tr + C + (i - 1) * S, LDT, Mc, true, P);
             a.act1 = 1;
-            if (i >= 2) { a.X2 = (const float*)(rr + (i - 1) * S); a.x2_ld = LD; }
+            if (i >= 2) { a.X2 = (const float*)(tr + C + (i - 2) * S); a.x2_ld = LDT; }
             a.rowtab = t_cc;
             if ((rc = launch_conv_gemm(c, a, "res2net"))) return rc;
         }
-        { ConvArgs a = conv_args(B.tdnn2, rr, LD, t2, LD, Mo, true, P); a.act1 = 1; a.rowtab = t_oc; a.in_rows = (int)Mc; if ((rc = launch_conv_gemm(c, a, "tdnn2"))) return rc; }
+        { ConvArgs a = conv_args(B.tdnn2, tr + C - S, LDT, t2, LD, Mo, true, P); a.act1 = 1; a.rowtab = t_oc; a.in_rows = (int)Mc; if ((rc = launch_conv_gemm(c, a, "tdnn2"))) return rc; }
         {
             ProfScope ps(c, "se_mean", 0, (double)Mo * C * 4.0);
             hipLaunchKernelGGL(k_masked_mean<T>, dim3((C + 255) / 256, (unsigned)items), dim3(256), 0, st, t2, LD, d_nvalid, ro[os], rbase[os], se_s, C);

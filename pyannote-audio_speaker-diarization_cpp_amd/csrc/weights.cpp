@@ -61,8 +61,10 @@ template <class T> static T* upload(sd_ctx* c, const std::vector<T>& h)
 // optional input-channel slice [ci0, ci0+cin) of the source tensor
 static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const std::string& bname,
                      const std::string& bnprefix, int dil, ConvLayer& L, int ci0 = 0, int cin = -1,
-                     const std::vector<float>* in_scale = nullptr, const std::vector<float>* in_shift = nullptr, bool want16 = false)
+                     const std::vector<float>* in_scale = nullptr, const std::vector<float>* in_shift = nullptr, bool want16 = false, int out_rot = 0)
 {
+    // out_rot: output channel o of the layer built here is channel (o + out_rot) mod Cout of the model's layer (a rotation of the
+    // output channels: ecapa.hip stores tdnn1's sub-band 0 LAST, next to the Res2Net outputs, so that tdnn2 reads one contiguous row)
     const PackTensor* w = need(c, p, wname);
     if (!w) return SD_ERR_MODEL;
     if (w->dims.size() < 2 || w->dims.size() > 3) SD_FAIL(c, SD_ERR_MODEL, "tensor '%s' has rank %zu (conv / linear weights are [Cout][Cin] or [Cout][Cin][K])", wname.c_str(), w->dims.size());
@@ -77,13 +79,13 @@ static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const s
     if (!bname.empty()) {
         const PackTensor* b = need(c, p, bname);
         if (!b) return SD_ERR_MODEL;
-        for (int o = 0; o < Cout; ++o) hb[o] = b->data[o];
+        for (int o = 0; o < Cout; ++o) hb[o] = b->data[(o + out_rot) % Cout];
         has_bias = true;
     }
     for (int o = 0; o < Cout; ++o)
         for (int i = 0; i < cin; ++i)
             for (int k = 0; k < K; ++k) {
-                float v = w->data[((size_t)o * CinAll + (ci0 + i)) * K + k];
+                float v = w->data[((size_t)((o + out_rot) % Cout) * CinAll + (ci0 + i)) * K + k];
                 if (in_scale) {           // fold an affine on the INPUT (BatchNorm before a 1x1 conv)
                     hb[o] += v * (*in_shift)[i];
                     v *= (*in_scale)[i];
@@ -119,8 +121,9 @@ static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const s
         if (!g || !be || !mu || !var) return SD_ERR_MODEL;
         std::vector<float> sc(Cout), sh(Cout);
         for (int o = 0; o < Cout; ++o) {
-            float s = g->data[o] / sqrtf(var->data[o] + 1e-5f);
-            sc[o] = s; sh[o] = be->data[o] - mu->data[o] * s;
+            const int so = (o + out_rot) % Cout;
+            float s = g->data[so] / sqrtf(var->data[so] + 1e-5f);
+            sc[o] = s; sh[o] = be->data[so] - mu->data[so] * s;
         }
         L.scale = upload(c, sc); L.shift = upload(c, sh);
         if (!L.scale || !L.shift) return SD_ERR_HIP;
@@ -171,7 +174,7 @@ int build_ecapa_weights(sd_ctx* c, const Pack& p)
         std::string pre = "blocks." + std::to_string(b + 1);
         auto& B = E.blk[b];
         B.dil = dils[b];
-        if ((rc = make_conv(c, p, pre + ".tdnn1.conv.weight", pre + ".tdnn1.conv.bias", pre + ".tdnn1.norm", 1, B.tdnn1, 0, -1, nullptr, nullptr, true))) return rc;
+        if ((rc = make_conv(c, p, pre + ".tdnn1.conv.weight", pre + ".tdnn1.conv.bias", pre + ".tdnn1.norm", 1, B.tdnn1, 0, -1, nullptr, nullptr, true, E.C / 8))) return rc;      // sub-bands 1..7 first, sub-band 0 last
         for (int i = 0; i < 7; ++i) {
             std::string q = pre + ".res2net." + std::to_string(i);
             if ((rc = make_conv(c, p, q + ".conv.weight", q + ".conv.bias", q + ".norm", dils[b], B.res[i], 0, -1, nullptr, nullptr, true))) return rc;

@@ -34,8 +34,10 @@ def grab(half):
     if not half:
         pass                                  # f32 mode: the logits overwrite cat -> the block outputs are gone; second run below
     out["cat"] = cat
-    for nm in ("t1", "r", "t2"):
-        out[nm] = d.read_ws("ec_" + nm, dt, n * 501 * 1024).reshape(n, 501, 1024).astype(np.float32)
+    tr = d.read_ws("ec_tr", dt, n * 501 * 1920).reshape(n, 501, 1920).astype(np.float32)      # [t1 sub-bands 1..7 | t1 sub-band 0 | r1..r7]
+    out["t1"] = np.concatenate([tr[:, :, 896:1024], tr[:, :, :896]], axis=2)
+    out["r"] = tr[:, :, 896:]
+    out["t2"] = d.read_ws("ec_t2", dt, n * 501 * 1024).reshape(n, 501, 1024).astype(np.float32)
     out["pooled"] = d.read_ws("ec_pooled", np.float32, n * 6144).reshape(n, 6144)
     out["se_g"] = d.read_ws("ec_se_g", np.float32, n * 1024).reshape(n, 1024)
     out["se_s"] = d.read_ws("ec_se_s", np.float32, n * 1024).reshape(n, 1024)
