@@ -2,6 +2,7 @@
 the same exporter the reference uses (torch.onnx.export, opset 17) from nn.Module forms of the two networks:
 every tensor it extracts must equal the weights that went in (LSTM gates re-ordered iofc -> ifgo)."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -424,3 +425,55 @@ def test_constant_folder_survives_malformed_nodes(tmp_path, case):
         with pytest.raises(sdhip.SdError) as e:
             sdhip.convert_onnx(str(path), kind, str(tmp_path / "x.sdw"))
         assert e.value.code == 3 and ("expected" in str(e.value) or "no MatMul" in str(e.value))        # SD_ERR_MODEL with a reason
+
+
+def test_onnx_reader_under_address_and_ub_sanitizers(onnx_files, tmp_path):
+    """the code that parses untrusted model files (protobuf reader, constant folder, layer extraction, weight-pack reader), built for
+    the CPU with AddressSanitizer + UBSan (tools/sanitize/build.sh) and run over: the malformed weight-shuffling graphs above, the two
+    valid exports, truncations of a valid export at 60 lengths and 300 single-byte corruptions of it.  No sanitizer report, no crash;
+    the valid files convert."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "onnx_convert_asan")
+    b = subprocess.run(["bash", os.path.join(root, "tools", "sanitize", "build.sh"), exe], capture_output=True, text=True, timeout=600)
+    if b.returncode != 0:
+        pytest.skip("sanitizer build not available here: " + b.stderr[-300:])
+    x = _tensor(b"x", [2, 3], floats=np.arange(6))
+    graphs = {
+        "perm_oob": ([_node(b"Transpose", [b"x"], [b"y"], _ints_attr(b"perm", [0, 5]))], [x]),
+        "perm_dup": ([_node(b"Transpose", [b"x"], [b"y"], _ints_attr(b"perm", [1, 1]))], [x]),
+        "unsq_dup": ([_node(b"Unsqueeze", [b"x", b"ax"], [b"y"])], [x, _tensor(b"ax", [3], ints=[0, 0, 1])]),
+        "concat_short": ([_node(b"Concat", [b"x", b"z"], [b"y"], _emit(5, 2, _emit(1, 2, b"axis") + _emit(3, 0, _varint(1)) + _emit(20, 0, _varint(2))))],
+                         [x, _tensor(b"z", [2, 300000], floats=np.arange(4))]),
+        "overflow": ([_node(b"Identity", [b"x"], [b"y"])], [_tensor(b"x", [1 << 40, 1 << 40], floats=np.arange(6))]),
+        "reshape2": ([_node(b"Reshape", [b"x", b"sh"], [b"y"])], [x, _tensor(b"sh", [2], ints=[-1, -1])]),
+        "squeeze_oob": ([_node(b"Squeeze", [b"x", b"ax"], [b"y"])], [x, _tensor(b"ax", [1], ints=[7])]),
+        "slice_oob": ([_node(b"Slice", [b"x", b"st", b"en", b"ax"], [b"y"])],
+                      [x, _tensor(b"st", [1], ints=[-100]), _tensor(b"en", [1], ints=[1 << 40]), _tensor(b"ax", [1], ints=[9])]),
+    }
+    paths = []
+    for k, (n, i) in graphs.items():
+        p = tmp_path / (k + ".onnx")
+        p.write_bytes(_model(n, i))
+        paths.append(str(p))
+    good = open(onnx_files[0], "rb").read()
+    rng = np.random.default_rng(5)
+    for j, ln in enumerate(sorted(set(int(v) for v in np.linspace(1, len(good) - 1, 60)))):
+        p = tmp_path / ("trunc%02d.onnx" % j)
+        p.write_bytes(good[:ln])
+        paths.append(str(p))
+    for j in range(300):
+        bad = bytearray(good)
+        pos = int(rng.integers(0, min(len(bad), 60000)))       # the graph structure sits in front of the big raw_data blobs
+        bad[pos] = int(rng.integers(0, 256))
+        p = tmp_path / ("flip%03d.onnx" % j)
+        p.write_bytes(bytes(bad))
+        paths.append(str(p))
+    paths += [onnx_files[0], onnx_files[1]]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([exe] + paths, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "Sanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
+    lines = out.stdout.splitlines()
+    assert len(re.findall(r" kind [01] -> \d", out.stdout)) == 2 * len(paths)               # (a corrupted tensor name may put a newline into a message)
+    assert lines[-4].endswith("kind 0 -> 0 ") and lines[-1].endswith("kind 1 -> 0 ")        # segment2.onnx as segmentation, emd4.onnx as embedding
