@@ -1197,7 +1197,9 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     if (G < 0) G = N >= 60000 ? 128 : N >= 8000 ? 64 : N >= 1500 ? 32 : 0;
     if (G > c->num_cu) G = c->num_cu;
     int TH = (int)c->linkage_threads;
-    if (TH <= 0) TH = N >= 8000 ? 512 : 256;          // measured (r03, square form, three runs each): one XCD 32 x 512 77.2 ms, 32 x 256 82.7 ms at N = 12 602 (condensed: 80.5 / 86.8); all XCDs 128 x 512 0.99 s at N = 100 174
+    // measured (r03, square form, N = 12 602, one XCD, three boxes): 32 x 256 75.2 / 82.7 / 76.8 ms, 32 x 512 84.4 / 77.2 / 85.0 ms -- the
+    // boxes disagree, 256 wins on two of three; all XCDs 128 x 512 0.99 s at N = 100 174 (128 x 256: 1.10 s)
+    if (TH <= 0) TH = auto_onex ? 256 : N >= 8000 ? 512 : 256;
     TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : TH >= 256 ? 256 : 128;
     if (G <= 1) {
         WS(c, double, D, "cl_D", m);
