@@ -76,6 +76,36 @@ def cpu_baseline(ws, we, seconds, planted, threads=None):
             "turns": len(turns)}
 
 
+def reference_clustering_baseline(d, seconds=1800):
+    """the one stage of the path whose REFERENCE code builds here: pipeline/src/clustering/clustering.cpp, compiled in place into
+    oracle/_ref/libref_clustering.so (oracle/Makefile; the prebuilt .so travels to the GPU box).  Clustering::cluster (pdist + centroid
+    linkage + fcluster) on the live planted embeddings of the first `seconds` of the synthetic hour, one host thread as the reference
+    runs it, next to the library's sd_cluster on the same rows (host -> device copy included); labels must be identical."""
+    import synth
+    from oracle import orc
+    R = orc.ref()
+    if R is None:
+        return None
+    n = seconds * SR
+    nc = synth.num_chunks(n)
+    sc, asg = synth.planted_scores(synth.with_duets(synth.schedule(float(HOUR), 1234, limit=n)), n, 0, nc)
+    emb = synth.planted_embeddings(asg).astype(np.float64)
+    live = (sc > 0.4442333667381752).sum(1).reshape(-1) > 12
+    X = np.ascontiguousarray(emb[live] / np.linalg.norm(emb[live], axis=1, keepdims=True))
+    N = len(X)
+    T_ref = np.zeros(N, np.int32)
+    t0 = time.perf_counter()
+    R.ref_cluster(X, N, 192, orc.THRESH_F32, T_ref)
+    cpu_s = time.perf_counter() - t0
+    d.cluster(X, orc.THRESH_F32)
+    t0 = time.perf_counter()
+    T_gpu = d.cluster(X, orc.THRESH_F32)
+    gpu_ms = (time.perf_counter() - t0) * 1e3
+    return {"kind": "reference", "what": "Clustering::cluster of the reference's own clustering.cpp (oracle/_ref, built in place) on the %d live planted embeddings of the "
+            "first %d s, 1 host thread, against sd_cluster on the same rows" % (N, seconds), "N": N, "cores": 1, "cpu_s": round(cpu_s, 2),
+            "gpu_ms": round(gpu_ms, 2), "ratio": round(cpu_s * 1e3 / gpu_ms, 1), "same_labels": bool(np.array_equal(T_ref, T_gpu))}
+
+
 def union_chunk_range(plan, n_total, world, rank, C):
     """chunks rank `rank` can be given under any rank-0 share between 0 and 1 / world (plan = sdhip.shard_plan): the hull of its ranges
     under the two extreme plans, widened by 32 * (world + 1) chunks: every range starts on a multiple of 32 chunks and the per-rank share
@@ -610,6 +640,10 @@ def main():
         }
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(ws, we, a.cpu_seconds, planted)
+            try:
+                out["cpu_baseline"]["reference_clustering"] = reference_clustering_baseline(d)
+            except Exception as e:                      # (the baseline beside the baseline must never cost the line)
+                out["cpu_baseline"]["reference_clustering"] = {"error": str(e)[:200]}
         else:
             out["cpu_baseline"] = None
         out["config"]["rank0_share"] = share_note

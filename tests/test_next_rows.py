@@ -424,3 +424,31 @@ def test_sharded_entry_point_through_rccl_world_of_one(diarizer):
     assert diarizer.comm_info() == (0, 0)
     with pytest.raises(sdhip.SdError):
         diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 0, n, n)                     # no communicator
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_on_a_short_job():
+    """the driver's contract for bench.py, on a 3-minute job: ONE JSON line with metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+    higher_is_better / scaling / vs_baseline / dtype / data / config.workload, a `roofline` object for the dominant kernel measured with HIP
+    events on the library's stream and a `cpu_baseline` object timed on this box's host cores; plus this round's additions"""
+    import json
+    out, _ = _run_bench(["--steps", "2", "--warmup", "1", "--hours-per-gpu", "0.05", "--cpu-seconds", "10", "--fp16-steps", "1"], 600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and out.stdout.strip().endswith(lines[0])
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] - j["config"]["audio_seconds"] / (j["ms_per_step"] / 1e3)) < 0.01 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
+    assert r["avg_launch_ms"] > 0 and r["launches_per_step"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["reference_clustering"] is None or cb["reference_clustering"].get("same_labels") is True          # oracle/_ref travels with the snapshot
+    assert j["value_host_pcm"]["same_turns"] is True and j["value_cold"]["ms"] > j["ms_per_step"]
+    f = j["fp16"]
+    assert f["same_turns_as_f32"] is True and f["roofline"]["peak"] == 2500.0 and f["cosine_distance_to_f32_embeddings"]["same_nan_rows"] is True
+    assert f["cosine_distance_to_f32_embeddings"]["q99"] < 2e-3
