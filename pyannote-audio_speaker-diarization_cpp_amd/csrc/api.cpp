@@ -105,6 +105,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "conv_pn") c->conv_pn = (int)v;
     else if (k == "ecapa_ld_pad") { if (v < 0 || v > 1024 || ((int64_t)v & 7)) return SD_ERR_ARG; c->ecapa_ld_pad = (int)v; }
     else if (k == "seg_shared_conv0") c->seg_shared_conv0 = v != 0;
+    else if (k == "seg_wide_ih") c->seg_wide_ih = v != 0;
     else if (k == "conv_w256_kmin") c->conv_w256_kmin = (int)v;
     else if (k == "conv_pn128") c->conv_pn128 = (int)v;
     else if (k == "ecapa_precision") { if (v < 0 || v > 2) SD_FAIL(c, SD_ERR_ARG, "ecapa_precision must be 0 (f32), 1 (fp16) or 2 (fp16, hi + lo weight planes)"); c->ecapa_precision = (int)v; }

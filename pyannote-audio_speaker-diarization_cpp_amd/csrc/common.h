@@ -123,6 +123,7 @@ struct sd_ctx {
     int conv_pn128 = 0;                         // 128 x 128 kernel: column tiles per super-block (0 = 8); tuning
     int ecapa_ld_pad = 0;                       // elements added to the leading dimensions of the ECAPA activation buffers (multiple of 8)
     bool wav_padded = false;                    // the waveform buffer in use was allocated by the library with 512 zeroed floats behind the samples
+    bool seg_wide_ih = true;                    // LSTM input projections of layers 1-3 on the 256 x 256 tile (identity row table); tuning
     bool seg_shared_conv0 = true;               // SincNet conv0 once over the waveform instead of once per (90 % overlapping) chunk
     int conv_w256_kmin = 0;                     // 256 x 256 kernel: shortest contraction Cin * KT it takes (0 = built-in: 1024 f32, 256 fp16); tuning
     int conv_pn = 0;                            // 256 x 256 kernel: column tiles per super-block (0 = 8); tuning

@@ -255,6 +255,14 @@ __global__ void k_zero_f32(float* p, int64_t n)
     if (i < n) p[i] = 0.0f;
 }
 
+// identity row table for a dense [M][K] operand: the 256 x 256 kernel (conv_gemm_h.hip) addresses its rows through ConvArgs::rowtab, which
+// packs the frame in 10 bits and the item in 12 -- rows are grouped into pseudo-items of 512 (up to 4095 * 512 rows)
+__global__ void k_dense_rowtab(int2* __restrict__ rowtab, int64_t M)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < M) rowtab[g] = make_int2((int)((g >> 9) << 9), (int)(g & 511) | (511 << 10) | ((int)(g >> 9) << 20));
+}
+
 static ConvArgs gemm_args(const ConvLayer& L, const float* X, int x_ld, float* Y, int y_ld, int64_t M)
 {
     ConvArgs a;
@@ -348,9 +356,24 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
     // if P2 > 293 (cannot happen for L <= 80000) only the first F frames would be used
     const float* lin = p2; int lin_ld = 64; int lin_rows_per_chunk = P2;
     float* hout = Ha;
+    int2* dense_tab = nullptr;
     for (int l = 0; l < 4; ++l) {
         if (lin_rows_per_chunk != F) SD_FAIL(c, SD_ERR_ARG, "unexpected frame count %d", P2);
-        { ConvArgs a = gemm_args(S.lstm_ih[l], lin, lin_ld, G, 1024, CB * F); if ((rc = launch_conv_gemm(c, a, "lstm_ih"))) return rc; }
+        {
+            // the input projections of layers 1-3 (K = 256, 1024 outputs) on the 256 x 256 tile: a dense operand seen through an identity row table.
+            // Same bits as the 128 x 128 form (K is summed in the same order in both); layer 0 (K = 64) is below that kernel's shortest contraction.
+            ConvArgs a = gemm_args(S.lstm_ih[l], lin, lin_ld, G, 1024, CB * F);
+            if (c->seg_wide_ih && l > 0 && CB * F <= (int64_t)ROWTAB_MAX_ITEMS * 512) {
+                if (!dense_tab) {
+                    dense_tab = ws_get<int2>(c, "seg_dense_rowtab", (size_t)(CB * F) + 512);
+                    if (!dense_tab) SD_FAIL(c, SD_ERR_HIP, "hipMalloc of the dense row table failed");
+                    hipLaunchKernelGGL(k_dense_rowtab, dim3((unsigned)((CB * F + 255) / 256)), dim3(256), 0, st, dense_tab, CB * F);
+                    KCHECK(c);
+                }
+                a.rowtab = dense_tab; a.pad_mode = 0; a.Tin = 512; a.T = 512; a.TpIn = a.TpOut = 512; a.in_rows = (int)(CB * F);
+            }
+            if ((rc = launch_conv_gemm(c, a, "lstm_ih"))) return rc;
+        }
         {
             ProfScope ps(c, "lstm_rec", 2.0 * CB * F * 2 * 512 * 128, 0);
             hipLaunchKernelGGL(k_lstm_rec, dim3((unsigned)((CB + 31) / 32), 2), dim3(512), 0, st, G, S.lstm_hh[l][0], S.lstm_hh[l][1], hout, (int)CB, F);
