@@ -343,6 +343,33 @@ def test_heap_linkage_with_global_heap_is_bit_identical(diarizer):
     assert np.array_equal(Z, Z_ref)
 
 
+@pytest.mark.parametrize("square", [1, 0])
+@pytest.mark.parametrize("N,d,G,T", [(2500, 3, 32, 256), (4000, 2, 16, 512), (3000, 8, 64, 256), (6000, 3, -1, 0)])
+def test_cooperative_linkage_on_unclustered_low_dimensional_data(diarizer, N, d, G, T, square):
+    """uniform points in 2 / 3 / 8 dimensions: the opposite regime of the speaker embeddings.  Merges are balanced (many small clusters grow
+    side by side), so rows go stale and are refreshed cooperatively all the time, the two-level bounds lose both levels regularly, and in
+    the square form most merges involve a cluster OLDER than many bystanders: the entries are then read from the bystanders' rows (the
+    last-rewrite index rule) instead of the pair's.  Dendrogram bit-identical to the oracle in both matrix layouts; the kernel must not
+    have fallen back to the heap kernel (the data has no exact ties)."""
+    rng = np.random.default_rng(31 * N + d)
+    X = rng.random((N, d))
+    _, Z_ref = orc.ahc(X, orc.THRESH_F32)
+    fb0 = diarizer.kernel_stats("linkage_fallbacks")["launches"]
+    rr0 = diarizer.kernel_stats("linkage_retry_rounds")["flops"]
+    diarizer.set_option("linkage_wgs", G)
+    diarizer.set_option("linkage_threads", T)
+    diarizer.set_option("linkage_square", square)
+    try:
+        Z = diarizer.linkage(X)
+    finally:
+        diarizer.set_option("linkage_wgs", -1)
+        diarizer.set_option("linkage_threads", 0)
+        diarizer.set_option("linkage_square", -1)
+    assert np.array_equal(Z, Z_ref)
+    assert diarizer.kernel_stats("linkage_fallbacks")["launches"] == fb0
+    assert diarizer.kernel_stats("linkage_retry_rounds")["flops"] > rr0          # stale candidates did reach the top here
+
+
 def test_tie_free_data_never_leaves_the_cooperative_kernel(diarizer):
     fb0 = diarizer.kernel_stats("linkage_fallbacks")["launches"]
     X = _blobs(np.random.default_rng(5), 4000)
