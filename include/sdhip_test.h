@@ -36,7 +36,9 @@ int sd_debug_read_ws(sd_ctx*, const char* name, int64_t offset, void* h_out, int
  * virtual_world -- reports SD_ERR_ARG instead of inferring; every rank must then return an error for the job),
  * "conv_h256" / "conv_w256_f32" (256 x 256 tile for the wide ECAPA layers in fp16 / f32), "conv_w256_kmin" (shortest contraction that tile
  * takes), "conv_pn" / "conv_pn128" (column tiles per super-block), "ecapa_ld_pad" (elements added to the activation rows, multiple of 8),
- * "seg_shared_conv0" (1 = SincNet's first convolution once over the waveform instead of once per overlapping chunk). */
+ * "seg_shared_conv0" (1 = SincNet's first convolution once over the waveform instead of once per overlapping chunk), "seg_wide_ih" (1 = LSTM input
+ * projections of layers 1-3 on the 256 x 256 tile), "linkage_square" (-1 auto, 0 condensed, 1 full N x N distance matrix), "ecapa_f16_hp" /
+ * "ecapa_keep_cat" (precision diagnostics of tools/diag_fp16_layers.py). */
 /* tuning hooks (tools/): time one conv_gemm shape on scratch data (dbg selects an ablation); time a grid barrier */
 int sd_bench_barrier(sd_ctx*, int workgroups, int iters, int dirty_doubles, double* us_per_barrier);
 int sd_bench_conv(sd_ctx*, int64_t items, int Tp, int T, int Cin, int Cout, int KT, int dil, int has_x2, int dbg, int reps, double* ms_per_launch);
