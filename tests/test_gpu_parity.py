@@ -400,6 +400,27 @@ def test_clustering_parity(diarizer):
     assert np.array_equal(h2, h2_ref)
 
 
+def test_clustering_with_more_clusters_than_one_assignment_tile(diarizer):
+    """K = 1 100 clusters (a recording with that many voices does not exist; a long one with hundreds does): k_assign's arg-max runs over
+    the clusters in tiles of 1 024 scores, first maximum wins across tiles as Helper::argmax does (sd.cpp:293-316).  32-dimensional rows,
+    which sd_clustering takes as they are, keep the oracle's O(N^2 d) pdist short."""
+    rng = np.random.default_rng(123)
+    K, per, d = 1100, 16, 32
+    cen = rng.standard_normal((K, d))
+    cen /= np.linalg.norm(cen, axis=1, keepdims=True)
+    lab = np.repeat(np.arange(K), per)
+    rng.shuffle(lab)
+    c = (len(lab) + 2) // 3
+    emb = np.full((c * 3, d), np.nan)
+    emb[:len(lab)] = cen[lab] + 0.02 * rng.standard_normal((len(lab), d))
+    emb = emb.astype(np.float32).astype(np.float64).reshape(c, 3, d)
+    h, Kg = diarizer.clustering(emb)
+    h_ref, K_ref, _ = orc.clustering(emb)
+    assert Kg == K_ref == K
+    assert np.array_equal(h, h_ref)
+    assert len(np.unique(h.reshape(-1)[:len(lab)])) == K
+
+
 # ------------------------------------------------------------------ a15 - a17
 @pytest.mark.parametrize("c,kmax", [(30, 3), (12, 1), (77, 6), (1, 2)])
 def test_reconstruct_parity(diarizer, c, kmax):
