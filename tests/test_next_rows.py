@@ -214,6 +214,25 @@ def test_cli_multi_gpu_launcher_fails_cleanly_without_devices(golden_dir):
     assert "rank 0" in out.stderr and "rank 1" in out.stderr and "Speaker_" not in out.stdout
 
 
+@pytest.mark.gpu
+def test_cli_multi_gpu_launcher_ends_promptly_when_one_rank_cannot_start(weights, golden_dir):
+    """`speakerDiarizer --gpus 2` on a ONE-GPU box: rank 0 gets its GPU, loads the models and the wav; rank 1 has no device.  Without the
+    ready handshake rank 0 would mint the rendezvous id and wait in ncclCommInitRank for a peer that never comes: now rank 0
+    learns from the closed ready pipe that rank 1 did not come up, and the launcher, reaping in completion order, returns 1 at once."""
+    import subprocess
+    import time
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one GPU")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pyannote-audio_speaker-diarization_cpp_amd", "speakerDiarizer")
+    t0 = time.time()
+    out = subprocess.run([exe, "--gpus", "2", weights[0], weights[1], os.path.join(golden_dir, "multi-speaker_1min.wav")], capture_output=True, text=True, timeout=120)
+    dt = time.time() - t0
+    assert out.returncode == 1 and dt < 60, (out.returncode, dt, out.stderr[-500:])
+    assert "rank 1: sd_create failed" in out.stderr and "rank 1 did not come up" in out.stderr
+    assert "Speaker_" not in out.stdout
+
+
 def _run_bench(args, timeout, env_extra=None):
     import subprocess
     import sys
