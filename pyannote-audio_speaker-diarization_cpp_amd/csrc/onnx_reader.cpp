@@ -60,9 +60,10 @@ bool parse_tensor(PB pb, OTensor& t)
     }
     if (!pb.ok) return false;
     if (!raw.empty()) {
-        if (t.dtype == 1) { t.f.resize(raw.size() / 4); memcpy(t.f.data(), raw.data(), t.f.size() * 4); }
+        if (t.dtype == 1) { t.f.resize(raw.size() / 4); if (!t.f.empty()) memcpy(t.f.data(), raw.data(), t.f.size() * 4); }
         else if (t.dtype == 11) { const size_t n = raw.size() / 8; t.f.resize(n); for (size_t k = 0; k < n; ++k) { double v; memcpy(&v, raw.data() + 8 * k, 8); t.f[k] = (float)v; } }
-        else if (t.dtype == 7) { t.i64.resize(raw.size() / 8); memcpy(t.i64.data(), raw.data(), t.i64.size() * 8); }
+        else if (t.dtype == 7) { t.i64.resize(raw.size() / 8); if (!t.i64.empty()) memcpy(t.i64.data(), raw.data(), t.i64.size() * 8); }
+        else if (t.dtype == 9) { t.i64.resize(raw.size()); for (size_t k = 0; k < raw.size(); ++k) t.i64[k] = raw[k] != 0; }
         else if (t.dtype == 6) { const size_t n = raw.size() / 4; t.i64.resize(n); for (size_t k = 0; k < n; ++k) { int32_t v; memcpy(&v, raw.data() + 4 * k, 4); t.i64[k] = v; } }
     }
     return true;
@@ -107,7 +108,15 @@ bool parse_graph(PB pb, OGraph& g)
     }
     // Constant nodes act as initializers under their output name
     for (auto& n : g.nodes)
-        if (n.op == "Constant" && !n.out.empty()) { const OAttr* a = n.attr("value"); if (a && a->has_t) { OTensor t = a->t; t.name = n.out[0]; g.init[n.out[0]] = std::move(t); } }
+        if (n.op == "Constant" && !n.out.empty()) {
+            const OAttr* a = n.attr("value");
+            OTensor t; bool have = false;
+            if (a && a->has_t) { t = a->t; have = true; }
+            else if ((a = n.attr("value_float"))) { t.dtype = 1; t.f = {a->f}; have = true; }
+            else if ((a = n.attr("value_int"))) { t.dtype = 7; t.i64 = {a->i}; have = true; }
+            else if ((a = n.attr("value_ints"))) { t.dtype = 7; t.i64 = a->ints; t.dims = {(int64_t)a->ints.size()}; have = true; }
+            if (have) { t.name = n.out[0]; g.init[n.out[0]] = std::move(t); }
+        }
     return pb.ok;
 }
 
@@ -115,6 +124,9 @@ bool parse_graph(PB pb, OGraph& g)
 // (torch.onnx.export with do_constant_folding=False builds the LSTM W / R / B by Slice + Concat + Unsqueeze of the PyTorch
 // parameters and the Linear weights by Transpose): a node whose inputs are all constants becomes a constant itself.
 // Only data movement is evaluated -- no arithmetic -- so the extracted weights stay the exporter's bits.
+// which of the two value fields a tensor's elements live in is decided by where the data IS (a malformed file may announce one element type and
+// fill the other field); every accessor below goes through this one rule
+bool is_int(const OTensor& t) { return !t.i64.empty() || (t.f.empty() && (t.dtype == 7 || t.dtype == 6 || t.dtype == 9)); }
 int64_t numel(const OTensor& t) { int64_t n = 1; for (auto d : t.dims) n *= d; return n; }
 // a tensor the constant folder may touch: non-negative dimensions, a bounded element count (no overflow, no giant resize) and exactly
 // that many stored elements -- a malformed model is skipped here and reported by the layer extraction ("... is not a constant")
@@ -126,10 +138,10 @@ bool sane(const OTensor& t)
         if (d != 0 && n > ((int64_t)1 << 31) / d) return false;
         n *= d;
     }
-    const int64_t have = (int64_t)(!t.i64.empty() ? t.i64.size() : t.f.size());
-    return have == n;
+    // the storage must be the one the element type says (an int tensor whose data sits in the float field would be indexed through the empty one)
+    if (is_int(t)) return t.f.empty() && (int64_t)t.i64.size() == n;
+    return t.i64.empty() && (int64_t)t.f.size() == n;
 }
-bool is_int(const OTensor& t) { return !t.i64.empty() || t.dtype == 7 || t.dtype == 6; }
 // copy a strided N-d view: out[idx] = in[sum (start_a + idx_a * step_a) * stride_a]
 void gather_nd(const OTensor& in, const std::vector<int64_t>& odims, const std::vector<int64_t>& start, const std::vector<int64_t>& step,
                const std::vector<int64_t>& istride, OTensor& out)
@@ -152,13 +164,284 @@ std::vector<int64_t> strides_of(const std::vector<int64_t>& dims)
     for (int a = (int)dims.size() - 2; a >= 0; --a) s[(size_t)a] = s[(size_t)a + 1] * dims[(size_t)a + 1];
     return s;
 }
+// ---- arithmetic on constants.  The TorchScript exporter folds only a short list of operators; what it leaves behind in a graph whose
+// first convolution is a PARAMETRISED filter bank -- pyannote's SincNet front end computes its 80 x 251 filters from 2 x 40 learnable
+// frequencies with Abs, Add, Clip, MatMul, Sin, Cos, Sub, Div, Mul, a flip (Slice with step -1), Concat and Reshape (asteroid
+// ParamSincFB.filters()) -- is a constant sub-graph in front of the Conv's weight input.  It is evaluated here in float32 / int64 the way
+// an ONNX runtime would evaluate it (element-wise with numpy broadcasting); only nodes ALL of whose inputs are constants are touched,
+// so nothing that depends on the audio is ever computed.  (sin / cos are the host libm's: within an ulp of another runtime's.)
+bool is_floaty(const OTensor& t) { return !is_int(t); }
+double getv(const OTensor& t, int64_t k) { return is_floaty(t) ? (double)t.f[(size_t)k] : (double)t.i64[(size_t)k]; }
+bool broadcast_dims(const std::vector<const OTensor*>& in, std::vector<int64_t>& od)
+{
+    size_t R = 0;
+    for (auto* t : in) R = std::max(R, t->dims.size());
+    od.assign(R, 1);
+    for (auto* t : in)
+        for (size_t a = 0; a < t->dims.size(); ++a) {
+            const size_t o = R - t->dims.size() + a;
+            const int64_t d = t->dims[a];
+            if (d == od[o] || d == 1) continue;
+            if (od[o] == 1) od[o] = d; else return false;
+        }
+    return true;
+}
+// offset of output element `idx` (multi-index over od) inside t under broadcasting
+int64_t bc_offset(const OTensor& t, const std::vector<int64_t>& od, const std::vector<int64_t>& idx)
+{
+    const size_t R = od.size(), r = t.dims.size();
+    int64_t off = 0, stride = 1;
+    for (size_t a = r; a-- > 0;) { const int64_t d = t.dims[a]; if (d != 1) off += idx[R - r + a] * stride; stride *= d; }
+    return off;
+}
+bool eval_arith(const ONode& n, const std::vector<const OTensor*>& in, OTensor& y)
+{
+    static const char* const UN[] = {"Abs", "Neg", "Sin", "Cos", "Exp", "Log", "Sqrt", "Reciprocal", "Floor", "Ceil", "Tanh", "Sigmoid", "Relu", "Not", "Sign"};
+    static const char* const BIN[] = {"Add", "Sub", "Mul", "Div", "Pow", "Min", "Max", "Equal", "Less", "Greater", "LessOrEqual", "GreaterOrEqual", "And", "Or"};
+    const std::string& op = n.op;
+    auto is_in = [&](const char* const* L, size_t cnt) { for (size_t k = 0; k < cnt; ++k) if (op == L[k]) return true; return false; };
+    const int64_t LIM = (int64_t)1 << 26;                        // no constant sub-graph of these models comes near 64 M elements
+    if (is_in(UN, sizeof(UN) / sizeof(UN[0]))) {
+        if (in.size() < 1 || !in[0]) return false;
+        const OTensor& x = *in[0];
+        const int64_t N = numel(x);
+        y.dims = x.dims; y.dtype = x.dtype;
+        if (is_floaty(x)) {
+            y.f.resize((size_t)N);
+            for (int64_t k = 0; k < N; ++k) {
+                const float v = x.f[(size_t)k]; float r;
+                if (op == "Abs") r = std::fabs(v); else if (op == "Neg") r = -v; else if (op == "Sin") r = std::sin(v); else if (op == "Cos") r = std::cos(v);
+                else if (op == "Exp") r = std::exp(v); else if (op == "Log") r = std::log(v); else if (op == "Sqrt") r = std::sqrt(v); else if (op == "Reciprocal") r = 1.0f / v;
+                else if (op == "Floor") r = std::floor(v); else if (op == "Ceil") r = std::ceil(v); else if (op == "Tanh") r = std::tanh(v);
+                else if (op == "Sigmoid") r = 1.0f / (1.0f + std::exp(-v)); else if (op == "Relu") r = v > 0.0f ? v : 0.0f; else if (op == "Sign") r = (float)((v > 0) - (v < 0));
+                else return false;
+                y.f[(size_t)k] = r;
+            }
+        } else {
+            y.i64.resize((size_t)N);
+            for (int64_t k = 0; k < N; ++k) {
+                const int64_t v = x.i64[(size_t)k];
+                if (op == "Abs") y.i64[(size_t)k] = v < 0 ? -v : v; else if (op == "Neg") y.i64[(size_t)k] = -v; else if (op == "Not") y.i64[(size_t)k] = !v;
+                else if (op == "Sign") y.i64[(size_t)k] = (v > 0) - (v < 0); else if (op == "Relu") y.i64[(size_t)k] = v > 0 ? v : 0; else return false;
+            }
+        }
+        return true;
+    }
+    if (is_in(BIN, sizeof(BIN) / sizeof(BIN[0])) || op == "Where") {
+        const size_t need = op == "Where" ? 3 : 2;
+        if (in.size() < need) return false;
+        for (auto* t : in) if (!t) return false;
+        std::vector<int64_t> od;
+        if (!broadcast_dims(in, od)) return false;
+        int64_t N = 1;
+        for (auto d : od) { if (d < 0 || (d && N > LIM / d)) return false; N *= d; }
+        const bool cmp = op == "Equal" || op == "Less" || op == "Greater" || op == "LessOrEqual" || op == "GreaterOrEqual" || op == "And" || op == "Or";
+        const size_t v0 = op == "Where" ? 1 : 0;
+        bool fl = false;
+        for (size_t k = v0; k < in.size(); ++k) fl |= is_floaty(*in[k]);
+        y.dims = od; y.dtype = cmp ? 9 : (fl ? 1 : 7);
+        if (cmp || !fl) y.i64.resize((size_t)N); else y.f.resize((size_t)N);
+        std::vector<int64_t> idx(od.size(), 0);
+        for (int64_t k = 0; k < N; ++k) {
+            double r;
+            if (op == "Where") {
+                const bool cnd = getv(*in[0], bc_offset(*in[0], od, idx)) != 0.0;
+                r = cnd ? getv(*in[1], bc_offset(*in[1], od, idx)) : getv(*in[2], bc_offset(*in[2], od, idx));
+                if (fl) r = (double)(float)r;
+            } else {
+                // float32 arithmetic exactly as a runtime does it: operands and result in float
+                const double a0 = getv(*in[0], bc_offset(*in[0], od, idx));
+                r = a0;
+                for (size_t q = 1; q < in.size(); ++q) {
+                    const double b = getv(*in[q], bc_offset(*in[q], od, idx));
+                    if (fl && !cmp) {
+                        const float fa = (float)r, fb = (float)b; float fr;
+                        if (op == "Add") fr = fa + fb; else if (op == "Sub") fr = fa - fb; else if (op == "Mul") fr = fa * fb; else if (op == "Div") fr = fa / fb;
+                        else if (op == "Pow") fr = std::pow(fa, fb); else if (op == "Min") fr = fb < fa ? fb : fa; else if (op == "Max") fr = fb > fa ? fb : fa; else return false;
+                        r = fr;
+                    } else if (!cmp) {
+                        const int64_t ia = (int64_t)r, ib = (int64_t)b; int64_t ir;
+                        if (op == "Add") ir = ia + ib; else if (op == "Sub") ir = ia - ib; else if (op == "Mul") ir = ia * ib;
+                        else if (op == "Div") { if (ib == 0) return false; ir = ia / ib; }
+                        else if (op == "Pow") ir = (int64_t)std::llround(std::pow((double)ia, (double)ib)); else if (op == "Min") ir = ib < ia ? ib : ia; else if (op == "Max") ir = ib > ia ? ib : ia; else return false;
+                        r = (double)ir;
+                    } else {
+                        if (op == "Equal") r = r == b; else if (op == "Less") r = r < b; else if (op == "Greater") r = r > b; else if (op == "LessOrEqual") r = r <= b;
+                        else if (op == "GreaterOrEqual") r = r >= b; else if (op == "And") r = (r != 0.0) && (b != 0.0); else r = (r != 0.0) || (b != 0.0);
+                        if (q + 1 < in.size()) return false;              // comparisons are binary
+                    }
+                    if (op != "Min" && op != "Max" && op != "Add" && op != "Mul" && q + 1 < in.size()) return false;      // only these are variadic
+                }
+            }
+            if (cmp || !fl) y.i64[(size_t)k] = (int64_t)r; else y.f[(size_t)k] = (float)r;
+            for (size_t a = od.size(); a-- > 0;) { if (++idx[a] < od[a]) break; idx[a] = 0; }
+        }
+        return true;
+    }
+    if (op == "Clip") {
+        if (in.empty() || !in[0] || !is_floaty(*in[0])) return false;
+        float lo = -INFINITY, hi = INFINITY;
+        if (const OAttr* a = n.attr("min")) lo = a->f;
+        if (const OAttr* a = n.attr("max")) hi = a->f;
+        if (in.size() > 1 && in[1]) { if (numel(*in[1]) != 1) return false; lo = (float)getv(*in[1], 0); }
+        if (in.size() > 2 && in[2]) { if (numel(*in[2]) != 1) return false; hi = (float)getv(*in[2], 0); }
+        y = *in[0];
+        for (auto& v : y.f) v = v < lo ? lo : (v > hi ? hi : v);
+        return true;
+    }
+    if (op == "Cast") {
+        if (in.empty() || !in[0]) return false;
+        const OAttr* a = n.attr("to");
+        if (!a) return false;
+        const OTensor& x = *in[0];
+        const int64_t N = numel(x);
+        y.dims = x.dims; y.dtype = (int)a->i;
+        if (a->i == 1 || a->i == 11) { y.dtype = 1; y.f.resize((size_t)N); for (int64_t k = 0; k < N; ++k) y.f[(size_t)k] = (float)getv(x, k); }
+        else if (a->i == 7 || a->i == 6 || a->i == 9) { y.i64.resize((size_t)N); for (int64_t k = 0; k < N; ++k) { const double v = getv(x, k); y.i64[(size_t)k] = a->i == 9 ? (v != 0.0) : (int64_t)v; } }
+        else return false;
+        return true;
+    }
+    if (op == "MatMul" || op == "Gemm") {
+        if (in.size() < 2 || !in[0] || !in[1] || !is_floaty(*in[0]) || !is_floaty(*in[1])) return false;
+        const OTensor &A = *in[0], &B = *in[1];
+        if (A.dims.size() > 2 || B.dims.size() > 2 || A.dims.empty() || B.dims.empty()) return false;
+        bool tA = false, tB = false; float alpha = 1.0f, beta = 1.0f;
+        if (op == "Gemm") {
+            if (const OAttr* a = n.attr("transA")) tA = a->i != 0;
+            if (const OAttr* a = n.attr("transB")) tB = a->i != 0;
+            if (const OAttr* a = n.attr("alpha")) alpha = a->f;
+            if (const OAttr* a = n.attr("beta")) beta = a->f;
+        }
+        const int64_t ar = A.dims.size() == 2 ? A.dims[0] : 1, ac = A.dims.size() == 2 ? A.dims[1] : A.dims[0];
+        const int64_t br = B.dims.size() == 2 ? B.dims[0] : B.dims[0], bc = B.dims.size() == 2 ? B.dims[1] : 1;
+        const int64_t M = tA ? ac : ar, K = tA ? ar : ac, K2 = tB ? bc : br, Nn = tB ? br : bc;
+        if (K != K2 || M <= 0 || Nn <= 0 || K <= 0 || M > LIM / Nn) return false;
+        y.dtype = 1; y.f.assign((size_t)(M * Nn), 0.0f);
+        if (A.dims.size() == 2 && B.dims.size() == 2) y.dims = {M, Nn}; else if (A.dims.size() == 1 && B.dims.size() == 2) y.dims = {Nn}; else if (A.dims.size() == 2) y.dims = {M}; else y.dims = {};
+        for (int64_t i = 0; i < M; ++i)
+            for (int64_t j = 0; j < Nn; ++j) {
+                float acc = 0.0f;
+                for (int64_t k = 0; k < K; ++k) acc += A.f[(size_t)(tA ? k * ac + i : i * ac + k)] * B.f[(size_t)(tB ? j * bc + k : k * bc + j)];
+                y.f[(size_t)(i * Nn + j)] = alpha * acc;
+            }
+        if (op == "Gemm" && in.size() > 2 && in[2]) {
+            std::vector<const OTensor*> two = {in[2]};
+            std::vector<int64_t> od = {M, Nn}, idx(2, 0);
+            for (int64_t k = 0; k < M * Nn; ++k) { y.f[(size_t)k] += beta * (float)getv(*in[2], bc_offset(*in[2], od, idx)); if (++idx[1] == Nn) { idx[1] = 0; ++idx[0]; } }
+        }
+        return true;
+    }
+    if (op == "Shape") {
+        if (in.empty() || !in[0]) return false;
+        y.dtype = 7; y.i64 = in[0]->dims; y.dims = {(int64_t)in[0]->dims.size()};
+        return true;
+    }
+    if (op == "Size") { if (in.empty() || !in[0]) return false; y.dtype = 7; y.i64 = {numel(*in[0])}; y.dims = {}; return true; }
+    if (op == "ConstantOfShape") {
+        if (in.empty() || !in[0] || is_floaty(*in[0])) return false;
+        int64_t N = 1;
+        for (auto d : in[0]->i64) { if (d < 0 || (d && N > LIM / d)) return false; N *= d; }
+        y.dims = in[0]->i64;
+        const OAttr* a = n.attr("value");
+        if (a && a->has_t && !is_floaty(a->t)) { y.dtype = a->t.dtype ? a->t.dtype : 7; y.i64.assign((size_t)N, a->t.i64.empty() ? 0 : a->t.i64[0]); }
+        else { y.dtype = 1; y.f.assign((size_t)N, (a && a->has_t && !a->t.f.empty()) ? a->t.f[0] : 0.0f); }
+        return true;
+    }
+    if (op == "Range") {
+        if (in.size() < 3 || !in[0] || !in[1] || !in[2]) return false;
+        const double st = getv(*in[0], 0), lim = getv(*in[1], 0), dl = getv(*in[2], 0);
+        if (dl == 0.0) return false;
+        const double cnt = std::ceil((lim - st) / dl);
+        if (!(cnt >= 0) || cnt > (double)LIM) return false;
+        const int64_t N = (int64_t)cnt;
+        y.dims = {N};
+        if (is_floaty(*in[0])) { y.dtype = 1; y.f.resize((size_t)N); for (int64_t k = 0; k < N; ++k) y.f[(size_t)k] = (float)st + (float)k * (float)dl; }
+        else { y.dtype = 7; y.i64.resize((size_t)N); for (int64_t k = 0; k < N; ++k) y.i64[(size_t)k] = (int64_t)st + k * (int64_t)dl; }
+        return true;
+    }
+    if (op == "Gather") {
+        if (in.size() < 2 || !in[0] || !in[1] || is_floaty(*in[1])) return false;
+        const OTensor &x = *in[0], &ix = *in[1];
+        const int R = (int)x.dims.size();
+        const OAttr* a = n.attr("axis");
+        int64_t axis = a ? a->i : 0; if (axis < 0) axis += R;
+        if (R == 0 || axis < 0 || axis >= R) return false;
+        int64_t outer = 1, inner = 1;
+        for (int q = 0; q < axis; ++q) outer *= x.dims[(size_t)q];
+        for (int q = (int)axis + 1; q < R; ++q) inner *= x.dims[(size_t)q];
+        const int64_t D = x.dims[(size_t)axis], NI = numel(ix);
+        if (outer * NI > LIM / std::max<int64_t>(inner, 1)) return false;
+        y.dtype = x.dtype; y.dims.clear();
+        for (int q = 0; q < axis; ++q) y.dims.push_back(x.dims[(size_t)q]);
+        for (auto d : ix.dims) y.dims.push_back(d);
+        for (int q = (int)axis + 1; q < R; ++q) y.dims.push_back(x.dims[(size_t)q]);
+        const bool fl = is_floaty(x);
+        if (fl) y.f.resize((size_t)(outer * NI * inner)); else y.i64.resize((size_t)(outer * NI * inner));
+        for (int64_t o = 0; o < outer; ++o)
+            for (int64_t k = 0; k < NI; ++k) {
+                int64_t g = ix.i64[(size_t)k]; if (g < 0) g += D;
+                if (g < 0 || g >= D) return false;
+                for (int64_t q = 0; q < inner; ++q) {
+                    const size_t src = (size_t)((o * D + g) * inner + q), dst = (size_t)((o * NI + k) * inner + q);
+                    if (fl) y.f[dst] = x.f[src]; else y.i64[dst] = x.i64[src];
+                }
+            }
+        return true;
+    }
+    if (op == "Tile") {
+        if (in.size() < 2 || !in[0] || !in[1] || is_floaty(*in[1])) return false;
+        const OTensor& x = *in[0];
+        const size_t R = x.dims.size();
+        if (in[1]->i64.size() != R) return false;
+        std::vector<int64_t> od(R);
+        int64_t N = 1;
+        for (size_t a = 0; a < R; ++a) { const int64_t rp = in[1]->i64[a]; if (rp < 0 || (x.dims[a] && rp > LIM / std::max<int64_t>(x.dims[a], 1))) return false; od[a] = x.dims[a] * rp; if (od[a] && N > LIM / od[a]) return false; N *= od[a]; }
+        y.dims = od; y.dtype = x.dtype;
+        const bool fl = is_floaty(x);
+        if (fl) y.f.resize((size_t)N); else y.i64.resize((size_t)N);
+        std::vector<int64_t> idx(R, 0);
+        for (int64_t k = 0; k < N; ++k) {
+            int64_t off = 0, stride = 1;
+            for (size_t a = R; a-- > 0;) { off += (idx[a] % x.dims[a]) * stride; stride *= x.dims[a]; }
+            if (fl) y.f[(size_t)k] = x.f[(size_t)off]; else y.i64[(size_t)k] = x.i64[(size_t)off];
+            for (size_t a = R; a-- > 0;) { if (++idx[a] < od[a]) break; idx[a] = 0; }
+        }
+        return true;
+    }
+    if (op == "Expand") {
+        if (in.size() < 2 || !in[0] || !in[1] || is_floaty(*in[1])) return false;
+        OTensor shp; shp.dims = in[1]->i64;                           // a tensor that only carries the target dims
+        std::vector<const OTensor*> two = {in[0], &shp};
+        std::vector<int64_t> od;
+        if (!broadcast_dims(two, od)) return false;
+        int64_t N = 1;
+        for (auto d : od) { if (d < 0 || (d && N > LIM / d)) return false; N *= d; }
+        y.dims = od; y.dtype = in[0]->dtype;
+        const bool fl = is_floaty(*in[0]);
+        if (fl) y.f.resize((size_t)N); else y.i64.resize((size_t)N);
+        std::vector<int64_t> idx(od.size(), 0);
+        for (int64_t k = 0; k < N; ++k) {
+            const int64_t o = bc_offset(*in[0], od, idx);
+            if (fl) y.f[(size_t)k] = in[0]->f[(size_t)o]; else y.i64[(size_t)k] = in[0]->i64[(size_t)o];
+            for (size_t a = od.size(); a-- > 0;) { if (++idx[a] < od[a]) break; idx[a] = 0; }
+        }
+        return true;
+    }
+    return false;
+}
+
 void fold_constants(OGraph& g)
 {
     for (const ONode& n : g.nodes) {
         if (n.out.empty() || g.init.count(n.out[0])) continue;
         const bool known = n.op == "Slice" || n.op == "Concat" || n.op == "Unsqueeze" || n.op == "Squeeze" || n.op == "Transpose" || n.op == "Identity" ||
-                           n.op == "Reshape";
-        if (!known) continue;
+                           n.op == "Reshape" || n.op == "Flatten";
+        static const char* const ARITH[] = {"Abs", "Neg", "Sin", "Cos", "Exp", "Log", "Sqrt", "Reciprocal", "Floor", "Ceil", "Tanh", "Sigmoid", "Relu", "Not", "Sign",
+                                            "Add", "Sub", "Mul", "Div", "Pow", "Min", "Max", "Equal", "Less", "Greater", "LessOrEqual", "GreaterOrEqual", "And", "Or", "Where",
+                                            "Clip", "Cast", "MatMul", "Gemm", "Shape", "Size", "ConstantOfShape", "Range", "Gather", "Expand", "Tile"};
+        bool arith = false;
+        for (auto* a : ARITH) if (n.op == a) arith = true;
+        if (!known && !arith) continue;
         std::vector<const OTensor*> in;
         bool all = !n.in.empty();
         for (auto& nm : n.in) {
@@ -172,6 +455,13 @@ void fold_constants(OGraph& g)
         bool in_ok = true;
         for (auto* t : in) if (t && !sane(*t)) in_ok = false;          // every input, not only the first: Concat copies from all of them
         if (!in_ok) continue;
+        if (arith) {
+            OTensor ya;
+            if (!eval_arith(n, in, ya) || !sane(ya)) continue;
+            ya.name = n.out[0];
+            g.init[ya.name] = std::move(ya);
+            continue;
+        }
         OTensor y; y.name = n.out[0]; y.dtype = x.dtype;
         const int R = (int)x.dims.size();
         auto ints_of = [&](size_t k, const char* attr) -> std::vector<int64_t> {
@@ -203,6 +493,13 @@ void fold_constants(OGraph& g)
                 }
                 y.dims = od;
             }
+        } else if (n.op == "Flatten") {
+            const OAttr* aa = n.attr("axis");
+            int64_t axis = aa ? aa->i : 1; if (axis < 0) axis += R;
+            if (axis < 0 || axis > R) continue;
+            int64_t o = 1, i2 = 1;
+            for (int q = 0; q < R; ++q) (q < axis ? o : i2) *= x.dims[(size_t)q];
+            y = x; y.name = n.out[0]; y.dims = {o, i2};
         } else if (n.op == "Reshape") {
             if (in.size() < 2 || !in[1]) continue;
             std::vector<int64_t> od = in[1]->i64;
@@ -241,13 +538,21 @@ void fold_constants(OGraph& g)
             bool ok = true;
             for (size_t k = 0; k < axes.size(); ++k) {
                 int64_t a = axes[k]; if (a < 0) a += R;
-                if (a < 0 || a >= R || steps[k] <= 0) { ok = false; break; }
+                if (a < 0 || a >= R || steps[k] == 0) { ok = false; break; }
                 const int64_t D = x.dims[(size_t)a];
                 int64_t s0 = starts[k], e0 = ends[k];
-                if (s0 < 0) s0 += D; if (e0 < 0) e0 += D;
-                s0 = std::min(std::max<int64_t>(s0, 0), D); e0 = std::min(std::max<int64_t>(e0, 0), D);
+                if (steps[k] > 0) {
+                    if (s0 < 0) s0 += D; if (e0 < 0) e0 += D;
+                    s0 = std::min(std::max<int64_t>(s0, 0), D); e0 = std::min(std::max<int64_t>(e0, 0), D);
+                    od[(size_t)a] = e0 > s0 ? (e0 - s0 + steps[k] - 1) / steps[k] : 0;
+                } else {
+                    // negative step (torch.flip exports as Slice(start = -1, end = INT64_MIN, step = -1)): ONNX clamps start to [0, D - 1], end to [-1, D - 1]
+                    if (s0 < 0) s0 += D; if (e0 < 0 && e0 > -((int64_t)1 << 40)) e0 += D;
+                    s0 = std::min(std::max<int64_t>(s0, 0), D - 1); e0 = std::min(std::max<int64_t>(e0, -1), D - 1);
+                    const int64_t stp = -steps[k];
+                    od[(size_t)a] = s0 > e0 ? (s0 - e0 + stp - 1) / stp : 0;
+                }
                 st[(size_t)a] = s0; sp[(size_t)a] = steps[k];
-                od[(size_t)a] = e0 > s0 ? (e0 - s0 + steps[k] - 1) / steps[k] : 0;
             }
             if (!ok) continue;
             gather_nd(x, od, st, sp, strides_of(x.dims), y);
@@ -271,6 +576,7 @@ void fold_constants(OGraph& g)
             int64_t off = 0;
             for (auto* t : in) {
                 const int64_t w = t->dims[(size_t)axis] * inner;
+                if (w == 0) continue;
                 for (int64_t o = 0; o < outer; ++o) {
                     if (ii) memcpy(&y.i64[(size_t)(o * total * inner + off)], &t->i64[(size_t)(o * w)], (size_t)w * 8);
                     else memcpy(&y.f[(size_t)(o * total * inner + off)], &t->f[(size_t)(o * w)], (size_t)w * 4);
@@ -320,6 +626,7 @@ int seg_from_onnx(const OGraph& g, Pack& p, std::string& err)
 {
     std::vector<const ONode*> inorm, conv, lstm, mm;
     for (auto& n : g.nodes) {
+        if (!n.out.empty() && g.init.count(n.out[0])) continue;          // part of a constant sub-graph (e.g. the filter bank's own MatMuls): folded, not a layer
         if (n.op == "InstanceNormalization") inorm.push_back(&n);
         else if (n.op == "Conv") conv.push_back(&n);
         else if (n.op == "LSTM") lstm.push_back(&n);
@@ -407,6 +714,7 @@ int emb_from_onnx(const OGraph& g, Pack& p, std::string& err)
     std::vector<const ONode*> conv, bn;
     const OTensor* mel = nullptr;
     for (auto& n : g.nodes) {
+        if (!n.out.empty() && g.init.count(n.out[0])) continue;          // folded constant sub-graph
         if (n.op == "Conv") conv.push_back(&n);
         else if (n.op == "BatchNormalization") bn.push_back(&n);
         else if (n.op == "MatMul" && !mel)

@@ -427,10 +427,135 @@ def test_constant_folder_survives_malformed_nodes(tmp_path, case):
         assert e.value.code == 3 and ("expected" in str(e.value) or "no MatMul" in str(e.value))        # SD_ERR_MODEL with a reason
 
 
-def test_onnx_reader_under_address_and_ub_sanitizers(onnx_files, tmp_path):
+# ------------------------------------------------------------------ a PARAMETRISED first convolution: the real segment2.onnx most likely has one
+class _ParamSincFB(torch.nn.Module):
+    """asteroid_filterbanks.ParamSincFB as pyannote.audio's SincNet uses it (80 filters of 251 taps computed from 2 x 40 learnable
+    frequencies): cos / sin band-pass pairs, Hamming half-window, flip for the right half"""
+    def __init__(self, n_filters=80, kernel_size=251, sample_rate=16000.0, min_low_hz=50.0, min_band_hz=50.0):
+        super().__init__()
+        self.half, self.cutoff, self.kernel_size = kernel_size // 2, n_filters // 2, kernel_size
+        self.min_low_hz, self.min_band_hz, self.sample_rate = min_low_hz, min_band_hz, sample_rate
+        mel = np.linspace(2595 * np.log10(1 + 30 / 700), 2595 * np.log10(1 + (sample_rate / 2 - (min_low_hz + min_band_hz)) / 700), self.cutoff + 1)
+        hz = 700 * (10 ** (mel / 2595) - 1)
+        self.low_hz_ = torch.nn.Parameter(torch.from_numpy(hz[:-1]).view(-1, 1).float())
+        self.band_hz_ = torch.nn.Parameter(torch.from_numpy(np.diff(hz)).view(-1, 1).float())
+        n_lin = torch.linspace(0, kernel_size / 2 - 1, steps=self.half)
+        self.register_buffer("window_", 0.54 - 0.46 * torch.cos(2 * np.pi * n_lin / kernel_size))
+        self.register_buffer("n_", 2 * np.pi * (torch.arange(-self.half, 0.0).view(1, -1) / sample_rate))
+
+    def _make(self, low, high, kind):
+        band = (high - low)[:, 0]
+        ft_low, ft_high = torch.matmul(low, self.n_), torch.matmul(high, self.n_)
+        if kind == "cos":
+            left = ((torch.sin(ft_high) - torch.sin(ft_low)) / (self.n_ / 2)) * self.window_
+            center, right = 2 * band.view(-1, 1), torch.flip(left, dims=[1])
+        else:
+            left = ((torch.cos(ft_low) - torch.cos(ft_high)) / (self.n_ / 2)) * self.window_
+            center, right = torch.zeros_like(band.view(-1, 1)), -torch.flip(left, dims=[1])
+        return (torch.cat([left, center, right], dim=1) / (2 * band[:, None])).view(self.cutoff, 1, self.kernel_size)
+
+    def filters(self):
+        low = self.min_low_hz + torch.abs(self.low_hz_)
+        high = torch.clamp(low + self.min_band_hz + torch.abs(self.band_hz_), self.min_low_hz, self.sample_rate / 2)
+        return torch.cat([self._make(low, high, "cos"), self._make(low, high, "sin")], dim=0)
+
+
+class _SincPyanNet(nm.PyanNetModule):
+    def __init__(self, w):
+        super().__init__(w)
+        self.fb = _ParamSincFB()
+
+    def forward(self, signal):
+        F = torch.nn.functional
+        x = F.conv1d(self.wav_norm(signal), self.fb.filters(), stride=10)
+        x = F.leaky_relu(self.norm0(F.max_pool1d(torch.abs(x), 3, 3)))
+        x = F.leaky_relu(self.norm1(F.max_pool1d(self.conv1(x), 3, 3)))
+        x = F.leaky_relu(self.norm2(F.max_pool1d(self.conv2(x), 3, 3)))
+        h, _ = self.lstm(x.transpose(1, 2))
+        return torch.sigmoid(self.cls(F.leaky_relu(self.lin1(F.leaky_relu(self.lin0(h))))))
+
+
+@pytest.mark.parametrize("fold", [True, False])
+def test_segmentation_reader_evaluates_a_parametrised_sinc_filter_bank(weights, tmp_path, fold):
+    """pyannote.audio's SincNet does not store its first convolution's 80 x 251 weights: it computes them in forward() from 2 x 40
+    learnable frequencies (asteroid ParamSincFB).  torch.onnx.export cannot fold that sub-graph -- Abs, Clip, MatMul, Sin, Cos, a flip
+    (Slice with step -1), ConstantOfShape, Neg are not on the TorchScript exporter's folding list -- so the reference's segment2.onnx
+    (segment/export2.py:42-52) in all likelihood carries it in front of the Conv's weight input, with or without `do_constant_folding`.
+    The reader evaluates constant sub-graphs the way a runtime would (float32, numpy broadcasting) and must arrive at torch's filters;
+    the filter bank's own MatMuls must not be mistaken for the network's three linear layers."""
+    m = _SincPyanNet(weights[2]).eval()
+    path = str(tmp_path / "sinc.onnx")
+    _export(m, (torch.randn(2, 1, 80000) * 0.1,), path, ["signal"], ["segments"], {"signal": {0: "B", 2: "T"}}, do_constant_folding=fold)
+    raw = open(path, "rb").read()
+    for op in (b"Sin", b"Cos", b"Clip", b"MatMul"):
+        assert op in raw                                                     # the exporter did leave the sub-graph in the file
+    out = str(tmp_path / "sinc.sdw")
+    sdhip.convert_onnx(path, "segmentation", out)
+    p = nn.load_pack(out)
+    ref = m.fb.filters().detach().numpy()
+    got = p["sincnet.conv0.weight"]
+    assert got.shape == ref.shape == (80, 1, 251)
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()                # libm sin / cos against torch's: a few ulp of the largest tap
+    for k, v in weights[2].items():                                          # everything else: the bits that went in
+        if k != "sincnet.conv0.weight":
+            assert np.array_equal(p[k], v), k
+
+
+class _SBFilterbankEncoder(nm.EmbeddingModule):
+    """the embedding exporter's front end with speechbrain 0.5.14's Filterbank as embeddings/threeModel.py:181-227 uses it: constructed
+    inside forward(), it builds the triangular [201, 80] mel matrix from `f_central` / `band` with repeat, sub, div, min, max, transpose
+    on every call instead of holding it as a buffer"""
+    def __init__(self, w):
+        super().__init__(w)
+        sr, n_fft, n_mels, f_min, f_max = 16000, 400, 80, 0.0, 8000.0
+        to_mel = lambda hz: 2595 * np.log10(1 + hz / 700)
+        mel = torch.linspace(to_mel(f_min), to_mel(f_max), n_mels + 2)
+        hz = 700 * (10 ** (mel / 2595) - 1)
+        self.register_buffer("band", (hz[1:] - hz[:-1])[:-1])
+        self.register_buffer("f_central", hz[1:-1])
+        all_freqs = torch.linspace(0, sr // 2, n_fft // 2 + 1)
+        self.register_buffer("all_freqs_mat", all_freqs.repeat(n_mels, 1))
+        self.n_stft = n_fft // 2 + 1
+
+    def sb_matrix(self):
+        f_central_mat = self.f_central.repeat(self.n_stft, 1).transpose(0, 1)
+        band_mat = self.band.repeat(self.n_stft, 1).transpose(0, 1)
+        slope = (self.all_freqs_mat - f_central_mat) / band_mat
+        left_side, right_side = slope + 1.0, -slope + 1.0
+        return torch.max(torch.zeros(1), torch.min(left_side, right_side)).transpose(0, 1)
+
+    def forward(self, feats, wav_lens):
+        self.mel = self.sb_matrix()
+        return super().forward(feats, wav_lens)
+
+
+@pytest.mark.parametrize("fold", [True, False])
+def test_embedding_reader_evaluates_a_filterbank_built_in_forward(weights, tmp_path, fold):
+    """the [201, 80] mel matrix the reader looks for may not be an initializer at all: speechbrain's Filterbank, built inside the exported
+    forward(), computes it from 80 centre frequencies with Tile / Sub / Div / Min / Max / Transpose.  Evaluated as a constant sub-graph it
+    must be the matrix torch computes, and the rest of the pack the bits that went in."""
+    w = dict(weights[3])
+    m = _SBFilterbankEncoder(w).eval()
+    st = nn.stft_ref((0.1 * np.random.default_rng(0).standard_normal((2, 80000))).astype(np.float32))
+    path = str(tmp_path / "sbfb.onnx")
+    _export(m, (st, torch.tensor([1.0, 0.7])), path, ["feats", "wav_lens"], ["embedding"], do_constant_folding=fold)
+    if not fold:
+        assert b"Tile" in open(path, "rb").read() or b"Expand" in open(path, "rb").read()      # the repeat() is in the file
+    out = str(tmp_path / "sbfb.sdw")
+    sdhip.convert_onnx(path, "embedding", out)
+    p = nn.load_pack(out)
+    ref = m.sb_matrix().numpy()
+    assert p["fbank.matrix"].shape == (201, 80) and np.array_equal(p["fbank.matrix"], ref)
+    for k in p:
+        if k != "fbank.matrix":
+            assert np.array_equal(p[k], weights[3][k]), k
+
+
+def test_onnx_reader_under_address_and_ub_sanitizers(onnx_files, weights, tmp_path):
     """the code that parses untrusted model files (protobuf reader, constant folder, layer extraction, weight-pack reader), built for
     the CPU with AddressSanitizer + UBSan (tools/sanitize/build.sh) and run over: the malformed weight-shuffling graphs above, the two
-    valid exports, truncations of a valid export at 60 lengths and 300 single-byte corruptions of it.  No sanitizer report, no crash;
+    valid exports, truncations of a valid export at 60 lengths, 300 single-byte corruptions of it, and 200 corruptions of an export whose first
+    convolution is a parametrised filter bank (the arithmetic constant evaluator).  No sanitizer report, no crash;
     the valid files convert."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -469,11 +594,22 @@ def test_onnx_reader_under_address_and_ub_sanitizers(onnx_files, tmp_path):
         p = tmp_path / ("flip%03d.onnx" % j)
         p.write_bytes(bytes(bad))
         paths.append(str(p))
-    paths += [onnx_files[0], onnx_files[1]]
+    # the arithmetic evaluator: a graph with a parametrised sinc filter bank in front of its first convolution, 200 corruptions of its node region
+    sinc = str(tmp_path / "sinc_good.onnx")
+    _export(_SincPyanNet(weights[2]).eval(), (torch.randn(2, 1, 80000) * 0.1,), sinc, ["signal"], ["segments"], {"signal": {0: "B", 2: "T"}}, do_constant_folding=False)
+    sgood = open(sinc, "rb").read()
+    for j in range(200):
+        bad = bytearray(sgood)
+        pos = int(rng.integers(0, min(len(bad), 30000)))
+        bad[pos] = int(rng.integers(0, 256))
+        p = tmp_path / ("sflip%03d.onnx" % j)
+        p.write_bytes(bytes(bad))
+        paths.append(str(p))
+    paths += [sinc, onnx_files[0], onnx_files[1]]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     out = subprocess.run([exe] + paths, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
     assert "Sanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
     lines = out.stdout.splitlines()
     assert len(re.findall(r" kind [01] -> \d", out.stdout)) == 2 * len(paths)               # (a corrupted tensor name may put a newline into a message)
-    assert lines[-4].endswith("kind 0 -> 0 ") and lines[-1].endswith("kind 1 -> 0 ")        # segment2.onnx as segmentation, emd4.onnx as embedding
+    assert lines[-6].endswith("kind 0 -> 0 ") and lines[-4].endswith("kind 0 -> 0 ") and lines[-1].endswith("kind 1 -> 0 ")   # sinc and plain segment2.onnx as segmentation, emd4.onnx as embedding
