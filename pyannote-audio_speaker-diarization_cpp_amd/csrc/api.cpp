@@ -233,6 +233,22 @@ extern "C" int sd_ecapa(sd_ctx* c, const float* h_feats, const float* h_lens, in
 }
 
 // ------------------------------------------------------------------ wav reader (a1)
+// bytes of the data chunk that are really in the file.  A wav written to a pipe (ffmpeg, sox) announces 0xFFFFFFFF (or 0) because the
+// writer could not seek back; the reference trusts the header (wav.h:92-97) and would "read" two billion samples from a short file.
+// Deliberate deviation, input robustness only: what is announced beyond the end of the file is not read, and a size of
+// 0 / 0xFFFFFFFF means "up to the end of the file".
+static uint32_t data_bytes_present(FILE* fp, uint32_t announced)
+{
+    const long cur = ftell(fp);
+    if (cur < 0 || fseek(fp, 0, SEEK_END) != 0) return announced;
+    const long end = ftell(fp);
+    (void)fseek(fp, cur, SEEK_SET);
+    if (end < cur) return announced;
+    const uint64_t remaining = (uint64_t)(end - cur);
+    if (announced == 0xFFFFFFFFu || announced == 0 || (uint64_t)announced > remaining) return (uint32_t)(remaining > 0xFFFFFFFEull ? 0xFFFFFFFEull : remaining);
+    return announced;
+}
+
 extern "C" int sd_read_wav(const char* path, int16_t** pcm, int64_t* n, int32_t* sample_rate, int32_t* channels)
 {
     if (!path || !pcm || !n) return SD_ERR_ARG;
@@ -257,6 +273,7 @@ extern "C" int sd_read_wav(const char* path, int16_t** pcm, int64_t* n, int32_t*
         memcpy(tag, t8, 4); memcpy(&dsz, t8 + 4, 4);
     }
     if (bits != 16) { fclose(fp); return SD_ERR_ARG; } // README.md:37: 16 kHz / mono / 16 bit only
+    dsz = data_bytes_present(fp, dsz);
     int64_t num = dsz / 2;
     int16_t* buf = (int16_t*)malloc((size_t)(num > 0 ? num : 1) * sizeof(int16_t));
     int64_t got = (int64_t)fread(buf, 2, (size_t)num, fp);
@@ -305,6 +322,7 @@ extern "C" int sd_read_wav_f32(const char* path, float** wav, int64_t* n, int32_
     }
     if (bits != 8 && bits != 16 && bits != 32) { fclose(fp); return SD_ERR_ARG; }     // reference: exit(1), wav.h:119-121
     const int bps = bits / 8;
+    dsz = data_bytes_present(fp, dsz);
     const int64_t num = dsz / bps;
     std::vector<unsigned char> raw((size_t)(num > 0 ? num * bps : 1));
     const size_t got = fread(raw.data(), 1, (size_t)num * bps, fp);

@@ -48,6 +48,27 @@ def test_wav_reader_multichannel_is_read_interleaved_like_the_reference(tmp_path
     assert ch == 2 and len(w) == 100 and np.array_equal(w, w_ref)
 
 
+def test_wav_reader_streamed_and_truncated_headers(tmp_path):
+    """a wav written to a pipe (ffmpeg -f wav -, sox) cannot seek back to fill in its sizes and announces 0xFFFFFFFF (or 0) for the data
+    chunk; a file cut off in transit announces more than it holds.  The reference trusts the header (wav.h:92-97); the library reads what is
+    there (deliberate deviation, input robustness) -- and a well-formed file is read exactly as before"""
+    s = (np.arange(3000) % 700 - 350).astype(np.int64) * 40
+    good = _wav_bytes(s, 16)
+    at = good.index(b"data") + 4                                           # the data chunk's size field (an extra LIST chunk sits in front)
+    want = (s.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    for name, data, n_expect in (("stream_ff.wav", good[:at] + struct.pack("<I", 0xFFFFFFFF) + good[at + 4:], 3000),
+                                 ("stream_0.wav", good[:at] + struct.pack("<I", 0) + good[at + 4:], 3000),
+                                 ("cut.wav", good[:at + 4 + 2 * 1234], 1234),
+                                 ("good.wav", good, 3000)):
+        p = tmp_path / name
+        p.write_bytes(data)
+        w, sr, ch, b = sdhip.read_wav_f32(str(p))
+        assert (sr, ch, b, len(w)) == (16000, 1, 16, n_expect), name
+        assert np.array_equal(w, want[:n_expect]), name
+        pcm, sr2, ch2 = sdhip.read_wav(str(p))
+        assert len(pcm) == n_expect and np.array_equal(pcm, s[:n_expect].astype(np.int16)), name
+
+
 def test_wav_reader_errors(tmp_path):
     p = tmp_path / "bad.wav"
     p.write_bytes(_wav_bytes(np.zeros(10), 16)[:30])
