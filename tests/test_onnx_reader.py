@@ -613,3 +613,25 @@ def test_onnx_reader_under_address_and_ub_sanitizers(onnx_files, weights, tmp_pa
     lines = out.stdout.splitlines()
     assert len(re.findall(r" kind [01] -> \d", out.stdout)) == 2 * len(paths)               # (a corrupted tensor name may put a newline into a message)
     assert lines[-6].endswith("kind 0 -> 0 ") and lines[-4].endswith("kind 0 -> 0 ") and lines[-1].endswith("kind 1 -> 0 ")   # sinc and plain segment2.onnx as segmentation, emd4.onnx as embedding
+
+
+@pytest.mark.gpu
+def test_segmentation_from_a_parametrised_sinc_export_matches_the_exported_module(weights, tmp_path):
+    """end to end through the operator seam: sd_create on an ONNX file whose first convolution is a parametrised sinc filter bank (the
+    reader evaluates the filters), sd_segment on the GPU, against the very torch module that was exported"""
+    import synth
+    m = _SincPyanNet(weights[2]).eval()
+    path = str(tmp_path / "sinc.onnx")
+    _export(m, (torch.randn(2, 1, 80000) * 0.1,), path, ["signal"], ["segments"], {"signal": {0: "B", 2: "T"}}, do_constant_folding=True)
+    d = sdhip.Diarizer(path, None)
+    try:
+        pcm = synth.make_pcm(12.0, seed=4)
+        wav = pcm.astype(np.float32) / np.float32(32768.0)
+        seg = d.segment(wav)
+        from oracle import orc
+        nc, _ = orc.num_chunks(len(wav))
+        with torch.no_grad():
+            ref = m(torch.from_numpy(np.stack([orc.crop(wav, i * 8000) for i in range(nc)]))[:, None, :]).numpy()
+        assert seg.shape == ref.shape and np.allclose(seg, ref, rtol=1e-3, atol=1e-4), np.abs(seg - ref).max()
+    finally:
+        d.close()
