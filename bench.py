@@ -479,6 +479,7 @@ def main():
     cg_all = d.kernel_stats("conv_gemm_f16" if a.precision == "f16" else "conv_gemm")      # every MFMA convolution launch of the precision
     cg = d.kernel_stats("conv_w256_f16" if a.precision == "f16" else "conv_w256_f32")       # the dominant kernel alone: k_conv_gemm_w256
     cg_f32 = d.kernel_stats("conv_gemm_f32")
+    cg_e, cg_s = d.kernel_stats("conv_w256_ecapa"), d.kernel_stats("conv_w256_seg")
     stages = d.stage_ms()
     extra = {}
     for k in ("stft_mel", "lstm_rec", "pdist", "linkage", "linkage_heap", "row_nn", "se_apply", "asp_pool", "rccl_all_gather"):
@@ -619,7 +620,7 @@ def main():
                                           "pipelined rate of back-to-back jobs (rank 0 finalizes job k while the others infer job k+1)"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_conv_gemm_w256<false> (v_mfma_f32_32x32x2_f32, 256 x 256 tile): every ECAPA layer with Cout >= 256" if a.precision == "f32" else
+                         "kernel": "k_conv_gemm_w256<false> (v_mfma_f32_32x32x2_f32, 256 x 256 tile): every ECAPA layer with Cout >= 256 + PyanNet's LSTM input projections" if a.precision == "f32" else
                                    "k_conv_gemm_w256<true> (v_mfma_f32_32x32x16_f16, fp16 activations): the wide ECAPA layers",
                          "all_mfma_conv_launches": {"what": "k_conv_gemm_w256 + k_conv_gemm (128 x 128 tile: Res2Net, ASP tdnn%s) %s" %
                                                             ((", PyanNet) + k_conv_narrow (SincNet", "of the step") if a.precision == "f32" else ("", "in fp16")),
@@ -630,6 +631,13 @@ def main():
                                                     "algorithmic_gflop_per_step": round(cg_all["flops"] / max(a.steps, 1) / 1e9, 1)},
                          "f32_launches_beside": None if a.precision == "f32" else {"what": "PyanNet layers, f32 MFMA", "kernel_ms_per_step": round(cg_f32["ms"] / max(a.steps, 1), 2),
                                                                                    "TFLOPs": round(cg_f32["flops"] / max(cg_f32["ms"], 1e-9) / 1e9, 1)},
+                         "by_caller": None if a.precision != "f32" else {
+                             "what": "the same kernel's launches split by caller: the ECAPA layers (Cout >= 256; all of round 2's launches) and, since round 3, PyanNet's LSTM input "
+                                     "projections (K = 256, moved here from the 128 x 128 kernel: 103 -> 120 TF for them, and a lower average for this kernel)",
+                             "ecapa_layers": {"achieved": round(cg_e["flops"] / max(cg_e["ms"], 1e-9) / 1e9, 2), "frac": round(cg_e["flops"] / max(cg_e["ms"], 1e-9) / 1e9 / peak, 4),
+                                              "launches_per_step": cg_e["launches"] // max(a.steps, 1), "kernel_ms_per_step": round(cg_e["ms"] / max(a.steps, 1), 2)},
+                             "lstm_input_projections": {"achieved": round(cg_s["flops"] / max(cg_s["ms"], 1e-9) / 1e9, 2), "launches_per_step": cg_s["launches"] // max(a.steps, 1),
+                                                        "kernel_ms_per_step": round(cg_s["ms"] / max(a.steps, 1), 2)}},
                          "launches_per_step": cg["launches"] // max(a.steps, 1),
                          "avg_launch_ms": round(cg["ms"] / max(cg["launches"], 1), 4),
                          "kernel_ms_per_step": round(cg["ms"] / max(a.steps, 1), 2),

@@ -360,6 +360,7 @@ int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& in, const char* tag)
         ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
         ProfScope ps16(c, h ? "conv_gemm_f16" : "conv_gemm_f32", flops, bytes);
         ProfScope psw(c, h ? "conv_w256_f16" : "conv_w256_f32", flops, bytes);         // this kernel alone (bench.py's roofline object)
+        ProfScope pss(c, strcmp(tag, "lstm_ih") == 0 ? "conv_w256_seg" : "conv_w256_ecapa", flops, bytes);   // ... split by caller (PyanNet's K = 256 projections / the ECAPA layers)
         if (h) hipLaunchKernelGGL(k_conv_gemm_w256<true>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
         else hipLaunchKernelGGL(k_conv_gemm_w256<false>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
     }
