@@ -190,7 +190,7 @@ int build_ecapa_weights(sd_ctx* c, const Pack& p);
 int build_seg_weights(sd_ctx* c, const Pack& p);
 // ---- frontend.hip
 int frontend_prepare(sd_ctx* c, const float* d_masks, int64_t items, int64_t first_item, float* d_wav_lens, int* d_nnorm, int* d_nvalid,
-                     int* d_flags, bool compact, int* h_n_active, int* d_cidx);
+                     int* d_flags, bool compact, int* h_n_active, int* d_cidx, std::vector<int>* h_nvalid = nullptr);
 int frontend_features(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_item, int64_t run_items, bool compact, const int* d_nnorm,
                       const int* d_rowoff, float* d_feats /*[rowoff[run_items]][96]*/);
 // ---- ecapa.hip

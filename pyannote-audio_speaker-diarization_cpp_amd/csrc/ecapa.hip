@@ -381,13 +381,11 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
     WS(c, int, d_rowoff, "emb_rowoff", EC_SPACES * (items + 1));
     WS(c, float, emb_c, "emb_compact", items * SD_EMB_DIM);
     int n_active = 0;
-    if ((rc = frontend_prepare(c, d_masks, items, first_item, lens, nnorm, nvalid, flags, true, &n_active, cidx))) return rc;
+    std::vector<int> h_nvalid;
+    if ((rc = frontend_prepare(c, d_masks, items, first_item, lens, nnorm, nvalid, flags, true, &n_active, cidx, &h_nvalid))) return rc;
     { KernelStat& ks = c->stats["items_live"]; ks.launches++; ks.flops += (double)n_active; ks.bytes += (double)items; }   // bench: live / all items
     if (n_active > 0) {
-        std::vector<int> h_nvalid((size_t)n_active);
         EcapaRowPlan plan;
-        HIPCHK(c, hipMemcpyAsync(h_nvalid.data(), nvalid, (size_t)n_active * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
         if ((rc = ecapa_row_plan(c, h_nvalid.data(), n_active, plan, d_rowoff))) return rc;
         const std::vector<int>& rowoff = plan.off[0];
         const int64_t rows_all = rowoff[(size_t)n_active];

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(1024) void k_compact_active(const int* __restrict__
 // rule are dropped -- *h_n_active receives the number of live items, d_nnorm / d_nvalid are indexed by the compact position,
 // d_cidx[item] = compact position or -1.  The prefix tables, sample counts and the active list stay in workspaces for phase B.
 int frontend_prepare(sd_ctx* c, const float* d_masks, int64_t items, int64_t first_item, float* d_wav_lens, int* d_nnorm, int* d_nvalid,
-                     int* d_flags, bool compact, int* h_n_active, int* d_cidx)
+                     int* d_flags, bool compact, int* h_n_active, int* d_cidx, std::vector<int>* h_nvalid)
 {
     if (!c->ew.loaded) SD_FAIL(c, SD_ERR_MODEL, "embedding model not loaded");
     if (h_n_active) *h_n_active = (int)items;
@@ -298,8 +298,11 @@ int frontend_prepare(sd_ctx* c, const float* d_masks, int64_t items, int64_t fir
         KCHECK(c);
         int na = 0;
         HIPCHK(c, hipMemcpyAsync(&na, t_nact, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        // the compacted nvalid array travels with the count (one synchronisation for both: the host plans the row spaces from it)
+        if (h_nvalid) { h_nvalid->assign((size_t)items, 0); HIPCHK(c, hipMemcpyAsync(h_nvalid->data(), d_nvalid, (size_t)items * sizeof(int), hipMemcpyDeviceToHost, c->stream)); }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (h_n_active) *h_n_active = na;
+        if (h_nvalid) h_nvalid->resize((size_t)na);
     } else {
         hipLaunchKernelGGL(k_wav_lens, dim3((unsigned)((items + 31) / 32)), dim3(64), 0, c->stream, d_counts, (int)items, d_wav_lens, d_nnorm, d_nvalid, d_flags);
         KCHECK(c);
