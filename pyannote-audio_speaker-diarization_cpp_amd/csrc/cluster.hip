@@ -1192,14 +1192,17 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     int G = (int)c->linkage_wgs;
     // auto geometry (measured on clustered data, profiles/r01_linkage_scaling.txt, r02_linkage_stamps.txt, r03_linkage_*.txt): up to N = 30 000
     // the one-XCD form with one workgroup on each of the XCD's 32 CUs; above, all XCDs
-    const bool auto_onex = G < 0 && c->linkage_one_xcd != 0 && c->num_cu >= 256 && N >= 1500 && N < 30000;
+    // (r03, square form: one XCD wins up to N ~ 70 000 -- 384 ms against 443 at N = 50 158, 719 against 715 at N = 75 090 -- all XCDs above: 987 ms against 1 064 at
+    // N = 100 174; all XCDs: 64 workgroups up to ~90 000 rows, 128 above)
+    const bool auto_onex = G < 0 && c->linkage_one_xcd != 0 && c->num_cu >= 256 && N >= 1500 && N < 70000;
     if (auto_onex) G = 32;
-    if (G < 0) G = N >= 60000 ? 128 : N >= 8000 ? 64 : N >= 1500 ? 32 : 0;
+    if (G < 0) G = N >= 90000 ? 128 : N >= 8000 ? 64 : N >= 1500 ? 32 : 0;
     if (G > c->num_cu) G = c->num_cu;
     int TH = (int)c->linkage_threads;
     // measured (r03, square form, N = 12 602, one XCD, three boxes): 32 x 256 75.2 / 82.7 / 76.8 ms, 32 x 512 84.4 / 77.2 / 85.0 ms -- the
     // boxes disagree, 256 wins on two of three; all XCDs 128 x 512 0.99 s at N = 100 174 (128 x 256: 1.10 s)
-    if (TH <= 0) TH = auto_onex ? 256 : N >= 8000 ? 512 : 256;
+    // one XCD, larger N: 512 threads (N = 18 867: 121 ms against 126; N = 25 274: 170 against 179; N = 50 158: 384 against 465)
+    if (TH <= 0) TH = auto_onex ? (N >= 16000 ? 512 : 256) : N >= 8000 ? 512 : 256;
     TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : TH >= 256 ? 256 : 128;
     if (G <= 1) {
         WS(c, double, D, "cl_D", m);
