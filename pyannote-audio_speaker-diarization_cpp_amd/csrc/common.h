@@ -40,6 +40,8 @@ struct ConvLayer {
     float* shift = nullptr;
     int Cin = 0, CinPad = 0, Cout = 0, KT = 1, dil = 1;
     int CinPad16 = 0;         // row length of W16 (multiple of 64)
+    void* W16x = nullptr;     // option ecapa_precision = 3: [KT][Cout][CinPad / 32][32 hi | 32 lo] fp16 planes of W * w16x_scale (a power of two)
+    float w16x_inv = 1.0f;    // 1 / w16x_scale
 };
 
 struct ConvArgs {
@@ -68,7 +70,10 @@ struct ConvArgs {
     int in_rows;
     int y_f32;             // fp16 mode: Y is float all the same (the attention logits feed an exp)
     int kt_real;           // fp16 split-weight mode: KT counts 2 * kt_real weight planes (hi, then lo) and tap kk shifts the rows like tap kk % kt_real; 0 = KT
-    int prec;              // 0 = f32 (X, X2, W, Y are float), 1 = fp16 end to end (X, X2, W16, Y are _Float16; option ecapa_precision)
+    int prec;              // 0 = f32 (X, X2, W, Y are float), 1 = fp16 end to end (X, X2, W16, Y are _Float16; option ecapa_precision),
+                           // 3 = f32 tensors, split fp16 operands on the matrix pipe (W16x; wide layers only, conv_gemm_h.hip)
+    const void* W16x;      // prec 3: split weights (ConvLayer::W16x)
+    float acc_scale;       // prec 3: 1 / weight scale, applied to the accumulator in the epilogue
 };
 #define ROWTAB_T(y) ((y) & 1023)
 #define ROWTAB_LAST(y) (((y) >> 10) & 1023)
@@ -116,7 +121,7 @@ struct sd_ctx {
     int64_t emb_batch_items = 768;             // multiple of 96
     int64_t seg_batch_chunks = 4096;           // 128 LSTM workgroups per direction: one full wave of CUs
     int num_clusters = -1, min_clusters = -1, max_clusters = -1;   // optional constraints for the whole-path entry points
-    int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation, 2 = the same with hi + lo fp16 weight planes
+    int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation, 2 = the same with hi + lo fp16 weight planes, 3 = f32 tensors, hi + lo split of BOTH operands on the fp16 MFMA (wide layers; the others stay f32)
     bool ecapa_keep_cat = false;                // diagnostics: f32 mode keeps the block outputs (the logits get their own buffer)
     int ecapa_f16_hp = 0;                       // fp16 mode: bit 0 = MFA output / pooling inputs in f32, bit 1 = attention branch on the f32 MFMA
     bool conv_w256_f32 = true;                  // f32: the same 256 x 256 kernel for the wide, long-K ECAPA layers (TDNN, MFA)

@@ -557,7 +557,8 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     if (f16 && !a.W16) SD_FAIL(c, SD_ERR_ARG, "conv_gemm(%s): fp16 mode without fp16 weights", tag);
     if (a.Cin % (f16 ? 64 : BK) != 0) SD_FAIL(c, SD_ERR_ARG, "conv_gemm(%s): Cin=%d not a multiple of %d", tag, a.Cin, f16 ? 64 : BK);
     if (a.M <= 0) return SD_OK;
-    if ((f16 && c->conv_h256) || (!f16 && c->conv_w256_f32)) { const int r = launch_conv_gemm_h256(c, a, tag); if (r != 1) return r; }
+    if ((f16 && c->conv_h256) || (!f16 && c->conv_w256_f32) || a.prec == 3) { const int r = launch_conv_gemm_h256(c, a, tag); if (r != 1) return r; }
+    if (a.prec == 3) a.prec = 0;              // a layer the wide kernel does not take (X2, per-item bias, Cout not a multiple of 256): the f32 kernels below
     if (a.prec == 0 && a.KT == 1 && a.M <= 2048 && a.TpIn == a.M && a.TpOut == a.M && a.T == a.M && a.Tin == a.M && !a.X2 && !a.item_bias && !a.R && !a.rowtab &&
         (a.x_ld & 3) == 0 && (a.w_ld & 3) == 0) {
         const int cinr = a.cin_real > 0 ? a.cin_real : a.Cin;

@@ -24,12 +24,19 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define HN 256
 #define HLDP 36            // LDS row: 64 halves + 8 halves of padding = 36 floats = 144 B (conflict-free ds_read_b128, see conv_gemm.hip)
 
-// H = true: fp16 operands (v_mfma_f32_32x32x16_f16, one MFMA per tile and k-block of 16); H = false: f32 operands
+// P = 1: fp16 operands (v_mfma_f32_32x32x16_f16, one MFMA per tile and k-block of 16); P = 0: f32 operands
 // (v_mfma_f32_32x32x2_f32 over the k pairs (k, k + 16) of a 32-chunk, four MFMAs per tile and K-group, conv_gemm.hip's order)
-template <bool H>
+// P = 3 ("x3", option ecapa_precision = 3): f32 tensors in HBM, 22-bit operands on the fp16 matrix pipe.  Every f32 activation is split when it
+// is staged, hi = fp16(a), lo = fp16(a - hi); the weights come split (and scaled by a power of two, so that the lo plane stays out of the
+// fp16 subnormals) from weights.cpp: a K-step is 32 channels = a 128-byte LDS row [hi 0..31 | lo 0..31] on both sides, and every 16-channel
+// block runs hi*hi + lo*hi + hi*lo (the lo*lo term, 2^-22 of the product, is dropped): 48 MFMAs of 32 cycles per wave and K-step where the
+// f32 form needs 128 of 64 cycles, with the f32 form's bytes.  f32 accumulation, f32 epilogue (times 1 / weight scale), f32 stores.
+template <int P>
 __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
 {
-    constexpr int ES = H ? 2 : 4;                    // bytes per element; a K-step is 128 bytes of every row either way
+    constexpr bool H = P == 1, X = P == 3;
+    constexpr int ES = H ? 2 : 4;                    // bytes per activation element; a K-step is 128 bytes of every row in all three forms
+    constexpr int ESB = (H || X) ? 2 : 4;            // bytes per weight element
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const As0 = lds;                          // [2][HM * HLDP]
     float* const Bs0 = lds + 2 * HM * HLDP;          // [2][HN * HLDP]
@@ -86,9 +93,9 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
     };
     __amdgpu_buffer_rsrc_t rA = make_rsrc(a.X, 0);
-    const __amdgpu_buffer_rsrc_t rB = make_rsrc(H ? a.W16 : (const void*)a.W, (size_t)a.KT * a.Cout * a.w_ld * ES);
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(X ? a.W16x : H ? a.W16 : (const void*)a.W, (size_t)a.KT * a.Cout * a.w_ld * ESB);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)((r0 + 64 * p) * a.w_ld * ES + c4 * 16);
+    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)((r0 + 64 * p) * a.w_ld * ESB + c4 * 16);
     int l_q = q0, l_kk = 0, l_kc = 0, m0l = 0, n0l = 0;
     unsigned sK = 0, sB = 0;
     auto set_tile = [&](int sb) {
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
             voA[p] = (unsigned)(rrel[p] + qr) * (unsigned)a.x_ld * ES + c4 * 16;
         }
         // weight rows beyond Cout (a 256-wide tile over Cout = 1024 / 3072 never has any) are clamped by the descriptor
-        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * ES);
+        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * ESB);
     };
     auto advance = [&]() {
         if (++l_kc < kcs) { sK += 128; return; }
@@ -140,7 +147,15 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
         float* A = As0 + buf * HM * HLDP; float* B = Bs0 + buf * HN * HLDP;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            *(float4*)&A[(r0 + 64 * p) * HLDP + c4 * 4] = make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]);
+            if constexpr (X) {
+                // split the four f32 channels 4 c4 .. + 3: hi halves at byte 8 c4 of the row, lo halves at 64 + 8 c4
+                half4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)ra[p][e]; lo[e] = (_Float16)(ra[p][e] - (float)hi[e]); }
+                *(half4*)&A[(r0 + 64 * p) * HLDP + c4 * 2] = hi;
+                *(half4*)&A[(r0 + 64 * p) * HLDP + 16 + c4 * 2] = lo;
+            } else
+                *(float4*)&A[(r0 + 64 * p) * HLDP + c4 * 4] = make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]);
             *(float4*)&B[(r0 + 64 * p) * HLDP + c4 * 4] = make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]);
         }
     };
@@ -155,9 +170,27 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
 
     // one 16-byte fragment per lane, row and K-group kb (4 groups per K-step).  fp16: lane (li, lh) holds k = 16 kb + 8 lh .. +7 of
     // row li (float offset lh * 4 + kb * 8 of the 144-byte row); f32: k = 16 lh + 4 kb .. +3 (float offset lh * 16 + kb * 4)
+    // x3: the four 16-byte groups of a row are hi k 0..15, hi k 16..31, lo k 0..15, lo k 16..31 (the fp16 form's offsets)
     float4 ha[2][2], hb[2][4];
+    auto afrag = [&](int buf, int kb, int fbuf) {
+        const float* Ab = As0 + buf * HM * HLDP + (wr * 64 + li) * HLDP + lh * 4 + kb * 8;
+        ha[fbuf][0] = *(const float4*)Ab;
+        ha[fbuf][1] = *(const float4*)(Ab + 32 * HLDP);
+    };
+    auto bfrag = [&](int buf, int kb, int fbuf) {
+        const float* Bb = Bs0 + buf * HN * HLDP + (wc * 128 + li) * HLDP + lh * 4 + kb * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hb[fbuf][j] = *(const float4*)(Bb + j * 32 * HLDP);
+    };
+    auto xmma = [&](int fa, int fb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ha[fa][0]), __builtin_bit_cast(half8, hb[fb][j]), acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ha[fa][1]), __builtin_bit_cast(half8, hb[fb][j]), acc[1][j], 0, 0, 0);
+        }
+    };
     auto hfrag = [&](int buf, int kb, int fbuf) {
-        const int ko = H ? lh * 4 + kb * 8 : lh * 16 + kb * 4;
+        const int ko = (H || X) ? lh * 4 + kb * 8 : lh * 16 + kb * 4;
         const float* Ab = As0 + buf * HM * HLDP + (wr * 64 + li) * HLDP + ko;
         const float* Bb = Bs0 + buf * HN * HLDP + (wc * 128 + li) * HLDP + ko;
         ha[fbuf][0] = *(const float4*)Ab;
@@ -207,6 +240,40 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
         // cycles, profiles/pmc_conv_gemm_bench.json).  sched_group_barrier pins them behind the FIRST MFMAs of the region, one
         // memory instruction per MFMA (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write).
 #define W_PAIR(mask, n) do { _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); } } while (0)
+        if constexpr (X) {
+            // x3: six groups of 8 MFMAs per K-step.  Fragment registers A0 / W0 hold hi block 0 of this step on entry; every group's operands
+            // are read one group ahead into the registers the group before last released; global loads are issued in group 1 and restaged in
+            // group 5 (four groups = 1024 MFMA cycles of latency budget, twice the fp16 form's)
+            afrag(buf, 2, 1);                      // lo block 0 of A
+            gload();
+            xmma(0, 0);                            // hi0 * hi0
+            W_PAIR(0x100, 2);
+#pragma unroll
+            for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bfrag(buf, 2, 1);                      // lo block 0 of W
+            xmma(1, 0);                            // lo0 * hi0
+            W_PAIR(0x100, 4); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            afrag(buf, 1, 1); bfrag(buf, 1, 0);    // hi block 1 of both
+            xmma(0, 1);                            // hi0 * lo0
+            W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            afrag(buf, 3, 0);                      // lo block 1 of A
+            xmma(1, 0);                            // hi1 * hi1
+            W_PAIR(0x100, 2); __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bfrag(buf, 3, 1);                      // lo block 1 of W
+            xmma(0, 0);                            // lo1 * hi1
+            lstore(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            afrag(buf ^ 1, 0, 0); bfrag(buf ^ 1, 0, 0);
+            xmma(1, 1);                            // hi1 * lo1
+            W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         hfrag(buf, 1, 1);
         gload();
         hmma(0);
@@ -241,13 +308,15 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
         hmma(1);
         W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, H ? 2 : 26, 0);
         __builtin_amdgcn_sched_barrier(0);
+        }
         advance();
 
         if (s == S - 1) {
             // ---- epilogue.  C layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); see conv_gemm.hip
             const float slope = (a.act1 == 1) ? 0.0f : ((a.act1 == 2) ? 0.01f : 1.0f);
             if constexpr (!H) {
-                // f32: every accumulator register is one output row for 32 consecutive columns across a half-wave: stored as it
+                const float as = X ? a.acc_scale : 1.0f;
+                // f32 (and x3): every accumulator register is one output row for 32 consecutive columns across a half-wave: stored as it
                 // lies, 128 contiguous bytes per row and instruction, no lane transposes (half the epilogue's VALU work).  The
                 // descriptor starts at the tile's first row and ends at the batch's last one, so rows >= M are dropped by the range
                 // check; the row term travels in the scalar offset.
@@ -264,7 +333,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
                         const unsigned vo = (unsigned)(wr * 64 + i * 32 + 4 * lh) * ybytes + (unsigned)cc * 4u;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            float v = acc[i][j][r] + cb;
+                            float v = X ? acc[i][j][r] * as + cb : acc[i][j][r] + cb;
                             acc[i][j][r] = 0.0f;
                             v = fmaxf(v, v * slope);
                             v = v * cs + ch;
@@ -332,20 +401,22 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
 int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& in, const char* tag)
 {
     ConvArgs a = in;
-    const bool h = a.prec == 1;
-    if (!a.rowtab || (h && !a.W16) || a.X2 || a.item_bias || a.R || a.act2 || a.pad_mode != 0 || a.Cout < 256 || (a.Cout % HN) != 0 || (a.y_ld & 3) ||
-        a.Cin % (h ? 64 : 32) != 0 || a.M < 8 * HM) return 1;
+    const bool h = a.prec == 1, x3 = a.prec == 3;
+    if (!a.rowtab || (h && !a.W16) || (x3 && !a.W16x) || a.X2 || a.item_bias || a.R || a.act2 || a.pad_mode != 0 || a.Cout < 256 || (a.Cout % HN) != 0 || (a.y_ld & 3) ||
+        a.Cin % (h ? 64 : 32) != 0 || (a.M < 8 * HM && !x3)) return 1;      // (x3 takes every batch size: the arithmetic of a layer must not depend on it)
     // fp16: the shortest contraction (ASP conv, K = 128) stays on the 128 x 128 form (measured); f32 takes every wide layer since the
     // K-groups are pinned (block0 K = 400: 92 -> 102 TF, ASP conv K = 128: 95 -> 105 TF)
-    if ((int64_t)a.Cin * (a.kt_real > 0 ? a.kt_real : a.KT) < (c->conv_w256_kmin > 0 ? c->conv_w256_kmin : (h ? 256 : 128))) return 1;
+    if (!x3 && (int64_t)a.Cin * (a.kt_real > 0 ? a.kt_real : a.KT) < (c->conv_w256_kmin > 0 ? c->conv_w256_kmin : (h ? 256 : 128))) return 1;
     static bool attr_set = false;
     const size_t lds_bytes = (size_t)2 * (HM + HN) * HLDP * sizeof(float);
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv_gemm_w256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_conv_gemm_w256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        if (hipFuncSetAttribute((const void*)k_conv_gemm_w256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_gemm_w256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_gemm_w256<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
         attr_set = true;
     }
     if (a.w_ld <= 0) a.w_ld = a.Cin;
+    if (x3) a.w_ld = 2 * a.Cin;              // halves: every 32-channel chunk of a row is [32 hi | 32 lo]
     a.m_tiles = (a.M + HM - 1) / HM;
     a.n_tiles = (a.Cout + HN - 1) / HN;
     a.sched = c->conv_pn;
@@ -358,11 +429,12 @@ int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& in, const char* tag)
     const double bytes = (h ? 2.0 : 4.0) * ((double)a.M * cin + (double)a.M * a.Cout + (double)a.Cout * cin * a.KT);
     {
         ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
-        ProfScope ps16(c, h ? "conv_gemm_f16" : "conv_gemm_f32", flops, bytes);
-        ProfScope psw(c, h ? "conv_w256_f16" : "conv_w256_f32", flops, bytes);         // this kernel alone (bench.py's roofline object)
+        ProfScope ps16(c, h ? "conv_gemm_f16" : x3 ? "conv_gemm_x3" : "conv_gemm_f32", flops, bytes);
+        ProfScope psw(c, h ? "conv_w256_f16" : x3 ? "conv_w256_x3" : "conv_w256_f32", flops, bytes);         // this kernel alone (bench.py's roofline object)
         ProfScope pss(c, strcmp(tag, "lstm_ih") == 0 ? "conv_w256_seg" : "conv_w256_ecapa", flops, bytes);   // ... split by caller (PyanNet's K = 256 projections / the ECAPA layers)
-        if (h) hipLaunchKernelGGL(k_conv_gemm_w256<true>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
-        else hipLaunchKernelGGL(k_conv_gemm_w256<false>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
+        if (h) hipLaunchKernelGGL(k_conv_gemm_w256<1>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
+        else if (x3) hipLaunchKernelGGL(k_conv_gemm_w256<3>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
+        else hipLaunchKernelGGL(k_conv_gemm_w256<0>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
     }
     if (hipGetLastError() != hipSuccess) SD_FAIL(c, SD_ERR_HIP, "k_conv_gemm_w256 launch failed (%s)", tag);
     return SD_OK;

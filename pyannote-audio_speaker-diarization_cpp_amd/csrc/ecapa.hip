@@ -165,10 +165,12 @@ static ConvArgs conv_args(const ConvLayer& L, const void* X, int x_ld, void* Y, 
     a.M = (int)M;
     if (per_item) { a.TpIn = a.TpOut = SD_TP; a.Tin = a.T = SD_T; }
     else { a.TpIn = a.TpOut = (int)M; a.Tin = a.T = (int)M; }
-    a.Cin = prec ? L.CinPad16 : L.CinPad; a.cin_real = L.Cin; a.Cout = L.Cout; a.KT = L.KT; a.dil = L.dil;
+    const bool f16 = prec == 1 || prec == 2;
+    a.Cin = f16 ? L.CinPad16 : L.CinPad; a.cin_real = L.Cin; a.Cout = L.Cout; a.KT = L.KT; a.dil = L.dil;
     a.w_ld = a.Cin;
-    a.pad_mode = 0; a.prec = prec ? 1 : 0;
+    a.pad_mode = 0; a.prec = f16 ? 1 : 0;
     if (prec == 2) { a.kt_real = L.KT; a.KT = 2 * L.KT; }       // hi + lo weight planes (weights.cpp)
+    if (prec == 3 && L.W16x) { a.prec = 3; a.W16x = L.W16x; a.acc_scale = L.w16x_inv; }      // f32 tensors, split operands on the fp16 MFMA (wide layers)
     return a;
 }
 
@@ -197,7 +199,8 @@ int ecapa_need_rows(int nvalid, bool skip_dead_rows) { return ec_space_rows(nval
 template <class T>
 static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_all, const EcapaRowPlan& plan, int64_t a0, int64_t a1, float* d_emb_all)
 {
-    const int P = sizeof(T) == 2 ? (c->ecapa_precision == 2 ? 2 : 1) : 0;      // conv_gemm precision of the per-frame layers (2 = fp16 MFMA, hi + lo weight planes)
+    // conv_gemm precision of the per-frame layers: 1 = fp16, 2 = fp16 with hi + lo weight planes, 3 = f32 tensors with split operands on the fp16 MFMA
+    const int P = sizeof(T) == 2 ? (c->ecapa_precision == 2 ? 2 : 1) : (c->ecapa_precision == 3 ? 3 : 0);
     const EcapaWeights& E = c->ew;
     if (!E.loaded) SD_FAIL(c, SD_ERR_MODEL, "embedding model not loaded");
     const int64_t items = a1 - a0;
@@ -252,7 +255,7 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
 
     // blocks[0]: TDNNBlock(80 -> C, k5)
     const void* f_in = d_feats; int f_ld = SD_FEAT_LD;
-    if (P) {
+    if (sizeof(T) == 2) {
         WS(c, _Float16, fh, "ec_feats16", M * 128);
         hipLaunchKernelGGL(k_feats_to_half, GRID1(M * 128), 0, st, d_feats, fh, M);
         KCHECK(c);
@@ -299,7 +302,7 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
     // fp16 mode, option ecapa_f16_hp: bit 0 = the MFA output is stored in f32 (one rounding less in front of the pooling statistics, which
     // are differences of large sums) and rounded once for the attention's fp16 MFMA; bit 1 = the attention branch (asp_tdnn, asp_conv: 4 % of
     // the network's FLOPs, and the exponent of the softmax) on the f32 MFMA
-    const int hp = P ? c->ecapa_f16_hp : 0;
+    const int hp = sizeof(T) == 2 ? c->ecapa_f16_hp : 0;
     float* mfa32 = nullptr;
     if (hp & 1) { WS(c, float, m32, "ec_mfa32", MN * LD3); mfa32 = m32; }
     {
@@ -322,7 +325,7 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
     // attention logits stay f32 in either mode (they feed an exp: fp16's 3 decimal digits at |logit| ~ 30 would be percents of a weight).
     // f32 mode: cat is dead after mfa and large enough; fp16 mode: its own buffer
     float* logits;
-    if (P || c->ecapa_keep_cat) { WS(c, float, lg, "ec_logits", MN * LD3); logits = lg; } else logits = (float*)cat;
+    if (sizeof(T) == 2 || c->ecapa_keep_cat) { WS(c, float, lg, "ec_logits", MN * LD3); logits = lg; } else logits = (float*)cat;
     if (hp & 2) {
         WS(c, float, hid32, "ec_hid32", MN * 128);
         { ConvArgs a = conv_args(E.asp_tdnn_x, mfa32, LD3, hid32, 128, MN, true, 0); a.act1 = 1; a.act2 = 1; a.item_bias = ib; a.ib_ld = 128; a.rowtab = t33; if ((rc = launch_conv_gemm(c, a, "asp_tdnn"))) return rc; }
@@ -344,7 +347,7 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
 
 int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const EcapaRowPlan& plan, int64_t a0, int64_t a1, float* d_emb)
 {
-    if (c->ecapa_precision >= 1) return run_ecapa_t<_Float16>(c, d_feats, d_nvalid, plan, a0, a1, d_emb);
+    if (c->ecapa_precision == 1 || c->ecapa_precision == 2) return run_ecapa_t<_Float16>(c, d_feats, d_nvalid, plan, a0, a1, d_emb);
     return run_ecapa_t<float>(c, d_feats, d_nvalid, plan, a0, a1, d_emb);
 }
 

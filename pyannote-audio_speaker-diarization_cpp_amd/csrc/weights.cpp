@@ -111,6 +111,29 @@ static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const s
                 }
         L.W16 = upload(c, h16);
         if (!L.W16) return SD_ERR_HIP;
+        // ecapa_precision = 3 (conv_gemm_h.hip, P = 3): hi / lo planes of W * 2^e, interleaved per 32-channel chunk the way the kernel stages
+        // them.  2^e puts the layer's largest weight just below 2^14, so that the lo plane of every weight down to 2^-17 of it is a normal
+        // fp16 number (unscaled, the residue of a weight of 0.02 is a subnormal with 7 significant bits); the epilogue multiplies by 2^-e
+        if (Cout % 256 == 0) {
+            float wmax = 0.0f;
+            for (float v : hw) wmax = fmaxf(wmax, fabsf(v));
+            int e = 0;
+            if (wmax > 0.0f && std::isfinite(wmax)) { (void)frexpf(wmax, &e); e = 14 - e; }
+            const float sc = ldexpf(1.0f, e);
+            L.w16x_inv = ldexpf(1.0f, -e);
+            std::vector<_Float16> hx((size_t)2 * K * Cout * CinPad, (_Float16)0.0f);
+            for (int k = 0; k < K; ++k)
+                for (int o = 0; o < Cout; ++o)
+                    for (int i = 0; i < cin; ++i) {
+                        const float v = hw[((size_t)k * Cout + o) * CinPad + i] * sc;
+                        const _Float16 hi = (_Float16)v;
+                        const size_t at = ((size_t)k * Cout + o) * 2 * CinPad + (size_t)(i / 32) * 64 + (i % 32);
+                        hx[at] = hi;
+                        hx[at + 32] = (_Float16)(v - (float)hi);
+                    }
+            L.W16x = upload(c, hx);
+            if (!L.W16x) return SD_ERR_HIP;
+        }
     }
     L.bias = nullptr;
     if (has_bias) { L.bias = upload(c, hb); if (!L.bias) return SD_ERR_HIP; }
