@@ -40,7 +40,7 @@ struct ConvLayer {
     float* shift = nullptr;
     int Cin = 0, CinPad = 0, Cout = 0, KT = 1, dil = 1;
     int CinPad16 = 0;         // row length of W16 (multiple of 64)
-    void* W16x = nullptr;     // option ecapa_precision = 3: [KT][Cout][CinPad / 32][32 hi | 32 lo] fp16 planes of W * w16x_scale (a power of two)
+    void* W16x = nullptr;     // option ecapa_precision = 3: [KT][Cout][CinPad / 8][8 hi | 8 lo] fp16 halves of W * w16x_scale (a power of two)
     float w16x_inv = 1.0f;    // 1 / w16x_scale
 };
 

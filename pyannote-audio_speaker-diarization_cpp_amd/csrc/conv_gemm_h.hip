@@ -78,16 +78,21 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
     const int half = ktr / 2;
     const size_t in_rows = (size_t)(a.in_rows > 0 ? a.in_rows : a.M);
 
-    int rrel[4], tt[4], nd[4];
-    unsigned voA[4], voB[4];
-    int2 pre[4]; int pre_base = 0;
+    // activation loader.  f32 / fp16: 16-byte chunk c4 of rows r0 + 64 p, p < 4.  x3: the 32-byte pair c8 (channels 8 c8 .. + 7) of rows
+    // r8 + 128 p, p < 2 -- eight channels per thread make one 16-byte LDS write of hi halves and one of lo halves
+    constexpr int NPA = X ? 2 : 4;
+    const int c8 = tid & 3, r8 = tid >> 2;
+    auto a_row = [&](int p) { return X ? r8 + 128 * p : r0 + 64 * p; };
+    int rrel[NPA], tt[NPA], nd[NPA];
+    unsigned voA[NPA], voB[4];
+    int2 pre[NPA]; int pre_base = 0;
     auto prefetch_tab = [&](int sb) {
         int j, nt;
         (void)sb_valid(sb, j, nt);
         const int m0 = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * HM);
         pre_base = a.rowtab[m0 < a.M ? m0 : a.M - 1].x;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { int g = m0 + r0 + 64 * p; if (g > a.M - 1) g = a.M - 1; pre[p] = a.rowtab[g]; }
+        for (int p = 0; p < NPA; ++p) { int g = m0 + a_row(p); if (g > a.M - 1) g = a.M - 1; pre[p] = a.rowtab[g]; }
     };
     auto make_rsrc = [&](const void* base, size_t bytes) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
@@ -105,18 +110,18 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
         n0l = __builtin_amdgcn_readfirstlane(nt * HN);
         const int base = __builtin_amdgcn_readfirstlane(pre_base);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { rrel[p] = pre[p].x - base; tt[p] = ROWTAB_T(pre[p].y); nd[p] = ROWTAB_LAST(pre[p].y); }
+        for (int p = 0; p < NPA; ++p) { rrel[p] = pre[p].x - base; tt[p] = ROWTAB_T(pre[p].y); nd[p] = ROWTAB_LAST(pre[p].y); }
         rA = make_rsrc((const char*)a.X + (size_t)base * a.x_ld * ES, (in_rows - base) * a.x_ld * ES);
     };
     auto set_tap = [&](int kk) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NPA; ++p) {
             int qr = tt[p] + ((kk >= ktr ? kk - ktr : kk) - half) * a.dil;
             if (qr < 0) qr = -qr;
             if (qr >= a.Tin) qr = 2 * (a.Tin - 1) - qr;
             if (qr < 0) qr = 0;
             if (qr > nd[p]) qr = nd[p];
-            voA[p] = (unsigned)(rrel[p] + qr) * (unsigned)a.x_ld * ES + c4 * 16;
+            voA[p] = (unsigned)(rrel[p] + qr) * (unsigned)a.x_ld * ES + (X ? c8 * 32 : c4 * 16);
         }
         // weight rows beyond Cout (a 256-wide tile over Cout = 1024 / 3072 never has any) are clamped by the descriptor
         sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * ESB);
@@ -139,21 +144,30 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
     auto gload = [&]() {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p], sK, 0));
+            if constexpr (X) ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p >> 1] + (p & 1) * 16, sK, 0));
+            else ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p], sK, 0));
             rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sB + sK, 0));
         }
+    };
+    auto lstore_part = [&](int buf, int p) {          // x3: row r8 + 128 p of A (the split), rows r0 + 64 (2 p), r0 + 64 (2 p + 1) of W
+        float* A = As0 + buf * HM * HLDP; float* B = Bs0 + buf * HN * HLDP;
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = ra[2 * p + (e >> 2)][e & 3]; hi[e] = (_Float16)f; lo[e] = (_Float16)(f - (float)hi[e]); }
+        // LDS row: [hi 0..7 | lo 0..7 | hi 8..15 | lo 8..15 | hi 16..23 | lo 16..23 | hi 24..31 | lo 24..31]: the 16-byte writes of the
+        // eight lanes of an LDS cycle (two rows 144 bytes apart, four 32-byte pairs each) touch 32 different banks
+        *(half8*)&A[(r8 + 128 * p) * HLDP + c8 * 8] = hi;
+        *(half8*)&A[(r8 + 128 * p) * HLDP + c8 * 8 + 4] = lo;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const int q = 2 * p + h; *(float4*)&B[(r0 + 64 * q) * HLDP + c4 * 4] = make_float4(rb[q][0], rb[q][1], rb[q][2], rb[q][3]); }
     };
     auto lstore = [&](int buf) {
         float* A = As0 + buf * HM * HLDP; float* B = Bs0 + buf * HN * HLDP;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if constexpr (X) {
-                // split the four f32 channels 4 c4 .. + 3: hi halves at byte 8 c4 of the row, lo halves at 64 + 8 c4
-                half4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)ra[p][e]; lo[e] = (_Float16)(ra[p][e] - (float)hi[e]); }
-                *(half4*)&A[(r0 + 64 * p) * HLDP + c4 * 2] = hi;
-                *(half4*)&A[(r0 + 64 * p) * HLDP + 16 + c4 * 2] = lo;
+                if (p < 2) lstore_part(buf, p);
+                continue;
             } else
                 *(float4*)&A[(r0 + 64 * p) * HLDP + c4 * 4] = make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]);
             *(float4*)&B[(r0 + 64 * p) * HLDP + c4 * 4] = make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]);
@@ -170,15 +184,16 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
 
     // one 16-byte fragment per lane, row and K-group kb (4 groups per K-step).  fp16: lane (li, lh) holds k = 16 kb + 8 lh .. +7 of
     // row li (float offset lh * 4 + kb * 8 of the 144-byte row); f32: k = 16 lh + 4 kb .. +3 (float offset lh * 16 + kb * 4)
-    // x3: the four 16-byte groups of a row are hi k 0..15, hi k 16..31, lo k 0..15, lo k 16..31 (the fp16 form's offsets)
     float4 ha[2][2], hb[2][4];
+    // x3 fragment kb: 0 / 1 = hi halves of the step's channels 0..15 / 16..31, 2 / 3 = their lo halves (row layout: lstore_part)
+    auto xoff = [&](int kb) { return ((kb & 1) * 2 + lh) * 8 + (kb >> 1) * 4; };
     auto afrag = [&](int buf, int kb, int fbuf) {
-        const float* Ab = As0 + buf * HM * HLDP + (wr * 64 + li) * HLDP + lh * 4 + kb * 8;
+        const float* Ab = As0 + buf * HM * HLDP + (wr * 64 + li) * HLDP + xoff(kb);
         ha[fbuf][0] = *(const float4*)Ab;
         ha[fbuf][1] = *(const float4*)(Ab + 32 * HLDP);
     };
     auto bfrag = [&](int buf, int kb, int fbuf) {
-        const float* Bb = Bs0 + buf * HN * HLDP + (wc * 128 + li) * HLDP + lh * 4 + kb * 8;
+        const float* Bb = Bs0 + buf * HN * HLDP + (wc * 128 + li) * HLDP + xoff(kb);
 #pragma unroll
         for (int j = 0; j < 4; ++j) hb[fbuf][j] = *(const float4*)(Bb + j * 32 * HLDP);
     };
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
     lstore(0);
     __syncthreads();
     advance();
-    hfrag(0, 0, 0);
+    if constexpr (X) { afrag(0, 0, 0); bfrag(0, 0, 0); } else hfrag(0, 0, 0);
 
     int q = q0, s = 0, buf = 0;
     while (true) {
@@ -262,11 +277,22 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
             __builtin_amdgcn_sched_barrier(0);
             afrag(buf, 3, 0);                      // lo block 1 of A
             xmma(1, 0);                            // hi1 * hi1
-            W_PAIR(0x100, 2); __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            lstore_part(buf ^ 1, 0);
+            // the split of a row's eight channels is ~28 VALU instructions, and there are four LDS writes: left alone they all sit behind the group's last MFMA, in
+            // front of the barrier, in all eight waves at once
+            W_PAIR(0x100, 2);
+#pragma unroll
+            for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
+#pragma unroll
+            for (int i_ = 0; i_ < 2; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 2, 0); }
             __builtin_amdgcn_sched_barrier(0);
             bfrag(buf, 3, 1);                      // lo block 1 of W
             xmma(0, 0);                            // lo1 * hi1
-            lstore(buf ^ 1);
+            lstore_part(buf ^ 1, 1);
+            W_PAIR(0x100, 4);
+#pragma unroll
+            for (int i_ = 0; i_ < 3; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 11, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             afrag(buf ^ 1, 0, 0); bfrag(buf ^ 1, 0, 0);
@@ -416,7 +442,7 @@ int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& in, const char* tag)
         attr_set = true;
     }
     if (a.w_ld <= 0) a.w_ld = a.Cin;
-    if (x3) a.w_ld = 2 * a.Cin;              // halves: every 32-channel chunk of a row is [32 hi | 32 lo]
+    if (x3) a.w_ld = 2 * a.Cin;              // halves: eight hi, eight lo, eight hi, ... (weights.cpp)
     a.m_tiles = (a.M + HM - 1) / HM;
     a.n_tiles = (a.Cout + HN - 1) / HN;
     a.sched = c->conv_pn;

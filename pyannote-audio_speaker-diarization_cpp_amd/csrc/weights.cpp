@@ -111,7 +111,7 @@ static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const s
                 }
         L.W16 = upload(c, h16);
         if (!L.W16) return SD_ERR_HIP;
-        // ecapa_precision = 3 (conv_gemm_h.hip, P = 3): hi / lo planes of W * 2^e, interleaved per 32-channel chunk the way the kernel stages
+        // ecapa_precision = 3 (conv_gemm_h.hip, P = 3): hi / lo halves of W * 2^e, interleaved in groups of eight channels the way the kernel stages
         // them.  2^e puts the layer's largest weight just below 2^14, so that the lo plane of every weight down to 2^-17 of it is a normal
         // fp16 number (unscaled, the residue of a weight of 0.02 is a subnormal with 7 significant bits); the epilogue multiplies by 2^-e
         if (Cout % 256 == 0) {
@@ -127,9 +127,10 @@ static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const s
                     for (int i = 0; i < cin; ++i) {
                         const float v = hw[((size_t)k * Cout + o) * CinPad + i] * sc;
                         const _Float16 hi = (_Float16)v;
-                        const size_t at = ((size_t)k * Cout + o) * 2 * CinPad + (size_t)(i / 32) * 64 + (i % 32);
+                        // per 32-channel chunk: [hi 0..7 | lo 0..7 | hi 8..15 | lo 8..15 | ...], the LDS row of the kernel
+                        const size_t at = ((size_t)k * Cout + o) * 2 * CinPad + (size_t)(i / 32) * 64 + (size_t)((i % 32) / 8) * 16 + (i % 8);
                         hx[at] = hi;
-                        hx[at + 32] = (_Float16)(v - (float)hi);
+                        hx[at + 8] = (_Float16)(v - (float)hi);
                     }
             L.W16x = upload(c, hx);
             if (!L.W16x) return SD_ERR_HIP;
