@@ -47,9 +47,14 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte a
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-template <bool HAS_X2, int DBG, bool F16>
+// PR = 3 ("x3", option ecapa_precision = 3; the layers conv_gemm_h.hip's wide tile does not take: Res2Net, the attention's hidden layer): f32
+// tensors, both operands split into hi + lo fp16 halves -- the activations (X + X2, added in f32) when they are staged, the weights by
+// weights.cpp (W16x) -- and every 16-channel block runs hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16: 24 MFMAs of 32 cycles per wave and
+// 32-channel K-step instead of 64 of 64 cycles.  LDS row and fragment offsets: conv_gemm_h.hip.
+template <bool HAS_X2, int DBG, int PR>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 {
+    constexpr bool F16 = PR == 1, X3 = PR == 3;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDP];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDP];
 
@@ -87,7 +92,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     const int c4 = tid & 7, r0 = tid >> 3;
     const int li = lane & 31, lh = lane >> 5;
 
-    constexpr int ES = F16 ? 2 : 4;     // bytes per element of X / X2 / W / Y
+    constexpr int ES = F16 ? 2 : 4;     // bytes per element of X / X2 / Y (and of W, except x3)
+    constexpr int ESB = (F16 || X3) ? 2 : 4;
+    // activation loader.  f32 / fp16: 16-byte chunk c4 of rows r0 + 32 p, p < 4.  x3: the 32-byte pair c8 of rows r8 + 64 p, p < 2
+    constexpr int NPA = X3 ? 2 : 4;
+    const int c8 = tid & 3, r8 = tid >> 2;
+    auto a_row = [&](int p) { return X3 ? r8 + 64 * p : r0 + 32 * p; };
     constexpr int BKE = 128 / ES;       // elements per K-step: 128 bytes per row either way
     const int kcs = a.Cin / BKE;
     const int S = a.KT * kcs;
@@ -98,27 +108,27 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     // All global reads are buffer loads: a per-tile resource descriptor in SGPRs, a per-lane byte offset that only
     // changes with the tap, and the K position as the instruction's scalar offset -- moving to the next K-step is
     // one scalar add instead of twelve 64-bit vector pointer increments on the MFMA issue path.
-    int rrel[4], tt[4], nd[4];          // per part: item offset (rows) relative to the tile's first item, clamped frame, last stored frame
-    unsigned voA[4], voX[HAS_X2 ? 4 : 1], voB[4];
+    int rrel[NPA], tt[NPA], nd[NPA];    // per part: item offset (rows) relative to the tile's first item, clamped frame, last stored frame
+    unsigned voA[NPA], voX[HAS_X2 ? NPA : 1], voB[4];
     const bool RT = a.rowtab != nullptr;                     // compact row space (see ConvArgs)
     const size_t in_rows = RT ? (size_t)(a.in_rows > 0 ? a.in_rows : a.M) : (size_t)((a.M + a.TpOut - 1) / a.TpOut) * a.TpIn;
     // row-table entries of the tile the load stream visits NEXT: fetched one tile ahead, so a tile switch never waits for them
-    int2 pre[4]; int pre_base = 0;
+    int2 pre[NPA]; int pre_base = 0;
     auto prefetch_tab = [&](int sb) {
         int j, nt;
         (void)sb_valid(sb, j, nt);
         const int m0 = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * BM);
         pre_base = a.rowtab[m0 < a.M ? m0 : a.M - 1].x;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { int g = m0 + r0 + 32 * p; if (g > a.M - 1) g = a.M - 1; pre[p] = a.rowtab[g]; }
+        for (int p = 0; p < NPA; ++p) { int g = m0 + a_row(p); if (g > a.M - 1) g = a.M - 1; pre[p] = a.rowtab[g]; }
     };
     auto make_rsrc = [&](const void* base, size_t bytes) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
     };
     __amdgpu_buffer_rsrc_t rA = make_rsrc(a.X, 0), rX = make_rsrc(a.X, 0);
-    const __amdgpu_buffer_rsrc_t rB = make_rsrc(F16 ? a.W16 : (const void*)a.W, (size_t)a.KT * a.Cout * a.w_ld * ES);
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(X3 ? a.W16x : F16 ? a.W16 : (const void*)a.W, (size_t)a.KT * a.Cout * a.w_ld * ESB);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)((r0 + 32 * p) * a.w_ld * ES + c4 * 16);
+    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)((r0 + 32 * p) * a.w_ld * ESB + c4 * 16);
     int l_q = q0, l_kk = 0, l_kc = 0, m0l = 0, n0l = 0;
     // K always runs 0 .. Cin-1 in the same order for every tile: a row's result does not depend on where its tile sits
     // in the schedule (sharded and unsharded runs, full and dead-row-skipping runs stay bit-identical).  [Tried and
@@ -136,13 +146,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
             const int base = __builtin_amdgcn_readfirstlane(pre_base);
             row0 = (size_t)base;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) { rrel[p] = pre[p].x - base; tt[p] = ROWTAB_T(pre[p].y); nd[p] = ROWTAB_LAST(pre[p].y); }
+            for (int p = 0; p < NPA; ++p) { rrel[p] = pre[p].x - base; tt[p] = ROWTAB_T(pre[p].y); nd[p] = ROWTAB_LAST(pre[p].y); }
         } else {
             const int b0 = m0l / a.TpOut;
             row0 = (size_t)b0 * a.TpIn;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                int g = m0l + r0 + 32 * p;
+            for (int p = 0; p < NPA; ++p) {
+                int g = m0l + a_row(p);
                 if (g > a.M - 1) g = a.M - 1;
                 const int b = g / a.TpOut;
                 int t = g - b * a.TpOut;
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     };
     auto set_tap = [&](int kk) {          // per-lane offsets of tap kk (reflect / valid row map)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NPA; ++p) {
             int qr;
             if (a.pad_mode == 0) {
                 qr = tt[p] + ((kk >= ktr ? kk - ktr : kk) - half) * a.dil;
@@ -169,10 +179,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                 if (qr > a.Tin - 1) qr = a.Tin - 1;
             }
             const unsigned row = (unsigned)(rrel[p] + qr);
-            voA[p] = row * (unsigned)a.x_ld * ES + c4 * 16;
-            if (HAS_X2) voX[p] = row * (unsigned)a.x2_ld * ES + c4 * 16;
+            voA[p] = row * (unsigned)a.x_ld * ES + (X3 ? c8 * 32 : c4 * 16);
+            if (HAS_X2) voX[p] = row * (unsigned)a.x2_ld * ES + (X3 ? c8 * 32 : c4 * 16);
         }
-        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * ES);
+        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * ESB);
     };
     auto advance = [&]() {                // move the load stream to the next K-step
         if (++l_kc < kcs) { sK += 128; return; }
@@ -190,11 +200,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
 
     f4u ra[4], rb[4], rx[HAS_X2 ? 4 : 1];
     auto gload_part = [&](int p) {
-        ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p], sK, 0));
-        if (HAS_X2) rx[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rX, voX[p], sK, 0));
+        if constexpr (X3) {
+            ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p >> 1] + (p & 1) * 16, sK, 0));
+            if (HAS_X2) rx[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rX, voX[p >> 1] + (p & 1) * 16, sK, 0));
+        } else {
+            ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p], sK, 0));
+            if (HAS_X2) rx[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rX, voX[p], sK, 0));
+        }
         rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sB + sK, 0));
     };
+    auto lstore_x3 = [&](int buf, int p) {           // x3: row r8 + 64 p of A (X + X2 in f32, then the split), rows r0 + 32 (2 p), + 32 of W
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = ra[2 * p + (e >> 2)][e & 3];
+            if (HAS_X2) f += rx[HAS_X2 ? 2 * p + (e >> 2) : 0][e & 3];
+            hi[e] = (_Float16)f; lo[e] = (_Float16)(f - (float)hi[e]);
+        }
+        *(half8*)&As[buf][(r8 + 64 * p) * LDP + c8 * 8] = hi;
+        *(half8*)&As[buf][(r8 + 64 * p) * LDP + c8 * 8 + 4] = lo;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const int q = 2 * p + h; *(float4*)&Bs[buf][(r0 + 32 * q) * LDP + c4 * 4] = make_float4(rb[q][0], rb[q][1], rb[q][2], rb[q][3]); }
+    };
     auto lstore = [&](int buf) {
+        if constexpr (X3) { lstore_x3(buf, 0); lstore_x3(buf, 1); return; }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if (HAS_X2) {                            // the add waits for the loads: keep it next to the LDS store
@@ -251,6 +280,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         hb[fbuf][0] = __builtin_bit_cast(half8, *(const float4*)Bb);
         hb[fbuf][1] = __builtin_bit_cast(half8, *(const float4*)(Bb + 32 * LDP));
     };
+    auto xoff = [&](int kb) { return ((kb & 1) * 2 + lh) * 8 + (kb >> 1) * 4; };     // x3 fragments: 0 / 1 = hi halves of channels 0..15 / 16..31, 2 / 3 = lo
+    auto afrag = [&](int buf, int kb, int fbuf) {
+        const float* Ab = &As[buf][(wr * 64 + li) * LDP + xoff(kb)];
+        ha[fbuf][0] = __builtin_bit_cast(half8, *(const float4*)Ab);
+        ha[fbuf][1] = __builtin_bit_cast(half8, *(const float4*)(Ab + 32 * LDP));
+    };
+    auto bfrag = [&](int buf, int kb, int fbuf) {
+        const float* Bb = &Bs[buf][(wc * 64 + li) * LDP + xoff(kb)];
+        hb[fbuf][0] = __builtin_bit_cast(half8, *(const float4*)Bb);
+        hb[fbuf][1] = __builtin_bit_cast(half8, *(const float4*)(Bb + 32 * LDP));
+    };
+    auto xmma = [&](int fa_, int fb_) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fa_][0], hb[fb_][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fa_][0], hb[fb_][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fa_][1], hb[fb_][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fa_][1], hb[fb_][1], acc[1][1], 0, 0, 0);
+    };
     auto hmma = [&](int fbuf) {
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fbuf][0], hb[fbuf][0], acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[fbuf][0], hb[fbuf][1], acc[0][1], 0, 0, 0);
@@ -269,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     lstore(0);
     __syncthreads();
     advance();
-    if constexpr (F16) hfrag(0, 0, 0); else lfrag(0, 0, 0);
+    if constexpr (X3) { afrag(0, 0, 0); bfrag(0, 0, 0); } else if constexpr (F16) hfrag(0, 0, 0); else lfrag(0, 0, 0);
     if constexpr (F16) {
         // the two workgroups of a CU tend to run in lockstep (same tile length): both sit in their VALU-bound epilogues
         // together and both K loops fight for the MFMA pipe together.  Starting every second workgroup of an XCD half a
@@ -280,7 +326,32 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
     int q = q0, s = 0, buf = 0;
     while (true) {
         const int cb = (DBG == 3) ? 0 : buf;
-        if constexpr (F16) {
+        if constexpr (X3) {
+            // six groups of 4 MFMAs per K-step (conv_gemm_h.hip's order: hi0*hi0, lo0*hi0, hi0*lo0, hi1*hi1, lo1*hi1, hi1*lo1); every group's
+            // operands are read one group ahead; loads in group 1, the split and the restaging in groups 4 and 5
+            afrag(buf, 2, 1);
+            gload_part(0); gload_part(1); gload_part(2); gload_part(3);
+            xmma(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bfrag(buf, 2, 1);
+            xmma(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            afrag(buf, 1, 1); bfrag(buf, 1, 0);
+            xmma(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            afrag(buf, 3, 0);
+            xmma(1, 0);
+            lstore_x3(buf ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bfrag(buf, 3, 1);
+            xmma(0, 0);
+            lstore_x3(buf ^ 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            afrag(buf ^ 1, 0, 0); bfrag(buf ^ 1, 0, 0);
+            xmma(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (F16) {
             // same shape as the f32 step: fragments of k-block kb+1 are read while the MFMAs of kb run, the next step's
             // global loads are issued early, restaged to the other LDS buffer during k-block 2, one barrier per step
             hfrag(buf, 1, 1);
@@ -359,6 +430,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                 if (a.scale) { cs_[j] = a.scale[cc]; ch_[j] = a.shift[cc]; }
             }
             const float slope = (a.act1 == 1) ? 0.0f : ((a.act1 == 2) ? 0.01f : 1.0f);
+            const float as = X3 ? a.acc_scale : 1.0f;        // x3: the weights were scaled by a power of two (weights.cpp)
             const int b0 = RT ? 0 : m0c / a.TpOut, t0 = RT ? 0 : m0c - b0 * a.TpOut;      // wave-uniform
             const bool fast_rows = a.TpOut >= BM;
             const bool wide = ((a.Cout | a.y_ld) & 3) == 0 && a.R == nullptr;
@@ -381,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                             const bool live = RT || t < a.T;
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
-                                float v = acc[i][j][4 * gq + e] + cb_[j];
+                                float v = X3 ? acc[i][j][4 * gq + e] * as + cb_[j] : acc[i][j][4 * gq + e] + cb_[j];
                                 acc[i][j][4 * gq + e] = 0.0f;
                                 if (IB) v += a.item_bias[(size_t)b * a.ib_ld + (cco[j] < a.Cout ? cco[j] : a.Cout - 1)];
                                 v = fmaxf(v, v * slope);                  // slope in [0, 1]: relu (0), leaky (0.01), identity (1)
@@ -451,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
                         const unsigned vo = (unsigned)(wr * 64 + i * 32 + 4 * lh) * ybytes + (unsigned)cco[j] * es;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            float v = acc[i][j][r] + cb_[j];
+                            float v = X3 ? acc[i][j][r] * as + cb_[j] : acc[i][j][r] + cb_[j];
                             acc[i][j][r] = 0.0f;
                             v = fmaxf(v, v * slope);
                             v = v * cs_[j] + ch_[j];
@@ -558,7 +630,9 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     if (a.Cin % (f16 ? 64 : BK) != 0) SD_FAIL(c, SD_ERR_ARG, "conv_gemm(%s): Cin=%d not a multiple of %d", tag, a.Cin, f16 ? 64 : BK);
     if (a.M <= 0) return SD_OK;
     if ((f16 && c->conv_h256) || (!f16 && c->conv_w256_f32) || a.prec == 3) { const int r = launch_conv_gemm_h256(c, a, tag); if (r != 1) return r; }
-    if (a.prec == 3) a.prec = 0;              // a layer the wide kernel does not take (X2, per-item bias, Cout not a multiple of 256): the f32 kernels below
+    const bool x3 = a.prec == 3 && a.W16x != nullptr;      // a layer the wide kernel does not take (X2, per-item bias, Cout = 128): the 128 x 128 form of the split
+    if (a.prec == 3 && !x3) a.prec = 0;
+    if (x3) a.w_ld = 2 * a.Cin;
     if (a.prec == 0 && a.KT == 1 && a.M <= 2048 && a.TpIn == a.M && a.TpOut == a.M && a.T == a.M && a.Tin == a.M && !a.X2 && !a.item_bias && !a.R && !a.rowtab &&
         (a.x_ld & 3) == 0 && (a.w_ld & 3) == 0) {
         const int cinr = a.cin_real > 0 ? a.cin_real : a.Cin;
@@ -580,12 +654,15 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     const double flops = 2.0 * rows * a.Cout * cin * kt_alg;
     const double bytes = (f16 ? 2.0 : 4.0) * (rows * cin * (a.X2 ? 2 : 1) + rows * a.Cout + (double)a.Cout * cin * a.KT);
     ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
-    ProfScope ps16(c, f16 ? "conv_gemm_f16" : "conv_gemm_f32", flops, bytes);        // per precision (bench: roofline of the fp16 instantiations alone)
+    ProfScope ps16(c, f16 ? "conv_gemm_f16" : x3 ? "conv_gemm_x3" : "conv_gemm_f32", flops, bytes);        // per precision (bench: roofline of the fp16 instantiations alone)
     if (f16) {
-        if (a.X2) hipLaunchKernelGGL((k_conv_gemm<true, 0, true>), dim3(grid), dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_conv_gemm<false, 0, true>), dim3(grid), dim3(256), 0, c->stream, a);
-    } else if (a.X2) hipLaunchKernelGGL((k_conv_gemm<true, 0, false>), dim3(grid), dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_conv_gemm<false, 0, false>), dim3(grid), dim3(256), 0, c->stream, a);
+        if (a.X2) hipLaunchKernelGGL((k_conv_gemm<true, 0, 1>), dim3(grid), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_conv_gemm<false, 0, 1>), dim3(grid), dim3(256), 0, c->stream, a);
+    } else if (x3) {
+        if (a.X2) hipLaunchKernelGGL((k_conv_gemm<true, 0, 3>), dim3(grid), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_conv_gemm<false, 0, 3>), dim3(grid), dim3(256), 0, c->stream, a);
+    } else if (a.X2) hipLaunchKernelGGL((k_conv_gemm<true, 0, 0>), dim3(grid), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_conv_gemm<false, 0, 0>), dim3(grid), dim3(256), 0, c->stream, a);
     KCHECK(c);
     return SD_OK;
 }
@@ -628,7 +705,7 @@ extern "C" int sd_bench_conv(sd_ctx* c, int64_t items, int Tp, int T, int Cin, i
     const int grid = conv_grid(c, a);
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
-#define LAUNCH_V(X2, D) hipLaunchKernelGGL((k_conv_gemm<X2, D, false>), dim3(grid), dim3(256), 0, c->stream, a)
+#define LAUNCH_V(X2, D) hipLaunchKernelGGL((k_conv_gemm<X2, D, 0>), dim3(grid), dim3(256), 0, c->stream, a)
 #ifdef SD_CONV_ABLATIONS      // make EXTRA=-DSD_CONV_ABLATIONS: 6 more instantiations of the kernel (minutes of compile time), tuning only
 #define LAUNCH_S(X2) do { if (dbg == 0) LAUNCH_V(X2, 0); else if (dbg == 1) LAUNCH_V(X2, 1); else if (dbg == 2) LAUNCH_V(X2, 2); else LAUNCH_V(X2, 3); } while (0)
 #else

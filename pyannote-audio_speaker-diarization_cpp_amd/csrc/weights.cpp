@@ -114,7 +114,7 @@ static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const s
         // ecapa_precision = 3 (conv_gemm_h.hip, P = 3): hi / lo halves of W * 2^e, interleaved in groups of eight channels the way the kernel stages
         // them.  2^e puts the layer's largest weight just below 2^14, so that the lo plane of every weight down to 2^-17 of it is a normal
         // fp16 number (unscaled, the residue of a weight of 0.02 is a subnormal with 7 significant bits); the epilogue multiplies by 2^-e
-        if (Cout % 256 == 0) {
+        {
             float wmax = 0.0f;
             for (float v : hw) wmax = fmaxf(wmax, fabsf(v));
             int e = 0;
