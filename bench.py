@@ -297,6 +297,8 @@ def main():
                     "shares and its stage times give the balance point; 1/N = equal shares, 0 = rank 0 only finalizes")
     ap.add_argument("--fp16-steps", type=int, default=3, help="N = 1, f32 run: also time this many steps in fp16 mode (BASELINE configs[4]) and put them, with the "
                     "cosine distances of the fp16 embeddings to the f32 ones, into the `fp16` object of the result line (0 = skip)")
+    ap.add_argument("--x3-steps", type=int, default=3, help="N = 1, f32 run: also time this many steps with ecapa_precision = 3 (f32 tensors, split fp16 operands on the "
+                    "MFMA) and put them into the `x3` object of the result line (0 = skip)")
     ap.add_argument("--dry-run-control-plane", action="store_true", help="no GPU work: a stand-in for the library (ControlPlaneStandIn) lets the multi-rank control "
                     "flow of this script run on a box without GPUs; the line says dry-run and is not a measurement")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL communicator inside the library, "
@@ -320,7 +322,7 @@ def main():
     gpu_sync = (lambda: None) if dry else torch.cuda.synchronize
     if dry:
         dev = torch.device("cpu")
-        a.cpu_seconds, a.fp16_steps = 0, 0
+        a.cpu_seconds, a.fp16_steps, a.x3_steps = 0, 0, 0
     else:
         ndev = torch.cuda.device_count()                 # (counting devices does not initialise the GPU)
         if ndev <= 0:
@@ -532,43 +534,60 @@ def main():
                                          "what": "sd_diarize: int16 PCM in pageable host memory, the 2 * n byte H2D copy and its buffer inside the timed call"}
         extra_lines["value_cold"] = {"value": round(audio_s / (cold_ms / 1e3), 2), "ms": round(cold_ms, 1),
                                      "what": "what a one-shot user of the CLI sees: sd_create + PCM upload + first job with cold workspaces"}
-        if a.precision == "f32" and a.fp16_steps > 0:
-            d.set_option("ecapa_precision", 1)
+        def secondary_mode(opt, steps, scope_wide, scope_all, kernel, what, mfma_per_flop):
+            """the same job `steps` times with ecapa_precision = opt; its own roofline (the wide kernel of the mode against the fp16 MFMA peak) and the
+            cosine distances of its REAL embeddings to the f32 ones"""
+            d.set_option("ecapa_precision", opt)
             d.set_option("profile", 1)
             step()
             d.reset_stats()
             fence()
             t1 = time.perf_counter()
-            for _ in range(a.fp16_steps):
+            for _ in range(steps):
                 step()
             fence()
-            ms16 = (time.perf_counter() - t1) / a.fp16_steps * 1e3
-            turns16 = turns_box[0]
-            w16, all16 = d.kernel_stats("conv_w256_f16"), d.kernel_stats("conv_gemm_f16")
+            ms_m = (time.perf_counter() - t1) / steps * 1e3
+            turns_m = turns_box[0]
+            wm, allm = d.kernel_stats(scope_wide), d.kernel_stats(scope_all)
+            st_m = d.stage_ms()
             d.set_option("profile", 0)
             cosd = None
             if planted:
                 # accuracy on the REAL embeddings (the planted ones replace them in the timed jobs): scores planted, embeddings kept
                 d.set_planted(d_ps.data_ptr(), 0, lo, hi - lo)
                 step()
-                e16 = d.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192).astype(np.float64)
+                em = d.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192).astype(np.float64)
                 d.set_option("ecapa_precision", 0)
                 step()
                 e32 = d.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192).astype(np.float64)
                 d.set_planted(d_ps.data_ptr(), d_pe.data_ptr(), lo, hi - lo)
                 lv = ~np.isnan(e32[:, 0])
-                same_nan = bool(np.array_equal(np.isnan(e16[:, 0]), ~lv))
-                cd = 1.0 - (e16[lv] * e32[lv]).sum(1) / np.linalg.norm(e16[lv], axis=1) / np.linalg.norm(e32[lv], axis=1)
+                same_nan = bool(np.array_equal(np.isnan(em[:, 0]), ~lv))
+                cd = 1.0 - (em[lv] * e32[lv]).sum(1) / np.linalg.norm(em[lv], axis=1) / np.linalg.norm(e32[lv], axis=1)
                 cosd = {"items": int(lv.sum()), "max": float("%.3g" % cd.max()), "q99": float("%.3g" % np.quantile(cd, 0.99)), "median": float("%.3g" % np.median(cd)),
                         "above_1e-3": int((cd > 1e-3).sum()), "same_nan_rows": same_nan}
             d.set_option("ecapa_precision", 0)
-            extra_lines["fp16"] = {"what": "BASELINE configs[4]: the same job with the per-frame ECAPA layers on the fp16 MFMA (fp16 weights and activations, f32 accumulation); "
-                                           "secondary mode, never the headline value",
-                                   "value": round(audio_s / (ms16 / 1e3), 2), "ms_per_step": round(ms16, 2), "steps": a.fp16_steps, "same_turns_as_f32": turns16 == turns,
-                                   "roofline": {"bound": "mfma", "kernel": "k_conv_gemm_w256<true> (v_mfma_f32_32x32x16_f16)", "achieved": round(w16["flops"] / max(w16["ms"], 1e-9) / 1e9, 1),
-                                                "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(w16["flops"] / max(w16["ms"], 1e-9) / 1e9 / F16_MFMA_PEAK_TFLOPS, 4),
-                                                "all_fp16_conv_launches_TFLOPs": round(all16["flops"] / max(all16["ms"], 1e-9) / 1e9, 1)},
-                                   "cosine_distance_to_f32_embeddings": cosd}
+            tf = wm["flops"] / max(wm["ms"], 1e-9) / 1e9
+            rl = {"bound": "mfma", "kernel": kernel, "achieved": round(tf * mfma_per_flop, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(tf * mfma_per_flop / F16_MFMA_PEAK_TFLOPS, 4), "kernel_ms_per_step": round(wm["ms"] / steps, 2), "launches_per_step": wm["launches"] // steps,
+                  "all_conv_launches_of_the_mode_TFLOPs_algorithmic": round(allm["flops"] / max(allm["ms"], 1e-9) / 1e9, 1)}
+            if mfma_per_flop != 1:
+                rl["achieved_algorithmic"] = round(tf, 1)
+                rl["note"] = ("`achieved` counts the MFMA work the kernel executes: %d fp16 products (hi*hi, lo*hi, hi*lo) per algorithmic multiply-add; "
+                              "`achieved_algorithmic` = the layer's 2 M N K over the same time, comparable with the f32 line's `roofline.achieved`" % mfma_per_flop)
+            return {"what": what, "value": round(audio_s / (ms_m / 1e3), 2), "ms_per_step": round(ms_m, 2), "steps": steps, "same_turns_as_f32": turns_m == turns,
+                    "stage_ms_last_step": {"segmentation": round(st_m[0], 1), "embedding": round(st_m[1], 1), "finalize": round(st_m[2], 1)},
+                    "roofline": rl, "cosine_distance_to_f32_embeddings": cosd}
+
+        if a.precision == "f32" and a.fp16_steps > 0:
+            extra_lines["fp16"] = secondary_mode(1, a.fp16_steps, "conv_w256_f16", "conv_gemm_f16", "k_conv_gemm_w256<1> (v_mfma_f32_32x32x16_f16)",
+                                                 "BASELINE configs[4]: the same job with the per-frame ECAPA layers on the fp16 MFMA (fp16 weights and activations, f32 accumulation); "
+                                                 "secondary mode, never the headline value", 1)
+        if a.precision == "f32" and a.x3_steps > 0:
+            extra_lines["x3"] = secondary_mode(3, a.x3_steps, "conv_w256_x3", "conv_gemm_x3", "k_conv_gemm_w256<3> (v_mfma_f32_32x32x16_f16 on split operands)",
+                                               "option ecapa_precision = 3: f32 tensors in HBM as in the headline run; every ECAPA conv layer splits both operands into hi + lo fp16 "
+                                               "halves (22 bits) and runs hi*hi + lo*hi + hi*lo on the fp16 MFMA with f32 accumulation -- f32-grade embeddings (see the cosine "
+                                               "distances) from the fp16 matrix pipe; opt-in, not the headline value", 3)
 
     if rank == 0:
         ach = cg["flops"] / max(cg["ms"], 1e-9) / 1e9      # TFLOP/s
@@ -582,9 +601,9 @@ def main():
                 pj = json.load(open(pmc_path))
                 cur = "+".join(git_blob_sha1(os.path.join(PKG, "csrc", f)) for f in ("conv_gemm.hip", "conv_gemm_h.hip", "conv_narrow.hip"))
                 if pj.get("conv_gemm_blob") == cur and pj.get("workload", "raw") == a.workload and float(pj.get("hours_per_gpu", 1.0)) == float(a.hours_per_gpu):
-                    pk = pj["per_kernel"]["k_conv_gemm_w256<false>"]
-                    traffic, traffic_src = pk["fetch_x2_bytes_per_launch"] + pk["write_bytes_per_launch"], pj["source"] + " -- this field: the k_conv_gemm_w256<false> launches alone"
-                    mfma_util = {"k_conv_gemm_w256<false>": pj.get("mfma", {}).get("k_conv_gemm_w256<false>"), "all_kernels": pj.get("mfma"),
+                    pk = pj["per_kernel"]["k_conv_gemm_w256<0>"]
+                    traffic, traffic_src = pk["fetch_x2_bytes_per_launch"] + pk["write_bytes_per_launch"], pj["source"] + " -- this field: the k_conv_gemm_w256<0> launches alone"
+                    mfma_util = {"k_conv_gemm_w256<0>": pj.get("mfma", {}).get("k_conv_gemm_w256<0>"), "all_kernels": pj.get("mfma"),
                                  "traffic_all_mfma_conv_launches_bytes_per_launch": pj["bytes_per_launch"]}
                 else:
                     recorded = {"note": "PMC recording is of another kernel source, workload or size: not quoted", "recorded_blob": pj.get("conv_gemm_blob"),
@@ -620,8 +639,8 @@ def main():
                                           "pipelined rate of back-to-back jobs (rank 0 finalizes job k while the others infer job k+1)"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_conv_gemm_w256<false> (v_mfma_f32_32x32x2_f32, 256 x 256 tile): every ECAPA layer with Cout >= 256 + PyanNet's LSTM input projections" if a.precision == "f32" else
-                                   "k_conv_gemm_w256<true> (v_mfma_f32_32x32x16_f16, fp16 activations): the wide ECAPA layers",
+                         "kernel": "k_conv_gemm_w256<0> (v_mfma_f32_32x32x2_f32, 256 x 256 tile): every ECAPA layer with Cout >= 256 + PyanNet's LSTM input projections" if a.precision == "f32" else
+                                   "k_conv_gemm_w256<1> (v_mfma_f32_32x32x16_f16, fp16 activations): the wide ECAPA layers",
                          "all_mfma_conv_launches": {"what": "k_conv_gemm_w256 + k_conv_gemm (128 x 128 tile: Res2Net, ASP tdnn%s) %s" %
                                                             ((", PyanNet) + k_conv_narrow (SincNet", "of the step") if a.precision == "f32" else ("", "in fp16")),
                                                     "achieved": round(cg_all["flops"] / max(cg_all["ms"], 1e-9) / 1e9, 2),

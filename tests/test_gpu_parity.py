@@ -204,6 +204,42 @@ def test_ecapa_fp16_mfma_within_reference_tolerance(diarizer, weights):
     assert np.array_equal(diarizer.ecapa(feats, lens), e32)                 # and the f32 path is back, bit for bit
 
 
+def test_ecapa_x3_split_operands_on_the_fp16_mfma_hold_the_f32_bars(diarizer, weights):
+    """option ecapa_precision = 3: f32 tensors, every ECAPA conv layer with both operands split into hi + lo fp16 halves on
+    v_mfma_f32_32x32x16_f16 (conv_gemm_h.hip P = 3, conv_gemm.hip PR = 3).  22-bit operands, f32 accumulation: the mode has to pass the bars
+    of the F32 path -- element-wise RTOL / ATOL against the torch oracle and a cosine distance three orders below the north-star 1e-3 --
+    on full and partial lengths, through the wide tile (block0, TDNN, MFA, attention logits) and the 128 x 128 tile (Res2Net with its
+    second input, the attention's hidden layer with per-item bias and tanh); the result does not depend on the batch it is computed in
+    (the wide tile takes every batch size in this mode), and leaving the mode restores the f32 bits."""
+    rng = np.random.default_rng(31)
+    lens = np.array([1.0, 0.5, 0.25, 0.9, 0.7, 0.33, 1.0, 0.6, 0.8, 0.45, 0.05, 1.0], np.float32)
+    feats = (3.0 * rng.standard_normal((len(lens), 501, 80))).astype(np.float32)
+    feats[3] *= 30.0                                       # loud item: activations of a few thousand stay far inside fp16's range
+    feats[5] *= 1e-3                                       # quiet item: the lo halves of small activations are fp16 subnormals
+    e32 = diarizer.ecapa(feats, lens)
+    diarizer.set_option("ecapa_precision", 3)
+    try:
+        ex = diarizer.ecapa(feats, lens)
+        ex_one = np.concatenate([diarizer.ecapa(feats[i:i + 1], lens[i:i + 1]) for i in (0, 2, 10)])
+        ex_pair = diarizer.ecapa(feats[4:9], lens[4:9])
+    finally:
+        diarizer.set_option("ecapa_precision", 0)
+    assert np.isfinite(ex).all() and not np.array_equal(ex, e32)                  # the split kernels really ran
+    assert np.array_equal(ex_one, ex[[0, 2, 10]]) and np.array_equal(ex_pair, ex[4:9])
+    e_ref = nn.EcapaOracle(weights[3])(feats, lens).numpy()
+    np.testing.assert_allclose(ex, e_ref, rtol=RTOL, atol=ATOL * np.abs(e_ref).max())
+    g, r = ex.astype(np.float64), e_ref.astype(np.float64)
+    cd = 1 - (g * r).sum(1) / np.linalg.norm(g, axis=1) / np.linalg.norm(r, axis=1)
+    g32 = e32.astype(np.float64)
+    cd32 = 1 - (g32 * r).sum(1) / np.linalg.norm(g32, axis=1) / np.linalg.norm(r, axis=1)
+    assert cd.max() < 1e-6 and cd32.max() < 1e-6, (cd.max(), cd32.max())
+    # as close to the oracle as the f32 MFMA path is (both differ from it by summation order; the split adds 2^-22 per product)
+    rel = np.linalg.norm(g - r, axis=1) / np.linalg.norm(r, axis=1)
+    rel32 = np.linalg.norm(g32 - r, axis=1) / np.linalg.norm(r, axis=1)
+    assert rel.max() < 3 * max(rel32.max(), 1e-5), (rel.max(), rel32.max())
+    assert np.array_equal(diarizer.ecapa(feats, lens), e32)
+
+
 def test_ecapa_fp16_wide_tile_kernel_gives_the_same_bits(diarizer):
     """fp16 mode: the 256 x 256 kernel of the wide layers (conv_gemm_h.hip) and the 128 x 128 kernel feed the same k-blocks to the
     same MFMA in the same order: embeddings must be bit-identical, whichever kernel a batch size selects"""

@@ -472,7 +472,7 @@ def test_bench_line_contract_on_a_short_job():
     higher_is_better / scaling / vs_baseline / dtype / data / config.workload, a `roofline` object for the dominant kernel measured with HIP
     events on the library's stream and a `cpu_baseline` object timed on this box's host cores; plus this round's additions"""
     import json
-    out, _ = _run_bench(["--steps", "2", "--warmup", "1", "--hours-per-gpu", "0.05", "--cpu-seconds", "10", "--fp16-steps", "1"], 600)
+    out, _ = _run_bench(["--steps", "2", "--warmup", "1", "--hours-per-gpu", "0.05", "--cpu-seconds", "10", "--fp16-steps", "1", "--x3-steps", "1"], 600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and out.stdout.strip().endswith(lines[0])
@@ -492,3 +492,7 @@ def test_bench_line_contract_on_a_short_job():
     f = j["fp16"]
     assert f["same_turns_as_f32"] is True and f["roofline"]["peak"] == 2500.0 and f["cosine_distance_to_f32_embeddings"]["same_nan_rows"] is True
     assert f["cosine_distance_to_f32_embeddings"]["q99"] < 2e-3
+    x = j["x3"]
+    assert x["same_turns_as_f32"] is True and x["roofline"]["peak"] == 2500.0 and x["cosine_distance_to_f32_embeddings"]["same_nan_rows"] is True
+    assert x["cosine_distance_to_f32_embeddings"]["max"] < 1e-6 and x["cosine_distance_to_f32_embeddings"]["above_1e-3"] == 0
+    assert abs(x["roofline"]["achieved"] - 3 * x["roofline"]["achieved_algorithmic"]) < 0.5 and x["value"] > j["value"]
