@@ -186,7 +186,9 @@ int sd_stage_ms(const sd_ctx*, double* ms4);
 /* ---- options.  Product keys (the knobs clustering/Clustering.py and the multi-GPU path expose; the reference hard-codes them):
  * "num_clusters", "min_clusters", "max_clusters" (-1 = unset; Clustering.py:21-43), "constrained_assignment" (1 = constrained_argmax of
  * Clustering.py:81-94: the local speakers of a chunk go to different clusters; applies to sd_clustering* and the whole path),
- * "ecapa_precision" (0 = f32 MFMA = the reference's ORT precision, 1 = fp16 MFMA with f32 accumulation),
+ * "ecapa_precision" (0 = f32 MFMA = the reference's ORT precision (default); 1 = fp16 weights and activations on the fp16 MFMA with f32
+ *   accumulation; 2 = the same with hi + lo fp16 weight planes; 3 = f32 tensors, both MFMA operands split into hi + lo fp16 halves, three
+ *   products per multiply-add: f32-grade embeddings (<= 1e-7 cosine distance to mode 0) at about half of mode 0's time),
  * "rank0_permille" (sd_diarize_sharded: share of the chunks rank 0 infers itself, -1 = equal),
  * "comm_timeout_ms" (deadline of the exchange step of a sharded job, default 600 000).
  * Test and tuning keys are listed in sdhip_test.h.  An unknown key returns SD_ERR_ARG. */
