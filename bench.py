@@ -289,8 +289,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=int, default=60, help="audio seconds for the cpu_baseline sample (0 = skip)")
     ap.add_argument("--workload", default="planted", choices=["planted", "raw"], help="planted = SURVEY 8d (network outputs replaced by the "
                     "schedule-derived scores / talker embeddings after the networks ran); raw = whatever the random-weight networks say (K = 1)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="f32 = the measured configuration (f32 MFMA); f16 = "
-                    "BASELINE configs[4]: ECAPA conv layers on the fp16 MFMA with f32 accumulation (secondary, tolerance-checked mode)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "x3"], help="f32 = the measured configuration (f32 MFMA); f16 = "
+                    "BASELINE configs[4]: ECAPA conv layers on the fp16 MFMA with f32 accumulation (secondary, tolerance-checked mode); x3 = f32 tensors, "
+                    "both operands of the ECAPA conv layers split into hi + lo fp16 halves on the fp16 MFMA (opt-in mode; the default run reports it in its `x3` object)")
     ap.add_argument("--rank0-share", type=float, default=-1.0, help="fraction of the chunks rank 0 infers itself (it also finalizes: count / "
                     "clustering / reconstruction).  The other ranks return from the sharded call once the exchange is done, so rank 0's "
                     "finalize(k) overlaps their inference(k+1); a smaller rank-0 share balances the two. -1 = measured: the warm-up job runs with equal "
@@ -395,8 +396,8 @@ def main():
     t_cold = time.perf_counter()
     d = (ControlPlaneStandIn(rank, world, dist, sdhip.shard_plan, sdhip.num_chunks) if dry else
          sdhip.Diarizer(os.path.join(tmp, "segment.sdw"), os.path.join(tmp, "embedding.sdw"), local))
-    if a.precision == "f16":
-        d.set_option("ecapa_precision", 1)
+    if a.precision != "f32":
+        d.set_option("ecapa_precision", 1 if a.precision == "f16" else 3)
     for kv in a.opt:
         k, v = kv.split("=")
         d.set_option(k, int(v))
@@ -478,8 +479,10 @@ def main():
     live_local = stats_live["flops"] / max(stats_live["launches"], 1)
     # dominant kernel: k_conv_gemm.  f32 mode: every launch is the f32-MFMA instantiation.  fp16 mode: the roofline is that of the fp16
     # instantiations (ECAPA per-frame layers: k_conv_gemm_h256 + k_conv_gemm<F16>); the f32 launches left (PyanNet) are listed beside it
-    cg_all = d.kernel_stats("conv_gemm_f16" if a.precision == "f16" else "conv_gemm")      # every MFMA convolution launch of the precision
-    cg = d.kernel_stats("conv_w256_f16" if a.precision == "f16" else "conv_w256_f32")       # the dominant kernel alone: k_conv_gemm_w256
+    cg_all = d.kernel_stats({"f16": "conv_gemm_f16", "x3": "conv_gemm_x3"}.get(a.precision, "conv_gemm"))      # every MFMA convolution launch of the precision
+    cg = d.kernel_stats({"f16": "conv_w256_f16", "x3": "conv_w256_x3"}.get(a.precision, "conv_w256_f32"))       # the dominant kernel alone: k_conv_gemm_w256
+    if a.precision == "x3":          # executed MFMA work: three fp16 products per algorithmic multiply-add
+        cg, cg_all = dict(cg, flops=3.0 * cg["flops"]), dict(cg_all, flops=3.0 * cg_all["flops"])
     cg_f32 = d.kernel_stats("conv_gemm_f32")
     cg_e, cg_s = d.kernel_stats("conv_w256_ecapa"), d.kernel_stats("conv_w256_seg")
     stages = d.stage_ms()
@@ -617,7 +620,7 @@ def main():
             "n_gpus": world, "rccl_ranks": d.comm_info()[1], "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.precision, "data": "dry-run (stand-in for the library, no GPU work)" if dry else "synthetic",
+            "dtype": "f32 tensors; MFMA operands split into hi + lo fp16 halves (x3)" if a.precision == "x3" else a.precision, "data": "dry-run (stand-in for the library, no GPU work)" if dry else "synthetic",
             "config": {"workload": "%g h synthetic 16 kHz mono per GPU (%g h total), full pipeline: PyanNet segmentation + post-seg + STFT/fbank + "
                                    "ECAPA-TDNN + centroid AHC + reconstruction; %s" % (a.hours_per_gpu, audio_s / HOUR,
                                    "planted multi-speaker workload (SURVEY 8d): both networks run at full cost, then their outputs are replaced by the scores / "
@@ -640,6 +643,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_conv_gemm_w256<0> (v_mfma_f32_32x32x2_f32, 256 x 256 tile): every ECAPA layer with Cout >= 256 + PyanNet's LSTM input projections" if a.precision == "f32" else
+                                   "k_conv_gemm_w256<3> (v_mfma_f32_32x32x16_f16 on split operands; `achieved` = executed MFMA work = 3 x the algorithmic FLOPs): the wide ECAPA layers" if a.precision == "x3" else
                                    "k_conv_gemm_w256<1> (v_mfma_f32_32x32x16_f16, fp16 activations): the wide ECAPA layers",
                          "all_mfma_conv_launches": {"what": "k_conv_gemm_w256 + k_conv_gemm (128 x 128 tile: Res2Net, ASP tdnn%s) %s" %
                                                             ((", PyanNet) + k_conv_narrow (SincNet", "of the step") if a.precision == "f32" else ("", "in fp16")),
@@ -647,7 +651,7 @@ def main():
                                                     "frac": round(cg_all["flops"] / max(cg_all["ms"], 1e-9) / 1e9 / peak, 4),
                                                     "launches_per_step": cg_all["launches"] // max(a.steps, 1),
                                                     "kernel_ms_per_step": round(cg_all["ms"] / max(a.steps, 1), 2),
-                                                    "algorithmic_gflop_per_step": round(cg_all["flops"] / max(a.steps, 1) / 1e9, 1)},
+                                                    "algorithmic_gflop_per_step": round(cg_all["flops"] / (3.0 if a.precision == "x3" else 1.0) / max(a.steps, 1) / 1e9, 1)},
                          "f32_launches_beside": None if a.precision == "f32" else {"what": "PyanNet layers, f32 MFMA", "kernel_ms_per_step": round(cg_f32["ms"] / max(a.steps, 1), 2),
                                                                                    "TFLOPs": round(cg_f32["flops"] / max(cg_f32["ms"], 1e-9) / 1e9, 1)},
                          "by_caller": None if a.precision != "f32" else {
@@ -660,7 +664,7 @@ def main():
                          "launches_per_step": cg["launches"] // max(a.steps, 1),
                          "avg_launch_ms": round(cg["ms"] / max(cg["launches"], 1), 4),
                          "kernel_ms_per_step": round(cg["ms"] / max(a.steps, 1), 2),
-                         "algorithmic_gflop_per_step": round(cg["flops"] / max(a.steps, 1) / 1e9, 1),
+                         "algorithmic_gflop_per_step": round(cg["flops"] / (3.0 if a.precision == "x3" else 1.0) / max(a.steps, 1) / 1e9, 1),
                          "algorithmic_bytes_per_launch": round(cg["bytes"] / max(cg["launches"], 1)),
                          "mfma_utilisation_pmc": mfma_util, "recorded_pmc": recorded},
             "other_kernels": extra,
