@@ -29,6 +29,10 @@ void sd_reset_stats(sd_ctx*);
 /* copy `bytes` of the library's named device workspace (from byte `offset`) to the host: intermediate activations for the precision
  * diagnostics under tools/ ("ec_x0", "ec_cat", "ec_mfa", "ec_pooled", ...) */
 int sd_debug_read_ws(sd_ctx*, const char* name, int64_t offset, void* h_out, int64_t bytes);
+/* host only: the split-weight packing of option ecapa_precision = 3 (weights.cpp) on host buffers.  w = [K][Cout][CinPad] floats (CinPad a
+ * multiple of 32, channels >= cin ignored), out_halves = 2 * K * Cout * CinPad fp16 bit patterns: per 32-channel chunk of a row
+ * [hi 0..7 | lo 0..7 | hi 8..15 | ...] of w * 2^e; *inv_scale = 2^-e */
+int sd_test_pack_split_weights(const float* w, int K, int Cout, int CinPad, int cin, uint16_t* out_halves, float* inv_scale);
 /* test / tuning keys of sd_set_option (defaults are the measured optimum; results do not depend on the tuning keys):
  * "profile", "emb_batch_items", "seg_batch_chunks", "linkage_wgs" (-1 auto, 0 one workgroup), "linkage_threads", "linkage_one_xcd",
  * "skip_dead_rows", "virtual_world" (test mode: a communicator of ONE rank plays all W ranks of the plan in turn, slot by slot, so plan +

@@ -57,6 +57,39 @@ template <class T> static T* upload(sd_ctx* c, const std::vector<T>& h)
     return d;
 }
 
+// ecapa_precision = 3 (conv_gemm_h.hip P = 3, conv_gemm.hip PR = 3): hi / lo fp16 halves of W * 2^e, interleaved in groups of eight channels the
+// way the kernels stage them -- per 32-channel chunk of a row [hi 0..7 | lo 0..7 | hi 8..15 | lo 8..15 | hi 16..23 | lo 16..23 | hi 24..31 | lo 24..31].
+// 2^e puts the layer's largest weight into [2^13, 2^14), so that the lo half of every weight down to 2^-17 of it is a normal fp16 number
+// (unscaled, the residue of a weight of 0.02 is a subnormal with 7 significant bits); the epilogue multiplies the accumulator by 2^-e.
+static void pack_split_weights(const float* hw, int K, int Cout, int CinPad, int cin, _Float16* out, float* inv_scale)
+{
+    float wmax = 0.0f;
+    for (size_t r = 0; r < (size_t)K * Cout; ++r)
+        for (int i = 0; i < cin; ++i) { const float v = hw[r * CinPad + i]; if (std::isfinite(v)) wmax = fmaxf(wmax, fabsf(v)); }
+    int e = 0;
+    if (wmax > 0.0f) { (void)frexpf(wmax, &e); e = 14 - e; }
+    const float sc = ldexpf(1.0f, e);
+    *inv_scale = ldexpf(1.0f, -e);
+    for (size_t q = 0; q < (size_t)2 * K * Cout * CinPad; ++q) out[q] = (_Float16)0.0f;
+    for (int k = 0; k < K; ++k)
+        for (int o = 0; o < Cout; ++o)
+            for (int i = 0; i < cin; ++i) {
+                const float v = hw[((size_t)k * Cout + o) * CinPad + i] * sc;
+                const _Float16 hi = (_Float16)v;
+                const size_t at = ((size_t)k * Cout + o) * 2 * CinPad + (size_t)(i / 32) * 64 + (size_t)((i % 32) / 8) * 16 + (i % 8);
+                out[at] = hi;
+                out[at + 8] = (_Float16)(v - (float)hi);
+            }
+}
+
+// test hook (sdhip_test.h): the packing above on host buffers, no GPU
+extern "C" int sd_test_pack_split_weights(const float* w, int K, int Cout, int CinPad, int cin, uint16_t* out_halves, float* inv_scale)
+{
+    if (!w || !out_halves || !inv_scale || K <= 0 || Cout <= 0 || CinPad <= 0 || CinPad % 32 || cin <= 0 || cin > CinPad) return SD_ERR_ARG;
+    pack_split_weights(w, K, Cout, CinPad, cin, (_Float16*)out_halves, inv_scale);
+    return SD_OK;
+}
+
 // PyTorch conv weight [Cout][Cin][K] (or linear [Cout][Cin]) -> [K][Cout][CinPad]
 // optional input-channel slice [ci0, ci0+cin) of the source tensor
 static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const std::string& bname,
@@ -111,27 +144,10 @@ static int make_conv(sd_ctx* c, const Pack& p, const std::string& wname, const s
                 }
         L.W16 = upload(c, h16);
         if (!L.W16) return SD_ERR_HIP;
-        // ecapa_precision = 3 (conv_gemm_h.hip, P = 3): hi / lo halves of W * 2^e, interleaved in groups of eight channels the way the kernel stages
-        // them.  2^e puts the layer's largest weight just below 2^14, so that the lo plane of every weight down to 2^-17 of it is a normal
-        // fp16 number (unscaled, the residue of a weight of 0.02 is a subnormal with 7 significant bits); the epilogue multiplies by 2^-e
+        // ecapa_precision = 3: split weights in the kernel's staging layout (pack_split_weights below)
         {
-            float wmax = 0.0f;
-            for (float v : hw) wmax = fmaxf(wmax, fabsf(v));
-            int e = 0;
-            if (wmax > 0.0f && std::isfinite(wmax)) { (void)frexpf(wmax, &e); e = 14 - e; }
-            const float sc = ldexpf(1.0f, e);
-            L.w16x_inv = ldexpf(1.0f, -e);
-            std::vector<_Float16> hx((size_t)2 * K * Cout * CinPad, (_Float16)0.0f);
-            for (int k = 0; k < K; ++k)
-                for (int o = 0; o < Cout; ++o)
-                    for (int i = 0; i < cin; ++i) {
-                        const float v = hw[((size_t)k * Cout + o) * CinPad + i] * sc;
-                        const _Float16 hi = (_Float16)v;
-                        // per 32-channel chunk: [hi 0..7 | lo 0..7 | hi 8..15 | lo 8..15 | ...], the LDS row of the kernel
-                        const size_t at = ((size_t)k * Cout + o) * 2 * CinPad + (size_t)(i / 32) * 64 + (size_t)((i % 32) / 8) * 16 + (i % 8);
-                        hx[at] = hi;
-                        hx[at + 8] = (_Float16)(v - (float)hi);
-                    }
+            std::vector<_Float16> hx((size_t)2 * K * Cout * CinPad);
+            pack_split_weights(hw.data(), K, Cout, CinPad, cin, hx.data(), &L.w16x_inv);
             L.W16x = upload(c, hx);
             if (!L.W16x) return SD_ERR_HIP;
         }

@@ -37,7 +37,7 @@ EXPORTS = [
     "sd_reset_stats", "sd_set_option", "sd_bench_conv", "sd_bench_barrier", "sd_convert_onnx", "sd_convert_error", "sd_read_wav_f32", "sd_free_wav", "sd_diarize_f32",
     "sd_write_rttm", "sd_set_planted", "sd_comm_unique_id", "sd_comm_init", "sd_comm_destroy", "sd_comm_info", "sd_shard_plan",
     "sd_diarize_sharded", "sd_diarize_sharded_dev", "sd_write_rttm_ex", "sd_relabel_turns", "sd_relabel_turns_ex", "sd_last_confidence",
-    "sd_debug_read_ws",
+    "sd_debug_read_ws", "sd_test_pack_split_weights",
 ]
 COMM_ID_BYTES = 128
 
@@ -104,6 +104,7 @@ def lib():
     L.sd_convert_onnx.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
     L.sd_convert_error.restype = C.c_char_p
     L.sd_debug_read_ws.argtypes = [vp, C.c_char_p, i64, vp, i64]
+    L.sd_test_pack_split_weights.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.sd_bench_barrier.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(dbl)]
     L.sd_bench_conv.argtypes = [vp, i64] + [C.c_int] * 9 + [C.POINTER(dbl)]
     _lib = L

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     # the drop-in header holds reference-cited entries only: the test / bench / tuning hooks live in sdhip_test.h
-    assert decl["sdhip_test.h"] == {"sd_set_planted", "sd_kernel_stats", "sd_reset_stats", "sd_bench_barrier", "sd_bench_conv", "sd_debug_read_ws"}
+    assert decl["sdhip_test.h"] == {"sd_set_planted", "sd_kernel_stats", "sd_reset_stats", "sd_bench_barrier", "sd_bench_conv", "sd_debug_read_ws", "sd_test_pack_split_weights"}
 
 
 def test_create_fails_loudly_without_gpu_or_model(tmp_path):
@@ -122,3 +122,39 @@ def test_reference_side_binding_of_seam4_compiles_against_the_reference_header(t
         pytest.skip("reference tree absent (GPU box)")
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-include", "vector", "-include", "algorithm", "-include", "cstdint", "-I", ref,
                            "-I", os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "oracle", "ref_build", "seam4_binding.cpp"), "-o", str(tmp_path / "seam4.o")])
+
+
+def test_split_weight_packing_of_the_x3_mode_on_the_host():
+    """option ecapa_precision = 3 feeds the fp16 MFMA with hi + lo halves of both operands; the weight side is packed once on the host
+    (weights.cpp pack_split_weights, exposed as sd_test_pack_split_weights): per layer a power-of-two scale that puts the largest weight
+    into [2^13, 2^14), per 32-channel chunk the kernel's LDS row [hi 0..7 | lo 0..7 | hi 8..15 | ...], padding channels zero.
+    hi + lo must give the weight back to 2^-21 relative for every weight down to 2^-17 of the largest (their lo halves are normal fp16
+    numbers), with an ABSOLUTE error of at most 2^-25 of the scaled range below that -- for small, for huge and for mixed magnitudes."""
+    import ctypes as C
+    L = sdhip.lib()
+    rng = np.random.default_rng(5)
+    K, Cout, CinPad, cin = 3, 8, 96, 80
+    for mag in (1.0, 0.02, 3e-7, 4e5):
+        w = np.zeros((K, Cout, CinPad), np.float32)
+        w[:, :, :cin] = (mag * rng.standard_normal((K, Cout, cin)) * np.exp(4.0 * rng.standard_normal((K, Cout, cin)))).astype(np.float32)
+        w[0, 0, 0] = 0.0
+        w[:, :, cin:] = 7.0                                               # channels beyond cin are ignored, whatever they hold
+        out = np.zeros(2 * K * Cout * CinPad, np.uint16)
+        inv = C.c_float(0.0)
+        assert L.sd_test_pack_split_weights(w.ctypes.data_as(C.c_void_p), K, Cout, CinPad, cin, out.ctypes.data_as(C.c_void_p), C.byref(inv)) == 0
+        wmax = np.abs(w[:, :, :cin]).max()
+        scale = 1.0 / inv.value
+        assert np.log2(scale) == np.round(np.log2(scale)) and 2.0 ** 13 <= wmax * scale < 2.0 ** 14
+        h = out.view(np.float16).astype(np.float64).reshape(K, Cout, CinPad // 32, 4, 2, 8)      # [chunk][group of 8][hi | lo][channel]
+        hi = h[..., 0, :].reshape(K, Cout, CinPad)
+        lo = h[..., 1, :].reshape(K, Cout, CinPad)
+        assert (hi[:, :, cin:] == 0).all() and (lo[:, :, cin:] == 0).all()
+        assert np.array_equal(hi[:, :, :cin], (w[:, :, :cin].astype(np.float64) * scale).astype(np.float16).astype(np.float64))   # hi = fp16(w 2^e), nearest-even
+        back = (hi + lo) * inv.value
+        ref = w.astype(np.float64)
+        err = np.abs(back - ref)[:, :, :cin]
+        big = np.abs(ref[:, :, :cin]) >= wmax * 2.0 ** -17
+        assert big.sum() > 100 and (~big).sum() > 5
+        assert (err[big] <= 2.0 ** -21 * np.abs(ref[:, :, :cin][big])).all()
+        assert (err[~big] <= 2.0 ** -25 * inv.value).all()                # subnormal lo halves: absolute error of half a subnormal step
+    assert L.sd_test_pack_split_weights(w.ctypes.data_as(C.c_void_p), K, Cout, 80, 80, out.ctypes.data_as(C.c_void_p), C.byref(inv)) != 0      # CinPad % 32

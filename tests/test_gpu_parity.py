@@ -579,6 +579,14 @@ def test_cli_matches_api(diarizer, weights, golden_dir):
     assert lines[i0 + 1:i1] == [sdhip.format_turn(t) for t in turns]
     for lab in ("Segmenations time", "Embedding time", "Clustering time", "Time cost"):
         assert any(l.startswith(lab) for l in lines)
+    # --precision x3 (f32 tensors, split fp16 MFMA operands): the same turns from the command line; an unknown precision is refused
+    outx = subprocess.run([exe, weights[0], weights[1], wav, "--precision", "x3"], capture_output=True, text=True, timeout=600)
+    assert outx.returncode == 0, outx.stderr
+    lx = outx.stdout.splitlines()
+    j0 = lx.index(rule)
+    assert lx[j0 + 1:lx.index(rule, j0 + 1)] == lines[i0 + 1:i1]
+    bad = subprocess.run([exe, weights[0], weights[1], wav, "--precision", "bf16"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "f32, f16 or x3" in bad.stderr
 
 
 # ------------------------------------------------------------------ full-size, size-independent properties
