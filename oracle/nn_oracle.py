@@ -100,13 +100,19 @@ def fbank_norm_ref(stft_out, wav_lens, mel, dtype=torch.float32):
     x_db = 10.0 * torch.log10(torch.clamp(fb, min=1e-10))
     mx = x_db.amax(dim=(-2, -1)) - 80.0
     x_db = torch.max(x_db, mx.view(-1, 1, 1))
-    Tn = x_db.shape[1]
+    return sentence_mean_norm(x_db, wav_lens)
+
+
+def sentence_mean_norm(x, wav_lens):
+    """threeModel.py:333-369 (MyNormalization, norm_type "sentence", mean only): subtract the mean over the first round(len * T) frames;
+    pinned on the reference's own class by tests/test_reference_nn_glue.py"""
+    Tn = x.shape[1]
     lens = torch.as_tensor(wav_lens, dtype=torch.float32)
-    out = x_db.clone()
-    for i in range(x_db.shape[0]):
+    out = x.clone()
+    for i in range(x.shape[0]):
         n = int(torch.round(lens[i] * Tn).long())
-        mean = x_db[i, 0:n].mean(dim=0)
-        out[i] = x_db[i] - mean
+        mean = x[i, 0:n].mean(dim=0)
+        out[i] = x[i] - mean
     return out
 
 
