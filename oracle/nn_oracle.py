@@ -14,6 +14,9 @@ here are the published upstream ones the exporters load:
     -> MyNormalization (mean only) -> ECAPA_TDNN(C=1024, att 128, lin 192).
   * STFT: sd.cpp:1980-2013 (torch::stft fp64, fp32 periodic Hamming window,
     center, zero pad, onesided), transposed to [B,501,201,2] and cast to f32.
+What the reference's own Python holds of these stages IS pinned (tests/test_reference_nn_glue.py, fixtures minted from
+embeddings/threeModel.py): stft_ref against MySTFT (to float32 rounding: the Python runs it in float32, the C++ in fp64)
+and sentence_mean_norm against MyNormalization (bit for bit).
 Weights are seeded synthetic (no checkpoints travel); the same weight pack file
 feeds the HIP library so both sides use identical numbers.
 """
