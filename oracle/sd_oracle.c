@@ -22,14 +22,15 @@
  *   - orc_closest_frame, orc_window_start, orc_range_to_segment, orc_support (gap / merge), the frame count of
  *     orc_speaker_count : pinned on the reference's own segment/utils.py (Segment, SlidingWindow), imported in the
  *     build container -> tests/golden/ref_glue.npz (tools/mint_reference_fixtures.py, tests/test_reference_glue.py).
- *   - orc_binarize, orc_crop, orc_mask_compact, orc_wav_lens : pinned on binarize_ndarray / crop / embedding_mask of the
+ *   - orc_binarize, orc_select_masks, orc_crop, orc_mask_compact, orc_wav_lens : pinned on binarize_ndarray / the mask choice of
+ *     forward / crop / embedding_mask of the
  *     reference's segment/mysegment.py, executed from the file's own definitions -> tests/golden/ref_nn_glue.npz
  *     (tools/mint_reference_fixtures_nn.py, tests/test_reference_nn_glue.py).
  *   - orc_clustering_ex / orc_clustering_full / orc_cluster_embeddings_ex / orc_constrained_argmax (filter, AHC + small ->
  *     large re-assignment, recuts, assignment, constrained assignment) : pinned on the reference's clustering/Clustering.py
  *     executed on the real scipy -> tests/golden/ref_clustering.npz (tools/mint_reference_fixtures_clustering.py,
  *     tests/test_reference_clustering.py).
- *   - what is left -- the mask choice of a6, the overlap-add of orc_aggregate beyond its frame indexing, the state machine of
+ *   - what is left -- the overlap-add of orc_aggregate beyond its frame indexing, the state machine of
  *     to_annotation beyond the Segment operations, reconstruct / to_diarization -- is a line-by-line restatement whose only
  *     golden in the reference is the README sample output (needs the missing ONNX blobs) => "parity unpinned" beyond the
  *     restatement itself.

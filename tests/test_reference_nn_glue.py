@@ -87,6 +87,26 @@ def test_mask_interpolation_compaction_and_wav_lens_against_reference_python(gol
     assert an and ts.all()
 
 
+def test_mask_choice_against_reference_python(gold):
+    """a6: per (chunk, local speaker) the clean mask -- frames where fewer than two speakers are active -- if it keeps MORE than
+    ceil(293 * 640 / 80000) = 3 frames, else the full mask (mysegment.py:436-485 <-> sd.cpp:2430-2470), in the order the embedding batches are
+    filled (chunk-major, speaker-minor); the chunk windows handed over with the masks are the crops of a7"""
+    bz = gold["mc_binarized"].astype(np.float64)
+    want = gold["mc_used_masks"]
+    got = orc.select_masks(bz)
+    assert np.array_equal(got, want)
+    clean = bz * (bz.sum(axis=2, keepdims=True) < 2)
+    cm = clean.transpose(0, 2, 1).reshape(-1, 293)
+    fm = bz.transpose(0, 2, 1).reshape(-1, 293)
+    took_clean = (want == cm).all(1) & (cm != fm).any(1)
+    took_full = (want == fm).all(1) & (cm != fm).any(1)
+    assert took_clean.sum() >= 10 and took_full.sum() >= 3            # both branches decided somewhere
+    assert took_full[7 * 3 + 0] and cm[7 * 3 + 0].sum() == 3          # exactly 3 clean frames is not "more than 3"
+    wav, _ = _em_case(gold)
+    for i in range(0, len(want), 3):
+        assert orc.crop(wav, (i // 3) * 8000).astype(np.float64).sum() == gold["mc_wave_sum"][i]
+
+
 def test_chunk_crop_against_reference_python(gold):
     """the 5-second window of chunk k: samples floor(t * 16000) ... + 80 000, zeros past the end of the recording (mysegment.py:226-260, mode
     "pad") <-> the crop in front of a7 (sd.cpp:2567-2635); chunk starts k * 0.5 s and a few off-grid starts"""
@@ -136,6 +156,15 @@ def test_hip_postseg_binarize_against_reference_python(diarizer, gold):
     s, want, tie = _pin_case(gold)
     nb, masks, count = diarizer.postseg(s)
     assert np.array_equal(nb[~tie], want[~tie]) and (nb[tie] == 0).all()
+
+
+@pytest.mark.gpu
+def test_hip_postseg_mask_choice_against_reference_python(diarizer, gold):
+    """sd_postseg on scores that binarise to the reference's a6 patterns (0.9 where active, 0.1 where not): its masks are the reference's choice"""
+    bz = gold["mc_binarized"]
+    scores = np.where(bz > 0, np.float32(0.9), np.float32(0.1)).astype(np.float32)
+    nb, masks, count = diarizer.postseg(scores)
+    assert np.array_equal(nb, bz) and np.array_equal(masks, gold["mc_used_masks"])
 
 
 @pytest.mark.gpu

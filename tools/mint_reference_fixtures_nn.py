@@ -21,6 +21,11 @@ What is minted:
            of the 293-frame mask to 80 000 samples, > 0.5, compaction, wav_lens = count / max, too-short items -> 1.0, a batch whose longest
            item is too short -> all NaN)  <-> a7.  Two batches of 32 items cut from one recording the way the pipeline cuts them
            (item i = local speaker i % 3 of chunk i // 3, chunk hop 8 000 samples) + one batch that is too short as a whole
+  mc_*     the mask choice of a6 (clean mask if it keeps more than ceil(293 * 640 / 80000) frames, else the full mask; sd.cpp:2430-2470).  In
+           the reference's Python this rule stands in mysegment.py:forward (:436-485) BEHIND an early `return` (the author's test hook), so it
+           cannot be reached by a call: the script takes those lines as they stand, puts `def _(self, waveform, sample_rate,
+           binary_segmentations):` in front and `return list(iter_waveform_and_mask())` behind (the only two lines that are not the
+           reference's), and runs them on the reference's own SlidingWindowFeature / SlidingWindow / crop
   crop_*   crop(waveform, 16000, Segment(t, t + 5), duration = 5.0, mode = "pad") (:226-260, with downmix_and_resample :261-291 at the native rate)
            <-> the chunk windows of a7 (sd.cpp:2567-2635): start sample floor(t * 16000), zero padding past the end of the recording
   stft_*   MySTFT(16000)(x) on float32 signals (the Python's arithmetic; the C++ runs the same torch::stft in fp64, sd.cpp:1980-2036) <-> a8
@@ -59,6 +64,14 @@ def take(path, names, ns):
         mod = ast.Module(body=[found[n]], type_ignores=[])
         exec(compile(mod, path, "exec"), ns)
     return [ns[n] for n in names]
+
+
+def l_is_batches(line):
+    return line.strip().startswith("batches = batchify(")
+
+
+def tw_for_mc(wav):
+    return torch.from_numpy(wav)[None]
 
 
 def main():
@@ -159,6 +172,43 @@ def main():
     short[:, 10:12] = 1.0
     r = embedding_mask(self_, torch.zeros(32, 1, 80000), short)
     out["em_all_short_is_nan"] = np.array([isinstance(r, np.ndarray) and bool(np.isnan(r).all()) and r.shape == (32, 192)])
+
+    # ---- mask choice (a6)
+    lines = open(SEG).read().splitlines(keepends=True)
+    i0 = next(i for i, l in enumerate(lines) if l.strip().startswith("duration = binary_segmentations.sliding_window.duration"))
+    i1 = next(i for i in range(i0, len(lines)) if l_is_batches(lines[i]))
+    body = "".join(l[4:] if l.startswith("    ") else l for l in lines[i0:i1])
+    src = "def _mask_choice(self, waveform, sample_rate, binary_segmentations):\n" + body + "    return list(iter_waveform_and_mask())\n"
+    ns.update({"SlidingWindowFeature": ref_utils.SlidingWindowFeature, "SlidingWindow": ref_utils.SlidingWindow})
+    exec(compile(src, SEG, "exec"), ns)
+    mself = types.SimpleNamespace(sample_rate=16000, min_num_samples=640)
+    mself.downmix_and_resample = types.MethodType(downmix_and_resample, mself)
+    mself.crop = types.MethodType(crop, mself)
+    mc_chunks = 22
+    bz = np.zeros((mc_chunks, Fr, 3), np.float64)
+    for ci in range(mc_chunks):
+        for k in range(3):
+            kind = (3 * ci + k) % 7
+            if kind == 0:
+                bz[ci, :, k] = 1.0
+            elif kind == 1:
+                a = int(rng.integers(0, Fr - 8)); bz[ci, a:a + int(rng.integers(1, 8)), k] = 1.0      # 1..7 frames: around the 3-frame limit
+            elif kind == 2:
+                pass
+            else:
+                a, bb = sorted(rng.integers(0, Fr + 1, 2)); bz[ci, a:bb, k] = 1.0
+    bz[5, :, :] = 0.0
+    bz[5, 10:14, 0] = 1.0; bz[5, 11:14, 1] = 1.0          # clean mask keeps exactly 1 / 0 frames
+    bz[6, :, :] = 0.0
+    bz[6, 10:20, 0] = 1.0; bz[6, 16:30, 1] = 1.0          # clean masks keep 6 / 10 frames (> 3)
+    bz[7, :, :] = 0.0
+    bz[7, 10:15, 0] = 1.0; bz[7, 13:40, 1] = 1.0          # speaker 0 keeps exactly 3 clean frames: NOT more than 3 -> full mask
+    swf = ref_utils.SlidingWindowFeature(bz, ref_utils.SlidingWindow(start=0.0, duration=5.0, step=0.5))
+    got = ns["_mask_choice"](mself, tw_for_mc(wav), 16000, swf)
+    assert len(got) == 3 * mc_chunks
+    out["mc_binarized"] = bz.astype(np.uint8)
+    out["mc_used_masks"] = np.stack([m[0].numpy() for _, m in got]).astype(np.float32)
+    out["mc_wave_sum"] = np.array([float(w.double().sum()) for w, _ in got])
 
     # ---- crop (chunk windows of a7)
     cself = types.SimpleNamespace(sample_rate=16000)
