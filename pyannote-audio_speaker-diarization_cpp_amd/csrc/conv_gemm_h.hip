@@ -149,6 +149,13 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
             rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sB + sK, 0));
         }
     };
+    auto gload_half = [&](int h) {                    // x3: the loader registers of restaging part h (row r8 + 128 h of A, two W rows)
+#pragma unroll
+        for (int p = 2 * h; p < 2 * h + 2; ++p) {
+            ra[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rA, voA[p >> 1] + (p & 1) * 16, sK, 0));
+            rb[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rB, voB[p], sB + sK, 0));
+        }
+    };
     auto lstore_part = [&](int buf, int p) {          // x3: row r8 + 128 p of A (the split), rows r0 + 64 (2 p), r0 + 64 (2 p + 1) of W
         float* A = As0 + buf * HM * HLDP; float* B = Bs0 + buf * HN * HLDP;
         half8 hi, lo;
@@ -243,7 +250,8 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
     lstore(0);
     __syncthreads();
     advance();
-    if constexpr (X) { afrag(0, 0, 0); bfrag(0, 0, 0); } else hfrag(0, 0, 0);
+    if constexpr (X) { gload(); advance(); afrag(0, 0, 0); bfrag(0, 0, 0); }       // x3: the loader registers hold step 1, the load stream stands at step 2
+    else hfrag(0, 0, 0);
 
     int q = q0, s = 0, buf = 0;
     while (true) {
@@ -257,29 +265,39 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
 #define W_PAIR(mask, n) do { _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); } } while (0)
         if constexpr (X) {
             // x3: six groups of 8 MFMAs per K-step.  Fragment registers A0 / W0 hold hi block 0 of this step on entry; every group's operands
-            // are read one group ahead into the registers the group before last released; global loads are issued in group 1 and restaged in
-            // group 5 (four groups = 1024 MFMA cycles of latency budget, twice the fp16 form's)
+            // are read one group ahead into the registers the group before last released.  The load stream runs TWO steps ahead: on entry the
+            // loader registers hold step s + 1 (restaged in groups 2 and 4, so that the LDS writes have landed long before the barrier behind
+            // group 5), and each half of them is refilled with step s + 2 in the group after its restaging (five groups of latency budget).
+            // [measured, tools/x3_ablate.sh, MFA layer: 168 ms with loads in group 1 and all restaging in groups 4-5; 142 ms without the
+            // global loads, 115 ms without restaging and barrier = the MFMA + fragment-read floor]
+            // SD_X3_ABLATE (tools/x3_ablate.sh, never in the product build): 1 = no global loads in the loop, 2 = no restaging / barrier, 3 = both
+#ifndef SD_X3_ABLATE
+#define SD_X3_ABLATE 0
+#endif
             afrag(buf, 2, 1);                      // lo block 0 of A
-            gload();
             xmma(0, 0);                            // hi0 * hi0
-            W_PAIR(0x100, 2);
-#pragma unroll
-            for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            W_PAIR(0x100, 2); __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             __builtin_amdgcn_sched_barrier(0);
             bfrag(buf, 2, 1);                      // lo block 0 of W
             xmma(1, 0);                            // lo0 * hi0
-            W_PAIR(0x100, 4); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (!(SD_X3_ABLATE & 2)) lstore_part(buf ^ 1, 0);
+            // the split of a row's eight channels is ~28 VALU instructions, and there are four LDS writes: left alone they all sit behind the
+            // group's last MFMA
+            W_PAIR(0x100, 4);
+#pragma unroll
+            for (int i_ = 0; i_ < 3; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 10, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
             __builtin_amdgcn_sched_barrier(0);
             afrag(buf, 1, 1); bfrag(buf, 1, 0);    // hi block 1 of both
             xmma(0, 1);                            // hi0 * lo0
-            W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (!(SD_X3_ABLATE & 1)) gload_half(0);
+            W_PAIR(0x100, 6);
+#pragma unroll
+            for (int i_ = 0; i_ < 2; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); }
             __builtin_amdgcn_sched_barrier(0);
             afrag(buf, 3, 0);                      // lo block 1 of A
             xmma(1, 0);                            // hi1 * hi1
-            lstore_part(buf ^ 1, 0);
-            // the split of a row's eight channels is ~28 VALU instructions, and there are four LDS writes: left alone they all sit behind the group's last MFMA, in
-            // front of the barrier, in all eight waves at once
+            if (!(SD_X3_ABLATE & 2)) lstore_part(buf ^ 1, 1);
             W_PAIR(0x100, 2);
 #pragma unroll
             for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
@@ -288,13 +306,13 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
             __builtin_amdgcn_sched_barrier(0);
             bfrag(buf, 3, 1);                      // lo block 1 of W
             xmma(0, 0);                            // lo1 * hi1
-            lstore_part(buf ^ 1, 1);
+            if (!(SD_X3_ABLATE & 1)) gload_half(1);
             W_PAIR(0x100, 4);
 #pragma unroll
-            for (int i_ = 0; i_ < 3; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 11, 0); }
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
+            for (int i_ = 0; i_ < 2; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
+            if (!(SD_X3_ABLATE & 2)) __syncthreads();
             afrag(buf ^ 1, 0, 0); bfrag(buf ^ 1, 0, 0);
             xmma(1, 1);                            // hi1 * lo1
             W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -335,7 +353,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_w256(ConvArgs a)
         W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, H ? 2 : 26, 0);
         __builtin_amdgcn_sched_barrier(0);
         }
-        advance();
+        advance();            // (x3: the load stream now stands two steps ahead of the step that starts next)
 
         if (s == S - 1) {
             // ---- epilogue.  C layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); see conv_gemm.hip
