@@ -435,6 +435,18 @@ def test_sharded_entry_point_through_rccl_world_of_one(diarizer):
             finally:
                 diarizer.set_option("virtual_world", 0)
                 diarizer.set_option("rank0_permille", -1)
+        # the same in x3 mode (ecapa_precision = 3): a rank's embeddings do not depend on which rank computed them or in which batch
+        diarizer.set_option("ecapa_precision", 3)
+        try:
+            whole_x3 = diarizer.diarize_dev(d_pcm.data_ptr(), n)
+            for W, pm in [(2, -1), (8, 30)]:
+                diarizer.set_option("virtual_world", W)
+                diarizer.set_option("rank0_permille", pm)
+                assert diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 0, n, n) == whole_x3, (W, pm)
+        finally:
+            diarizer.set_option("virtual_world", 0)
+            diarizer.set_option("rank0_permille", -1)
+            diarizer.set_option("ecapa_precision", 0)
         with pytest.raises(sdhip.SdError) as e:
             diarizer.diarize_sharded_dev(d_pcm.data_ptr(), 8000, n - 8000, n)       # samples do not cover the rank's chunks
         assert "do not cover" in str(e.value)
