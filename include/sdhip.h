@@ -188,7 +188,8 @@ int sd_stage_ms(const sd_ctx*, double* ms4);
  * Clustering.py:81-94: the local speakers of a chunk go to different clusters; applies to sd_clustering* and the whole path),
  * "ecapa_precision" (0 = f32 MFMA = the reference's ORT precision (default); 1 = fp16 weights and activations on the fp16 MFMA with f32
  *   accumulation; 2 = the same with hi + lo fp16 weight planes; 3 = f32 tensors, both MFMA operands split into hi + lo fp16 halves, three
- *   products per multiply-add: f32-grade embeddings (<= 1e-7 cosine distance to mode 0) at about half of mode 0's time),
+ *   products per multiply-add: f32-grade embeddings (<= 1e-7 cosine distance to mode 0) at about half of mode 0's time; a batch whose activations
+ *   leave fp16's range is detected and repeated on the f32 kernels),
  * "rank0_permille" (sd_diarize_sharded: share of the chunks rank 0 infers itself, -1 = equal),
  * "comm_timeout_ms" (deadline of the exchange step of a sharded job, default 600 000).
  * Test and tuning keys are listed in sdhip_test.h.  An unknown key returns SD_ERR_ARG. */

@@ -220,13 +220,18 @@ extern "C" int sd_ecapa(sd_ctx* c, const float* h_feats, const float* h_lens, in
     HIPCHK(c, hipMemcpy(dv.p, nv.data(), items * sizeof(int), hipMemcpyHostToDevice));
     int64_t nb = (c->emb_batch_items / 96) * 96; if (nb < 96) nb = 96;
     const int64_t cap_rows = nb * SD_TP;
-    for (int64_t a0 = 0; a0 < items;) {
-        int64_t a1 = a0;
-        while (a1 < items && a1 - a0 < ROWTAB_MAX_ITEMS && rowoff[(size_t)a1 + 1] - rowoff[(size_t)a0] <= cap_rows) ++a1;
-        if (a1 == a0) a1 = a0 + 1;
-        if ((rc = run_ecapa(c, (const float*)df.p, (const int*)dv.p, plan, a0, a1, (float*)de.p))) return rc;
-        a0 = a1;
-    }
+    rc = ecapa_run_batches(c, [&]() -> int {
+        for (int64_t a0 = 0; a0 < items;) {
+            int64_t a1 = a0;
+            while (a1 < items && a1 - a0 < ROWTAB_MAX_ITEMS && rowoff[(size_t)a1 + 1] - rowoff[(size_t)a0] <= cap_rows) ++a1;
+            if (a1 == a0) a1 = a0 + 1;
+            const int r = run_ecapa(c, (const float*)df.p, (const int*)dv.p, plan, a0, a1, (float*)de.p);
+            if (r) return r;
+            a0 = a1;
+        }
+        return SD_OK;
+    });
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(h_emb, de.p, items * SD_EMB_DIM * sizeof(float), hipMemcpyDeviceToHost));
     return SD_OK;

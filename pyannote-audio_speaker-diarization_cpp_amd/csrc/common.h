@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <functional>
 #include <vector>
 #include "../../include/sdhip_test.h"
 
@@ -212,6 +213,7 @@ int ecapa_need_rows(int nvalid, bool skip_dead_rows);             // rows of an 
 int ecapa_row_plan(sd_ctx* c, const int* h_nvalid, int64_t n, EcapaRowPlan& plan, int* d_off /*[EC_SPACES][n + 1]*/);
 // items [a0, a1) of the plan; d_feats = space-0 rows of ALL the plan's items
 int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid /*[n]*/, const EcapaRowPlan& plan, int64_t a0, int64_t a1, float* d_emb /*[n][192]*/);
+int ecapa_run_batches(sd_ctx* c, const std::function<int()>& batches);      // x3 mode: repeats the batches on the f32 kernels if an embedding came out non-finite
 int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item, float* d_emb);
 // ---- pyannet.hip
 int run_segment(sd_ctx* c, const float* d_wav, int64_t n, int64_t chunk_lo, int64_t chunk_hi, float* d_seg);

@@ -345,10 +345,45 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
     return SD_OK;
 }
 
+// x3 mode splits f32 activations into fp16 halves: an activation beyond +-65 504 has no hi half (Inf, then NaN all the way to the embedding), where
+// the f32 kernels would carry on.  Every x3 batch therefore raises a flag when one of its embeddings is not finite, and the caller
+// (ecapa_run_batches) repeats the call on the f32 kernels: the mode is never worse than f32, and an overflow costs time, not the result.
+__global__ void k_flag_nonfinite(const float* e, int64_t n, int* flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !isfinite(e[i])) *flag = 1;
+}
+
 int run_ecapa(sd_ctx* c, const float* d_feats, const int* d_nvalid, const EcapaRowPlan& plan, int64_t a0, int64_t a1, float* d_emb)
 {
     if (c->ecapa_precision == 1 || c->ecapa_precision == 2) return run_ecapa_t<_Float16>(c, d_feats, d_nvalid, plan, a0, a1, d_emb);
-    return run_ecapa_t<float>(c, d_feats, d_nvalid, plan, a0, a1, d_emb);
+    const int rc = run_ecapa_t<float>(c, d_feats, d_nvalid, plan, a0, a1, d_emb);
+    if (rc == SD_OK && c->ecapa_precision == 3 && a1 > a0) {
+        WS(c, int, flag, "ec_x3_flag", 1);
+        hipLaunchKernelGGL(k_flag_nonfinite, GRID1((a1 - a0) * SD_EMB_DIM), 0, c->stream, d_emb + (size_t)a0 * SD_EMB_DIM, (a1 - a0) * SD_EMB_DIM, flag);
+        KCHECK(c);
+    }
+    return rc;
+}
+
+// runs `batches` (a sequence of run_ecapa calls over one set of items); in x3 mode it runs them again on the f32 kernels when the flag says that an
+// embedding came out non-finite (one stream synchronisation per call of this function, x3 mode only)
+int ecapa_run_batches(sd_ctx* c, const std::function<int()>& batches)
+{
+    if (c->ecapa_precision != 3) return batches();
+    WS(c, int, flag, "ec_x3_flag", 1);
+    HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+    int rc = batches();
+    if (rc) return rc;
+    int h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!h) return SD_OK;
+    c->stats["x3_overflow_fallbacks"].launches += 1;
+    c->ecapa_precision = 0;
+    rc = batches();
+    c->ecapa_precision = 3;
+    return rc;
 }
 
 // host side of the compact row plan: first row of every item in each space, from the items' nvalid (uploaded to d_off)
@@ -427,6 +462,8 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
             return actual > 0.0 ? ideal / actual : 0.0;
         };
         const int64_t n_batches = (rows_all + cap_rows - 1) / cap_rows;
+        rc = ecapa_run_batches(c, [&]() -> int {
+        int rc = SD_OK;
         for (int64_t a0 = 0, k = 1; a0 < n_active; ++k) {
             int64_t a_max = a0;                                   // the most the workspaces take
             while (a_max < n_active && a_max - a0 < ROWTAB_MAX_ITEMS && rowoff[(size_t)a_max + 1] - rowoff[(size_t)a0] <= cap_rows) ++a_max;
@@ -448,6 +485,9 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
             if ((rc = run_ecapa(c, feats, nvalid, plan, a0, a1, emb_c))) return rc;
             a0 = a1;
         }
+        return rc;
+        });
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(k_scatter_emb, GRID1(items * SD_EMB_DIM), 0, c->stream, emb_c, cidx, d_emb, items);
     KCHECK(c);

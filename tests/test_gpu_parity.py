@@ -238,6 +238,22 @@ def test_ecapa_x3_split_operands_on_the_fp16_mfma_hold_the_f32_bars(diarizer, we
     rel32 = np.linalg.norm(g32 - r, axis=1) / np.linalg.norm(r, axis=1)
     assert rel.max() < 3 * max(rel32.max(), 1e-5), (rel.max(), rel32.max())
     assert np.array_equal(diarizer.ecapa(feats, lens), e32)
+    # overflow guard: activations beyond fp16's range have no hi half (Inf -> NaN embeddings); the mode notices and repeats the call on the
+    # f32 kernels -- the f32 path's bits, one fallback counted, and the mode stays selected for the next call
+    big = feats.copy()
+    big[1] *= 3.0e4
+    e32_big = diarizer.ecapa(big, lens)
+    assert np.isfinite(e32_big).all()
+    diarizer.set_option("ecapa_precision", 3)
+    try:
+        diarizer.reset_stats()
+        ex_big = diarizer.ecapa(big, lens)
+        assert diarizer.kernel_stats("x3_overflow_fallbacks")["launches"] == 1
+        assert np.array_equal(ex_big, e32_big)
+        again = diarizer.ecapa(feats, lens)
+        assert np.array_equal(again, ex) and diarizer.kernel_stats("x3_overflow_fallbacks")["launches"] == 1
+    finally:
+        diarizer.set_option("ecapa_precision", 0)
 
 
 def test_ecapa_fp16_wide_tile_kernel_gives_the_same_bits(diarizer):
