@@ -158,3 +158,47 @@ def test_split_weight_packing_of_the_x3_mode_on_the_host():
         assert (err[big] <= 2.0 ** -21 * np.abs(ref[:, :, :cin][big])).all()
         assert (err[~big] <= 2.0 ** -25 * inv.value).all()                # subnormal lo halves: absolute error of half a subnormal step
     assert L.sd_test_pack_split_weights(w.ctypes.data_as(C.c_void_p), K, Cout, 80, 80, out.ctypes.data_as(C.c_void_p), C.byref(inv)) != 0      # CinPad % 32
+
+
+def test_split_operand_arithmetic_of_the_x3_mode_is_f32_grade():
+    """the arithmetic of option ecapa_precision = 3, modelled in numpy (no GPU): both operands of a dot product are split into hi = fp16(v) and
+    lo = fp16(v - hi), the weights after the power-of-two scale of sd_test_pack_split_weights; hi*hi + lo*hi + hi*lo is accumulated in f32, the
+    lo*lo term dropped.  Per product the error is 2^-21 of |a w| plus -- for activations below 2^-3, whose lo halves are fp16 subnormals --
+    an absolute 2^-25 |w|: the bound asserted below.  For activations of order one and larger (what BatchNorm leaves in every ECAPA layer) that
+    is the class of the plain f32 dot product, three orders below fp16 operands (mode 1); a layer whose activations were ALL tiny would fall
+    back to the absolute term (the "small" case: still 20x better than fp16 operands, no longer f32-grade) -- DESIGN section 4 says so."""
+    rng = np.random.default_rng(11)
+    K, N = 3072, 64                                    # the MFA layer's contraction length
+
+    def split(v):
+        hi = v.astype(np.float16)
+        lo = (v - hi.astype(np.float32)).astype(np.float16)
+        return hi.astype(np.float32), lo.astype(np.float32)
+
+    res = {}
+    for name, a_scale in (("unit", 1.0), ("small", 2.0 ** -9), ("large", 3.0e3)):
+        a = (a_scale * np.abs(rng.standard_normal((N, K)))).astype(np.float32)                   # post-ReLU activations
+        w = (rng.standard_normal((K,)) * np.exp(2.0 * rng.standard_normal((K,))) / np.sqrt(K)).astype(np.float32)
+        e = int(np.floor(np.log2(np.abs(w).max()))) + 1
+        sc = np.float32(2.0 ** (14 - e))                                                         # largest weight into [2^13, 2^14)
+        ah, al = split(a)
+        wh, wl = split(w * sc)
+        exact = a.astype(np.float64) @ w.astype(np.float64)
+        acc = np.zeros(N, np.float32)
+        for k0 in range(0, K, 16):                                                               # one MFMA k-block at a time, f32 accumulator
+            s_ = slice(k0, k0 + 16)
+            for x, y in ((ah, wh), (al, wh), (ah, wl)):
+                acc = (acc + (x[:, s_].astype(np.float64) @ y[s_].astype(np.float64)).astype(np.float32)).astype(np.float32)
+        x3 = acc.astype(np.float64) / float(sc)
+        f32 = np.zeros(N, np.float32)
+        for k0 in range(0, K, 2):                                                                # v_mfma_f32_32x32x2_f32: two products per accumulation
+            f32 = (f32 + (a[:, k0:k0 + 2].astype(np.float64) @ w[k0:k0 + 2].astype(np.float64)).astype(np.float32)).astype(np.float32)
+        h16 = (a.astype(np.float16).astype(np.float64) @ w.astype(np.float16).astype(np.float64))
+        aw = np.abs(a.astype(np.float64)) @ np.abs(w.astype(np.float64))                         # the magnitude the roundings are relative to
+        bound = 2.0 ** -21 * aw + 2.0 ** -25 * np.abs(w.astype(np.float64)).sum() + 2.0 ** -22 * aw      # split terms + the f32 accumulation
+        assert (np.abs(x3 - exact) <= bound).all(), name
+        res[name] = (np.abs(x3 - exact) / aw).max(), (np.abs(f32 - exact) / aw).max(), (np.abs(h16 - exact) / aw).max()
+    for name in ("unit", "large"):
+        ex3, ef32, eh16 = res[name]
+        assert ex3 < 4e-7 and ex3 < 8 * max(ef32, 2.0 ** -24) and eh16 > 100 * ex3, (name, res[name])
+    assert res["small"][0] < 5e-6 and res["small"][2] > 20 * res["small"][0], res["small"]
