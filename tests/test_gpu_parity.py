@@ -256,6 +256,52 @@ def test_ecapa_x3_split_operands_on_the_fp16_mfma_hold_the_f32_bars(diarizer, we
         diarizer.set_option("ecapa_precision", 0)
 
 
+def test_ecapa_x3_holds_for_tiny_and_huge_weights(weights, tmp_path):
+    """x3 mode scales every layer's weights by a power of two before the split, so that their lo halves are normal fp16 numbers whatever the
+    layer's magnitude (weights.cpp).  Packs whose MFA / tdnn1 / Res2Net / block0 / tdnn2 layers are rescaled by 3e-5 ... 2e4 (conv weights and
+    bias by s, the BatchNorm behind them by s and s^2, so that the activations keep their size) are valid models of their own: on each of them
+    the x3 embeddings must sit on the f32 path's, as they do for the original pack.  (Without the per-layer scale the lo halves of weights of
+    1e-6 would all be zero: fp16-mode accuracy.)"""
+    import sdhip
+    we = weights[3]
+    rng = np.random.default_rng(41)
+    lens = np.array([1.0, 0.6, 0.3, 0.85], np.float32)
+    feats = (3.0 * rng.standard_normal((len(lens), 501, 80))).astype(np.float32)
+
+    def scaled(pack, layer, s):
+        w = dict(pack)
+        w[layer + ".conv.weight"] = (pack[layer + ".conv.weight"].astype(np.float64) * s).astype(np.float32)
+        w[layer + ".conv.bias"] = (pack[layer + ".conv.bias"].astype(np.float64) * s).astype(np.float32)
+        w[layer + ".norm.running_mean"] = (pack[layer + ".norm.running_mean"].astype(np.float64) * s).astype(np.float32)
+        w[layer + ".norm.running_var"] = np.maximum(pack[layer + ".norm.running_var"].astype(np.float64) * s * s, 1e-30).astype(np.float32)
+        return w
+
+    def run(pack, mode, k=[0]):
+        ep = str(tmp_path / ("e%d.sdw" % k[0])); k[0] += 1
+        nn.save_pack(ep, pack)
+        d = sdhip.Diarizer(weights[0], ep)
+        try:
+            d.set_option("ecapa_precision", mode)
+            return d.ecapa(feats, lens).astype(np.float64)
+        finally:
+            d.close()
+
+    def cosd(a, b):
+        return 1 - (a * b).sum(1) / np.linalg.norm(a, axis=1) / np.linalg.norm(b, axis=1)
+
+    packs = {"original": we,
+             "large": scaled(scaled(scaled(we, "mfa", 1.9e4), "blocks.1.tdnn1", 2.0 ** 14), "blocks.2.res2net.3", 3.0e2),
+             "small": scaled(scaled(scaled(scaled(we, "mfa", 2.0e-2), "blocks.1.tdnn1", 6.0e-3), "blocks.3.tdnn2", 7.3e-3), "blocks.0", 1.5e-2),
+             # weights of 1e-6: BatchNorm's eps dominates the variance, so the layer's output shrinks to ~1 % -- a different but valid model
+             "tiny": scaled(we, "mfa", 3.1e-5)}
+    for name, p in packs.items():
+        ex, ef = run(p, 3), run(p, 0)
+        assert np.isfinite(ex).all() and np.isfinite(ef).all() and not np.array_equal(ex, ef), name
+        assert cosd(ex, ef).max() < 1e-6, (name, cosd(ex, ef).max())
+        rel = np.linalg.norm(ex - ef, axis=1) / np.linalg.norm(ef, axis=1)
+        assert rel.max() < 1e-3, (name, rel.max())
+
+
 def test_ecapa_fp16_wide_tile_kernel_gives_the_same_bits(diarizer):
     """fp16 mode: the 256 x 256 kernel of the wide layers (conv_gemm_h.hip) and the 128 x 128 kernel feed the same k-blocks to the
     same MFMA in the same order: embeddings must be bit-identical, whichever kernel a batch size selects"""
