@@ -398,6 +398,8 @@ def main():
          sdhip.Diarizer(os.path.join(tmp, "segment.sdw"), os.path.join(tmp, "embedding.sdw"), local))
     if a.precision != "f32":
         d.set_option("ecapa_precision", 1 if a.precision == "f16" else 3)
+        if a.precision == "x3":
+            d.set_option("seg_precision", 3)
     for kv in a.opt:
         k, v = kv.split("=")
         d.set_option(k, int(v))
@@ -541,6 +543,7 @@ def main():
             """the same job `steps` times with ecapa_precision = opt; its own roofline (the wide kernel of the mode against the fp16 MFMA peak) and the
             cosine distances of its REAL embeddings to the f32 ones"""
             d.set_option("ecapa_precision", opt)
+            d.set_option("seg_precision", 3 if opt == 3 else 0)        # x3 = the split MFMA operands in both networks (ECAPA conv layers, PyanNet's LSTM)
             d.set_option("profile", 1)
             step()
             d.reset_stats()
@@ -562,6 +565,7 @@ def main():
                 step()
                 em = d.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192).astype(np.float64)
                 d.set_option("ecapa_precision", 0)
+                d.set_option("seg_precision", 0)
                 step()
                 e32 = d.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192).astype(np.float64)
                 if planted:
@@ -572,6 +576,7 @@ def main():
                 cosd = {"items": int(lv.sum()), "max": float("%.3g" % cd.max()), "q99": float("%.3g" % np.quantile(cd, 0.99)), "median": float("%.3g" % np.median(cd)),
                         "above_1e-3": int((cd > 1e-3).sum()), "same_nan_rows": same_nan}
             d.set_option("ecapa_precision", 0)
+            d.set_option("seg_precision", 0)
             tf = wm["flops"] / max(wm["ms"], 1e-9) / 1e9
             rl = {"bound": "mfma", "kernel": kernel, "achieved": round(tf * mfma_per_flop, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": round(tf * mfma_per_flop / F16_MFMA_PEAK_TFLOPS, 4), "kernel_ms_per_step": round(wm["ms"] / steps, 2), "launches_per_step": wm["launches"] // steps,
@@ -590,9 +595,10 @@ def main():
                                                  "secondary mode, never the headline value", 1)
         if a.precision == "f32" and a.x3_steps > 0:
             extra_lines["x3"] = secondary_mode(3, a.x3_steps, "conv_w256_x3", "conv_gemm_x3", "k_conv_gemm_w256<3> (v_mfma_f32_32x32x16_f16 on split operands)",
-                                               "option ecapa_precision = 3: f32 tensors in HBM as in the headline run; every ECAPA conv layer splits both operands into hi + lo fp16 "
-                                               "halves (22 bits) and runs hi*hi + lo*hi + hi*lo on the fp16 MFMA with f32 accumulation -- f32-grade embeddings (see the cosine "
-                                               "distances) from the fp16 matrix pipe; opt-in, not the headline value", 3)
+                                               "options ecapa_precision = 3 + seg_precision = 3: f32 tensors in HBM as in the headline run; every ECAPA conv layer and PyanNet's LSTM (input "
+                                               "projections of layers 1-3, recurrence) split both MFMA operands into hi + lo fp16 halves (22 bits) and run hi*hi + lo*hi + hi*lo on the "
+                                               "fp16 MFMA with f32 accumulation -- f32-grade scores and embeddings (see the cosine distances) from the fp16 matrix pipe; opt-in, not "
+                                               "the headline value", 3)
 
     if rank == 0:
         ach = cg["flops"] / max(cg["ms"], 1e-9) / 1e9      # TFLOP/s

@@ -190,6 +190,8 @@ int sd_stage_ms(const sd_ctx*, double* ms4);
  *   accumulation; 2 = the same with hi + lo fp16 weight planes; 3 = f32 tensors, both MFMA operands split into hi + lo fp16 halves, three
  *   products per multiply-add: f32-grade embeddings (<= 1e-7 cosine distance to mode 0) at about half of mode 0's time; a batch whose activations
  *   leave fp16's range is detected and repeated on the f32 kernels),
+ * "seg_precision" (0 = f32 MFMA (default); 3 = the same operand split for PyanNet's LSTM: input projections of layers 1-3 and the recurrence;
+ *   scores within 1e-6 of mode 0),
  * "rank0_permille" (sd_diarize_sharded: share of the chunks rank 0 infers itself, -1 = equal),
  * "comm_timeout_ms" (deadline of the exchange step of a sharded job, default 600 000).
  * Test and tuning keys are listed in sdhip_test.h.  An unknown key returns SD_ERR_ARG. */

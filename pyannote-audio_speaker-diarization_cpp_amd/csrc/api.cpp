@@ -108,6 +108,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "seg_wide_ih") c->seg_wide_ih = v != 0;
     else if (k == "conv_w256_kmin") c->conv_w256_kmin = (int)v;
     else if (k == "conv_pn128") c->conv_pn128 = (int)v;
+    else if (k == "seg_precision") { if (v != 0 && v != 3) SD_FAIL(c, SD_ERR_ARG, "seg_precision must be 0 (f32) or 3 (split fp16 operands for the LSTM)"); c->seg_precision = (int)v; }
     else if (k == "ecapa_precision") { if (v < 0 || v > 3) SD_FAIL(c, SD_ERR_ARG, "ecapa_precision must be 0 (f32), 1 (fp16), 2 (fp16, hi + lo weight planes) or 3 (f32 tensors, split fp16 operands on the wide layers)"); c->ecapa_precision = (int)v; }
     else if (k == "ecapa_f16_hp") c->ecapa_f16_hp = (int)v;
     else if (k == "ecapa_keep_cat") c->ecapa_keep_cat = v != 0;

@@ -102,6 +102,8 @@ struct SegWeights {
     float* in_b[3] = {nullptr, nullptr, nullptr};
     ConvLayer lstm_ih[4];              // [1024][in] both directions stacked, bias = b_ih + b_hh
     float* lstm_hh[4][2] = {};         // [512][128] per layer, direction (PyTorch gate order i,f,g,o)
+    void* lstm_hh_x[4][2] = {};        // option seg_precision = 3: [hi | lo][512][128] fp16 halves of W_hh * 2^e; lstm_hh_inv = 2^-e
+    float lstm_hh_inv[4][2] = {};
     ConvLayer lin0, lin1;
     float* cls_w = nullptr; float* cls_b = nullptr;   // [3][128], [3]
 };
@@ -123,6 +125,7 @@ struct sd_ctx {
     int64_t seg_batch_chunks = 4096;           // 128 LSTM workgroups per direction: one full wave of CUs
     int num_clusters = -1, min_clusters = -1, max_clusters = -1;   // optional constraints for the whole-path entry points
     int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation, 2 = the same with hi + lo fp16 weight planes, 3 = f32 tensors, hi + lo split of BOTH operands on the fp16 MFMA (wide layers; the others stay f32)
+    int seg_precision = 0;                      // 0 = f32 MFMA; 3 = PyanNet's LSTM (input projections of layers 1-3 and the recurrence) with both MFMA operands split into hi + lo fp16 halves
     bool ecapa_keep_cat = false;                // diagnostics: f32 mode keeps the block outputs (the logits get their own buffer)
     int ecapa_f16_hp = 0;                       // fp16 mode: bit 0 = MFA output / pooling inputs in f32, bit 1 = attention branch on the f32 MFMA
     bool conv_w256_f32 = true;                  // f32: the same 256 x 256 kernel for the wide, long-K ECAPA layers (TDNN, MFA)

@@ -11,7 +11,8 @@
 //                   passes it to the others through pipes created before the fork; turns are printed by rank 0
 //   --rttm FILE     also write the turns as RTTM
 //   --precision P   f32 (default: f32 MFMA, the reference's ORT precision) | f16 (fp16 ECAPA layers, BASELINE configs[4]) | x3 (f32 tensors, both
-//                   MFMA operands split into hi + lo fp16 halves: f32-grade embeddings from the fp16 matrix pipe) = sd_set_option "ecapa_precision"
+//                   MFMA operands split into hi + lo fp16 halves in the ECAPA conv layers and PyanNet's LSTM: f32-grade results from the fp16 matrix
+//                   pipe) = sd_set_option "ecapa_precision" (+ "seg_precision" = 3 for x3)
 //   --relabel       stdout / RTTM labels renumbered the way pyannote.audio names its output (the clusters that occur,
 //                   sorted by their string, become 0, 1, ... = SPEAKER_00, SPEAKER_01, ...); default = raw cluster ids (sd.cpp:3439)
 #include <cstdio>
@@ -53,6 +54,7 @@ static int run_single(const Args& a)
     sd_ctx* ctx = sd_create(a.seg, a.emb, 0);
     if (!ctx) { fprintf(stderr, "sd_create failed: %s\n", sd_create_error()); return 1; }
     if (a.precision && sd_set_option(ctx, "ecapa_precision", a.precision) != SD_OK) { fprintf(stderr, "%s\n", sd_last_error(ctx)); return 1; }
+    if (a.precision == 3 && sd_set_option(ctx, "seg_precision", 3) != SD_OK) { fprintf(stderr, "%s\n", sd_last_error(ctx)); return 1; }
     sd_turn* turns = nullptr; int64_t nt = 0;
     const int rc = sd_diarize_f32(ctx, wav, n, &turns, &nt);
     if (rc != SD_OK) { fprintf(stderr, "diarization failed (%d): %s\n", rc, sd_last_error(ctx)); return 1; }
@@ -84,6 +86,7 @@ static int run_rank(const Args& a, int rank, int world, int id_rd, const std::ve
     sd_ctx* ctx = sd_create(a.seg, a.emb, rank);
     if (!ctx) { fprintf(stderr, "rank %d: sd_create failed: %s\n", rank, sd_create_error()); return 1; }
     if (a.precision && sd_set_option(ctx, "ecapa_precision", a.precision) != SD_OK) { fprintf(stderr, "rank %d: %s\n", rank, sd_last_error(ctx)); return 1; }
+    if (a.precision == 3 && sd_set_option(ctx, "seg_precision", 3) != SD_OK) { fprintf(stderr, "rank %d: %s\n", rank, sd_last_error(ctx)); return 1; }
     unsigned char id[SD_COMM_ID_BYTES];
     if (rank == 0) {
         for (size_t q = 0; q < ready_rd.size(); ++q) {

@@ -232,6 +232,104 @@ __global__ __launch_bounds__(512) void k_lstm_rec(const float* __restrict__ G, c
     }
 }
 
+// ---------------------------------------------------------------- k_lstm_rec_x3
+// option seg_precision = 3: the same recurrence with both MFMA operands split into hi + lo fp16 halves (conv_gemm_h.hip's x3 arithmetic):
+// W_hh * 2^e as two fp16 planes, stationary in the same 128 registers; h is kept in LDS as hi and lo halves (the lane that computes a
+// unit writes both); per 16-wide k-block hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16, f32 accumulation, times 2^-e in front of the
+// gates: 48 MFMAs of 32 cycles per wave and step instead of 128 of 64.
+typedef _Float16 lhalf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lhalf4 __attribute__((ext_vector_type(4)));
+#define HXLD 264            // halves per batch row of the LDS image of h: 128 hi + 128 lo + 8 of padding (528 B: conflict-free 16-byte reads)
+__global__ __launch_bounds__(512) void k_lstm_rec_x3(const float* __restrict__ G, const _Float16* __restrict__ whh_f, const _Float16* __restrict__ whh_b,
+                                                     float inv_f, float inv_b, float* __restrict__ H, int B, int F)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 hbuf[2][32 * HXLD];
+    const int dir = blockIdx.y, b0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int u0 = 16 * w;
+    const _Float16* whh = dir ? whh_b : whh_f;
+    const float inv = dir ? inv_b : inv_f;
+
+    // stationary operand: Wr[tile][plane][kb] = W[plane][(2 tile + gsel) * 128 + unit][16 kb + 8 lh .. + 7]
+    lhalf8 Wr[2][2][8];
+    {
+        const int gsel = li >> 4, unit = u0 + (li & 15);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb)
+                    Wr[t][pl][kb] = *(const lhalf8*)(whh + (size_t)pl * 512 * 128 + ((size_t)((2 * t + gsel) * 128 + unit)) * 128 + 16 * kb + 8 * lh);
+    }
+    for (int i = tid; i < 2 * 32 * HXLD; i += 512) (&hbuf[0][0])[i] = (_Float16)0.0f;
+    float cst[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) cst[r] = 0.0f;
+    const int bj = (b0 + li < B) ? (b0 + li) : (B - 1);
+    const bool live = (b0 + li) < B;
+    const int ua = u0 + 4 * lh, ub = u0 + 8 + 4 * lh;      // the two 4-unit groups this lane owns
+    __syncthreads();
+
+    int cur = 0;
+    for (int step = 0; step < F; ++step) {
+        const int t = dir ? (F - 1 - step) : step;
+        const float* g = G + ((size_t)bj * F + t) * 1024 + dir * 512;
+        float4 gi[2], gf[2], gg[2], go[2];
+        gi[0] = *(const float4*)(g + 0 * 128 + ua); gi[1] = *(const float4*)(g + 0 * 128 + ub);
+        gf[0] = *(const float4*)(g + 1 * 128 + ua); gf[1] = *(const float4*)(g + 1 * 128 + ub);
+        gg[0] = *(const float4*)(g + 2 * 128 + ua); gg[1] = *(const float4*)(g + 2 * 128 + ub);
+        go[0] = *(const float4*)(g + 3 * 128 + ua); go[1] = *(const float4*)(g + 3 * 128 + ub);
+
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        const _Float16* hb = &hbuf[cur][li * HXLD + 8 * lh];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const lhalf8 hh = *(const lhalf8*)(hb + 16 * kb);
+            const lhalf8 hl = *(const lhalf8*)(hb + 128 + 16 * kb);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[0][0][kb], hh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[1][0][kb], hh, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[0][1][kb], hh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[1][1][kb], hh, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[0][0][kb], hl, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[1][0][kb], hl, acc1, 0, 0, 0);
+        }
+        const float giv[8] = {gi[0].x, gi[0].y, gi[0].z, gi[0].w, gi[1].x, gi[1].y, gi[1].z, gi[1].w};
+        const float gfv[8] = {gf[0].x, gf[0].y, gf[0].z, gf[0].w, gf[1].x, gf[1].y, gf[1].z, gf[1].w};
+        const float ggv[8] = {gg[0].x, gg[0].y, gg[0].z, gg[0].w, gg[1].x, gg[1].y, gg[1].z, gg[1].w};
+        const float gov[8] = {go[0].x, go[0].y, go[0].z, go[0].w, go[1].x, go[1].y, go[1].z, go[1].w};
+        float hv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float ig = sigm(acc0[r] * inv + giv[r]);
+            const float fg = sigm(acc0[r + 8] * inv + gfv[r]);
+            const float gt = tanh_fast(acc1[r] * inv + ggv[r]);
+            const float og = sigm(acc1[r + 8] * inv + gov[r]);
+            cst[r] = fg * cst[r] + ig * gt;
+            hv[r] = og * tanh_fast(cst[r]);
+        }
+        _Float16* hn = &hbuf[cur ^ 1][li * HXLD];
+        lhalf4 h0, l0, h1, l1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h0[e] = (_Float16)hv[e];     l0[e] = (_Float16)(hv[e] - (float)h0[e]);
+            h1[e] = (_Float16)hv[4 + e]; l1[e] = (_Float16)(hv[4 + e] - (float)h1[e]);
+        }
+        *(lhalf4*)(hn + ua) = h0; *(lhalf4*)(hn + 128 + ua) = l0;
+        *(lhalf4*)(hn + ub) = h1; *(lhalf4*)(hn + 128 + ub) = l1;
+        if (live) {
+            float* ho = H + ((size_t)(b0 + li) * F + t) * 256 + dir * 128;
+            *(float4*)(ho + ua) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+            *(float4*)(ho + ub) = make_float4(hv[4], hv[5], hv[6], hv[7]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // ---------------------------------------------------------------- k_classifier
 // seg[chunk][f][k] = sigmoid(W[k] . y[chunk*F + f] + b[k]) for f < F; zero-padded to 293 frames (sd.cpp:1473-1479)
 __global__ __launch_bounds__(256) void k_classifier(const float* __restrict__ y, const float* __restrict__ W, const float* __restrict__ bias,
@@ -381,12 +479,17 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
                     KCHECK(c);
                 }
                 a.rowtab = dense_tab; a.pad_mode = 0; a.Tin = 512; a.T = 512; a.TpIn = a.TpOut = 512; a.in_rows = (int)(CB * F);
+                if (c->seg_precision == 3 && S.lstm_ih[l].W16x) { a.prec = 3; a.W16x = S.lstm_ih[l].W16x; a.acc_scale = S.lstm_ih[l].w16x_inv; }   // split operands (conv_gemm_h.hip P = 3)
             }
             if ((rc = launch_conv_gemm(c, a, "lstm_ih"))) return rc;
         }
         {
             ProfScope ps(c, "lstm_rec", 2.0 * CB * F * 2 * 512 * 128, 0);
-            hipLaunchKernelGGL(k_lstm_rec, dim3((unsigned)((CB + 31) / 32), 2), dim3(512), 0, st, G, S.lstm_hh[l][0], S.lstm_hh[l][1], hout, (int)CB, F);
+            if (c->seg_precision == 3 && S.lstm_hh_x[l][0] && S.lstm_hh_x[l][1])
+                hipLaunchKernelGGL(k_lstm_rec_x3, dim3((unsigned)((CB + 31) / 32), 2), dim3(512), 0, st, G, (const _Float16*)S.lstm_hh_x[l][0], (const _Float16*)S.lstm_hh_x[l][1],
+                                   S.lstm_hh_inv[l][0], S.lstm_hh_inv[l][1], hout, (int)CB, F);
+            else
+                hipLaunchKernelGGL(k_lstm_rec, dim3((unsigned)((CB + 31) / 32), 2), dim3(512), 0, st, G, S.lstm_hh[l][0], S.lstm_hh[l][1], hout, (int)CB, F);
             KCHECK(c);
         }
         lin = hout; lin_ld = 256; lin_rows_per_chunk = F;

@@ -286,6 +286,22 @@ int build_seg_weights(sd_ctx* c, const Pack& p)
             if (!wih[d] || !bih[d] || !bhh[d] || !whh) return SD_ERR_MODEL;
             S.lstm_hh[l][d] = upload(c, whh->data);
             if (!S.lstm_hh[l][d]) return SD_ERR_HIP;
+            if (whh->data.size() == (size_t)512 * 128) {        // option seg_precision = 3: hi and lo planes of W_hh * 2^e (k_lstm_rec_x3)
+                float wmax = 0.0f;
+                for (float v : whh->data) if (std::isfinite(v)) wmax = fmaxf(wmax, fabsf(v));
+                int e = 0;
+                if (wmax > 0.0f) { (void)frexpf(wmax, &e); e = 14 - e; }
+                const float sc = ldexpf(1.0f, e);
+                std::vector<_Float16> hx((size_t)2 * 512 * 128);
+                for (size_t q = 0; q < (size_t)512 * 128; ++q) {
+                    const float v = whh->data[q] * sc;
+                    const _Float16 hi = (_Float16)v;
+                    hx[q] = hi; hx[(size_t)512 * 128 + q] = (_Float16)(v - (float)hi);
+                }
+                S.lstm_hh_x[l][d] = upload(c, hx);
+                if (!S.lstm_hh_x[l][d]) return SD_ERR_HIP;
+                S.lstm_hh_inv[l][d] = ldexpf(1.0f, -e);
+            }
         }
         const int nin = (int)wih[0]->dims[1];
         const int pad = (nin + 31) / 32 * 32;
@@ -299,6 +315,12 @@ int build_seg_weights(sd_ctx* c, const Pack& p)
         L.W = upload(c, hw); L.bias = upload(c, hb);
         if (!L.W || !L.bias) return SD_ERR_HIP;
         L.Cin = nin; L.CinPad = pad; L.Cout = 1024; L.KT = 1; L.dil = 1;
+        {       // option seg_precision = 3: split weights of the input projection (the wide conv kernel's x3 form)
+            std::vector<_Float16> hx((size_t)2 * 1024 * pad);
+            pack_split_weights(hw.data(), 1, 1024, pad, nin, hx.data(), &L.w16x_inv);
+            L.W16x = upload(c, hx);
+            if (!L.W16x) return SD_ERR_HIP;
+        }
     }
     if ((rc = make_conv(c, p, "linear.0.weight", "linear.0.bias", "", 1, S.lin0))) return rc;
     if ((rc = make_conv(c, p, "linear.1.weight", "linear.1.bias", "", 1, S.lin1))) return rc;

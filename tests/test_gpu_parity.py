@@ -43,6 +43,37 @@ def test_segmentation_parity(diarizer, weights, n):
         np.testing.assert_allclose(seg[i], ref, rtol=RTOL, atol=ATOL)
 
 
+def test_segmentation_with_split_lstm_operands_holds_the_f32_bars(diarizer, weights):
+    """option seg_precision = 3: PyanNet's LSTM -- the input projections of layers 1-3 (conv_gemm_h.hip's x3 form) and the recurrence
+    (k_lstm_rec_x3) -- with both MFMA operands split into hi + lo fp16 halves.  Same bars as the f32 path against the torch oracle, scores
+    within 2e-6 of the f32 path's (293 recurrent steps deep), through full chunks, a short last chunk, a loud stretch with a DC offset and
+    a nearly silent one; leaving the mode restores the f32 bits; the 8 s recording that yields a single short chunk works too."""
+    n = 80000 + 8000 * 5 + 3000
+    rng = np.random.default_rng(91)
+    wav = (0.05 * rng.standard_normal(n)).astype(np.float32) * (1 + np.sin(np.arange(n) / 2000.0)).astype(np.float32)
+    wav[:30000] = wav[:30000] * 8 + 0.2
+    wav[70000:95000] *= 1e-3
+    s32 = diarizer.segment(wav)
+    diarizer.set_option("seg_precision", 3)
+    try:
+        sx = diarizer.segment(wav)
+        short = diarizer.segment(wav[:47011])
+    finally:
+        diarizer.set_option("seg_precision", 0)
+    assert not np.array_equal(sx, s32) and np.abs(sx - s32).max() <= 2e-6, np.abs(sx - s32).max()
+    nc, last = orc.num_chunks(n)
+    net = nn.PyanNetOracle(weights[2])
+    refs = np.zeros((nc, 293, 3), np.float32)
+    for i in range(nc):
+        y = net(wav[None, i * 8000:i * 8000 + 80000]).numpy()[0]
+        refs[i, :y.shape[0]] = y                    # short last chunk is zero padded (sd.cpp:1473-1479)
+    np.testing.assert_allclose(sx, refs, rtol=RTOL, atol=ATOL)
+    # as close to the oracle as the f32 path is (both differ from it by summation order and by the gates' exp / rcp forms)
+    assert np.abs(sx - refs).max() <= 2 * max(np.abs(s32 - refs).max(), 1e-6), (np.abs(sx - refs).max(), np.abs(s32 - refs).max())
+    assert np.array_equal(diarizer.segment(wav), s32)
+    assert short.shape == (1, 293, 3) and np.abs(short - diarizer.segment(wav[:47011])).max() <= 2e-6
+
+
 def test_segmentation_shared_conv0_equals_per_chunk_conv0(diarizer, weights):
     """SincNet conv0 applied once to the raw waveform + the chunk normalisation as an affine map (pyannet.hip, k_chunk_stats)
     against one conv per normalised chunk: same scores to rounding, also with a DC offset, a loud and a nearly silent stretch
