@@ -272,15 +272,24 @@ __global__ __launch_bounds__(512) void k_lstm_rec_x3(const float* __restrict__ G
     const int ua = u0 + 4 * lh, ub = u0 + 8 + 4 * lh;      // the two 4-unit groups this lane owns
     __syncthreads();
 
+    // the input-projection rows of a step are fetched one step ahead: the MFMA phase (48 x 32 cycles) is shorter than a global load's latency
+    float4 ni[2], nf[2], ng[2], no[2];
+    auto fetch = [&](int step) {
+        const int t = dir ? (F - 1 - step) : step;
+        const float* g = G + ((size_t)bj * F + t) * 1024 + dir * 512;
+        ni[0] = *(const float4*)(g + 0 * 128 + ua); ni[1] = *(const float4*)(g + 0 * 128 + ub);
+        nf[0] = *(const float4*)(g + 1 * 128 + ua); nf[1] = *(const float4*)(g + 1 * 128 + ub);
+        ng[0] = *(const float4*)(g + 2 * 128 + ua); ng[1] = *(const float4*)(g + 2 * 128 + ub);
+        no[0] = *(const float4*)(g + 3 * 128 + ua); no[1] = *(const float4*)(g + 3 * 128 + ub);
+    };
+    fetch(0);
     int cur = 0;
     for (int step = 0; step < F; ++step) {
         const int t = dir ? (F - 1 - step) : step;
-        const float* g = G + ((size_t)bj * F + t) * 1024 + dir * 512;
         float4 gi[2], gf[2], gg[2], go[2];
-        gi[0] = *(const float4*)(g + 0 * 128 + ua); gi[1] = *(const float4*)(g + 0 * 128 + ub);
-        gf[0] = *(const float4*)(g + 1 * 128 + ua); gf[1] = *(const float4*)(g + 1 * 128 + ub);
-        gg[0] = *(const float4*)(g + 2 * 128 + ua); gg[1] = *(const float4*)(g + 2 * 128 + ub);
-        go[0] = *(const float4*)(g + 3 * 128 + ua); go[1] = *(const float4*)(g + 3 * 128 + ub);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { gi[q] = ni[q]; gf[q] = nf[q]; gg[q] = ng[q]; go[q] = no[q]; }
+        fetch(step + 1 < F ? step + 1 : step);
 
         f32x16 acc0, acc1;
 #pragma unroll
