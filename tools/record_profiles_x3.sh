@@ -8,7 +8,7 @@ mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python3 bench.py --precision x3 --steps 2 --warmup 1 --cpu-seconds 0 > gpurun_out/${tag}_bench_1h_x3_under_trace.json 2> $out/trace.err
 cp "$(find $out/trace -name "*kernel_stats.csv" | head -1)" gpurun_out/${tag}_bench_1h_x3_kernel_stats.csv
 {
-for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
+for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   d=$out/pmc_$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --output-format csv -d $d -o p -- python3 bench.py --precision x3 --steps 1 --warmup 1 --cpu-seconds 0 > /dev/null 2> $d.err
   echo "== rocprofv3 --pmc $set -- python3 bench.py --precision x3 --steps 1 --warmup 1 --cpu-seconds 0"
