@@ -74,6 +74,18 @@ def test_segmentation_with_split_lstm_operands_holds_the_f32_bars(diarizer, weig
     assert short.shape == (1, 293, 3) and np.abs(short - diarizer.segment(wav[:47011])).max() <= 2e-6
 
 
+def test_option_keys_are_validated(diarizer):
+    """sd_set_option: an unknown key and an out-of-range precision are refused with SD_ERR_ARG and a message; the context stays usable"""
+    import sdhip
+    for key, val, frag in (("no_such_key", 1, "no_such_key"), ("ecapa_precision", 4, "ecapa_precision must be"), ("ecapa_precision", -1, "ecapa_precision must be"),
+                           ("seg_precision", 1, "seg_precision must be"), ("seg_precision", 2, "seg_precision must be")):
+        with pytest.raises(sdhip.SdError) as e:
+            diarizer.set_option(key, val)
+        assert e.value.code == 1 and frag in str(e.value), (key, val, str(e.value))
+    for key, val in (("ecapa_precision", 3), ("ecapa_precision", 0), ("seg_precision", 3), ("seg_precision", 0)):
+        diarizer.set_option(key, val)
+
+
 def test_segmentation_shared_conv0_equals_per_chunk_conv0(diarizer, weights):
     """SincNet conv0 applied once to the raw waveform + the chunk normalisation as an affine map (pyannet.hip, k_chunk_stats)
     against one conv per normalised chunk: same scores to rounding, also with a DC offset, a loud and a nearly silent stretch
