@@ -100,11 +100,12 @@ template <class T> __global__ void k_asp_pool(const T* __restrict__ x, const flo
     const float* pl = logit + (size_t)(rowoff[item] - row_base) * ld + ch;
     float mx = -INFINITY, W = 0.0f, mean = 0.0f, m2 = 0.0f;
     auto step = [&](float l, float v) {
-        if (l > mx) { const float s = expf(mx - l); W *= s; m2 *= s; mx = l; }      // expf(-inf) = 0 on the first frame
-        const float w = expf(l - mx);
+        // (v_exp_f32 / v_rcp_f32 forms: the library's expf and the IEEE division made this kernel VALU-bound, two thirds of the chip's issue slots)
+        if (l > mx) { const float s = __expf(mx - l); W *= s; m2 *= s; mx = l; }      // exp(-inf) = 0 on the first frame
+        const float w = __expf(l - mx);
         W += w;
         const float d = v - mean;
-        mean += (w / W) * d;
+        mean += (w * __builtin_amdgcn_rcpf(W)) * d;
         m2 += w * d * (v - mean);
     };
     int t = 0;
