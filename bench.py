@@ -106,6 +106,32 @@ def reference_clustering_baseline(d, seconds=1800):
             "gpu_ms": round(gpu_ms, 2), "ratio": round(cpu_s * 1e3 / gpu_ms, 1), "same_labels": bool(np.array_equal(T_ref, T_gpu))}
 
 
+def reference_finalize_baseline(d, scores, emb32, n_total, turns, dev):
+    """Everything of the reference's speakerDiarization() behind the two networks -- binarize_swf, speaker_count (trim + aggregate +
+    np_rint), Cluster::clustering, the inactive rule, reconstruct / to_diarization, to_annotation, finalResult -- run by the REFERENCE'S
+    OWN compiled C++ (oracle/_ref/libref_glue.so: the ORT-free line ranges of speakerDiarizer.cpp built unedited, oracle/Makefile) on
+    the scores and embeddings of the job that was just timed, one host thread as the reference runs it, next to sd_finalize_dev on the
+    same device-resident inputs; the turns must be the job's own, order included."""
+    from oracle import orc
+    if orc.refglue() is None:
+        return None
+    G = orc.RefGlue()
+    C = scores.shape[0]
+    t0 = time.perf_counter()
+    t_ref, K = G.finalize(scores, emb32.astype(np.float64), n_total)
+    cpu_s = time.perf_counter() - t0
+    d_seg, d_emb = torch.from_numpy(scores).to(dev), torch.from_numpy(emb32).to(dev)
+    torch.cuda.synchronize()
+    d.finalize_dev(d_seg.data_ptr(), d_emb.data_ptr(), C, n_total)
+    t0 = time.perf_counter()
+    t_gpu = d.finalize_dev(d_seg.data_ptr(), d_emb.data_ptr(), C, n_total)
+    gpu_ms = (time.perf_counter() - t0) * 1e3
+    return {"kind": "reference", "what": "the reference's own compiled glue (oracle/_ref/libref_glue.so) from segmentation scores + embeddings to sorted turns on the "
+            "timed job's %d chunks / %d live items, 1 host thread, against sd_finalize_dev on the same inputs resident in HBM" % (C, int((~np.isnan(emb32[:, 0])).sum())),
+            "cores": 1, "cpu_s": round(cpu_s, 2), "gpu_ms": round(gpu_ms, 2), "ratio": round(cpu_s * 1e3 / gpu_ms, 1), "K": K, "turns": len(t_ref),
+            "same_turns_as_sd_finalize_dev": t_ref == t_gpu, "same_turns_as_the_timed_job": t_ref == turns}
+
+
 def union_chunk_range(plan, n_total, world, rank, C):
     """chunks rank `rank` can be given under any rank-0 share between 0 and 1 / world (plan = sdhip.shard_plan): the hull of its ranges
     under the two extreme plans, widened by 32 * (world + 1) chunks: every range starts on a multiple of 32 chunks and the per-rank share
@@ -287,6 +313,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hours-per-gpu", type=float, default=1.0)
     ap.add_argument("--cpu-seconds", type=int, default=60, help="audio seconds for the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--ref-finalize", type=int, default=1, help="N = 1, planted workload of at most 1 h: also run the REFERENCE's own compiled glue (oracle/_ref/"
+                    "libref_glue.so) from scores + embeddings to turns on the timed job and report it under cpu_baseline.reference_finalize (~45 s of host time; 0 = skip)")
     ap.add_argument("--workload", default="planted", choices=["planted", "raw"], help="planted = SURVEY 8d (network outputs replaced by the "
                     "schedule-derived scores / talker embeddings after the networks ran); raw = whatever the random-weight networks say (K = 1)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "x3"], help="f32 = the measured configuration (f32 MFMA); f16 = "
@@ -683,6 +711,14 @@ def main():
                 out["cpu_baseline"]["reference_clustering"] = reference_clustering_baseline(d)
             except Exception as e:                      # (the baseline beside the baseline must never cost the line)
                 out["cpu_baseline"]["reference_clustering"] = {"error": str(e)[:200]}
+            if planted and not use_dist and a.ref_finalize and C <= 7300:
+                try:
+                    step()                                                                  # the secondary modes ran last: leave the headline job's buffers behind
+                    gpu_sync()
+                    e32 = d.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192)     # the job's embeddings: planted rows, NaN rows by the reference's rule
+                    out["cpu_baseline"]["reference_finalize"] = reference_finalize_baseline(d, p_scores, e32, n_total, turns, dev)
+                except Exception as e:
+                    out["cpu_baseline"]["reference_finalize"] = {"error": str(e)[:200]}
         else:
             out["cpu_baseline"] = None
         out["config"]["rank0_share"] = share_note

@@ -1,6 +1,6 @@
 """ctypes binding of oracle/libsd_oracle.so (C restatement of the reference's
-non-neural stages) and oracle/_ref/libref_clustering.so (the reference's own
-clustering.cpp).  TEST INFRASTRUCTURE ONLY -- imported by tests/, smoke() and
+non-neural stages), oracle/_ref/libref_clustering.so (the reference's own
+clustering.cpp) and oracle/_ref/libref_glue.so (the reference's own speakerDiarizer.cpp glue).  TEST INFRASTRUCTURE ONLY -- imported by tests/, smoke() and
 bench.py's cpu_baseline leg; never by the product path."""
 import ctypes as C
 import os
@@ -16,6 +16,21 @@ c_fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 c_ip = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 c_lp = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 c_bp = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+# ---- constants of the reference (SURVEY Appendix A) ----
+SR = 16000
+WINDOW = 80000
+STEP = 8000
+FRAMES = 293
+SPEAKERS = 3
+ONSET = 0.4442333667381752
+MIN_OFF_F32 = float(np.float32(0.5817029604921046))       # sd.cpp:3210 (float)
+THRESH_F32 = float(np.float32(0.7153814381597874))         # sd.cpp:2049 (float)
+MIN_CLUSTER_SIZE = 15
+MIN_SAMPLES = 640
+FRAME_STEP = 0.016875
+EMB_BATCH = 32
 
 
 class Turn(C.Structure):
@@ -128,19 +143,205 @@ def ref_wav_read(path):
     return out[:n], sr.value, ch.value, bits.value
 
 
-# ---- constants of the reference (SURVEY Appendix A) ----
-SR = 16000
-WINDOW = 80000
-STEP = 8000
-FRAMES = 293
-SPEAKERS = 3
-ONSET = 0.4442333667381752
-MIN_OFF_F32 = float(np.float32(0.5817029604921046))       # sd.cpp:3210 (float)
-THRESH_F32 = float(np.float32(0.7153814381597874))         # sd.cpp:2049 (float)
-MIN_CLUSTER_SIZE = 15
-MIN_SAMPLES = 640
-FRAME_STEP = 0.016875
-EMB_BATCH = 32
+_REFGLUE = None
+
+
+def refglue():
+    """the reference's own speakerDiarizer.cpp glue (oracle/_ref/libref_glue.so: every ORT-free line range of that file,
+    compiled unedited -- see ref_build/make_glue_tu.sh).  None when oracle/_ref is absent."""
+    global _REFGLUE
+    if _REFGLUE is not None:
+        return _REFGLUE
+    p = os.path.join(_HERE, "_ref", "libref_glue.so")
+    if not os.path.exists(p):
+        return None
+    R = C.CDLL(p)
+    R.ref_np_rint.restype = C.c_int
+    R.ref_np_rint.argtypes = [C.c_double]
+    R.ref_closest_frame.restype = C.c_long
+    R.ref_closest_frame.argtypes = [C.c_double] * 4
+    R.ref_argsort.argtypes = [c_dp, C.c_long, c_ip]
+    R.ref_argmax.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, c_ip]
+    R.ref_cosine_cdist.argtypes = [c_dp, C.c_long, c_dp, C.c_long, C.c_int, c_dp]
+    R.ref_binarize.argtypes = [c_fp, C.c_long, C.c_int, C.c_int, c_dp]
+    R.ref_crop.restype = C.c_long
+    R.ref_crop.argtypes = [c_fp, C.c_long, C.c_double, c_fp, C.c_long]
+    R.ref_clean_segmentations.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, c_dp]
+    R.ref_select_masks.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, c_fp]
+    R.ref_speaker_count.restype = C.c_long
+    R.ref_speaker_count.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, C.c_long, c_ip, C.c_long, c_dp]
+    R.ref_aggregate.restype = C.c_long
+    R.ref_aggregate.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_long,
+                                C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_long]
+    R.ref_embedding_inputs.restype = C.c_int
+    R.ref_embedding_inputs.argtypes = [c_fp, c_fp, C.c_int, C.c_int, C.c_long, c_fp, c_fp, c_bp]
+    R.ref_cluster_embeddings.restype = C.c_int
+    R.ref_cluster_embeddings.argtypes = [c_dp, C.c_long, C.c_int, c_ip]
+    R.ref_clustering.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, c_ip]
+    R.ref_mark_inactive.argtypes = [c_dp, C.c_long, C.c_int, C.c_int, c_ip]
+    R.ref_reconstruct.restype = C.c_long
+    R.ref_reconstruct.argtypes = [c_fp, C.c_long, C.c_int, C.c_int, c_ip, c_ip, C.c_long, c_dp, C.c_long, C.c_void_p, C.c_long,
+                                  C.POINTER(C.c_int), c_dp]
+    R.ref_to_annotation.restype = C.c_long
+    R.ref_to_annotation.argtypes = [c_dp, C.c_long, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(Turn), C.c_long]
+    R.ref_support.restype = C.c_long
+    R.ref_support.argtypes = [C.POINTER(Turn), C.c_long, C.c_double]
+    R.ref_finalize.restype = C.c_long
+    R.ref_finalize.argtypes = [c_fp, C.c_long, C.c_int, C.c_int, c_dp, C.c_int, C.c_long, C.POINTER(Turn), C.c_long, C.POINTER(C.c_int)]
+    _REFGLUE = R
+    return R
+
+
+class RefGlue:
+    """numpy-level view of refglue(): the same call shapes as the oracle functions of this module, so that a test reads
+    `orc.f(x) == orc.RefGlue().f(x)`.  Every method runs the REFERENCE's compiled C++."""
+
+    def __init__(self):
+        self.R = refglue()
+        if self.R is None:
+            raise RuntimeError("oracle/_ref/libref_glue.so is absent (built only where /root/reference exists)")
+
+    def np_rint(self, v):
+        return self.R.ref_np_rint(float(v))
+
+    def closest_frame(self, t, start=0.0, step=FRAME_STEP, dur=FRAME_STEP):
+        return self.R.ref_closest_frame(start, step, dur, float(t))
+
+    def argsort(self, v):
+        v = np.ascontiguousarray(v, np.float64)
+        idx = np.zeros(len(v), np.int32)
+        self.R.ref_argsort(v, len(v), idx)
+        return idx
+
+    def argmax(self, soft):
+        soft = np.ascontiguousarray(soft, np.float64)
+        c, S, K = soft.shape
+        out = np.zeros((c, S), np.int32)
+        self.R.ref_argmax(soft, c, S, K, out)
+        return out
+
+    def cosine_cdist(self, A, B):
+        A, B = np.ascontiguousarray(A, np.float64), np.ascontiguousarray(B, np.float64)
+        out = np.zeros((len(A), len(B)), np.float64)
+        self.R.ref_cosine_cdist(A, len(A), B, len(B), A.shape[1], out)
+        return out
+
+    def binarize(self, seg):
+        seg = np.ascontiguousarray(seg, np.float32)
+        c, F, K = seg.shape
+        out = np.empty((c, F, K), np.float64)
+        self.R.ref_binarize(seg, c, F, K, out)
+        return out
+
+    def crop(self, wav, start_sample):
+        wav = np.ascontiguousarray(wav, np.float32)
+        out = np.zeros(WINDOW + 16, np.float32)
+        n = self.R.ref_crop(wav, len(wav), start_sample / float(SR), out, len(out))
+        return out[:n].copy()
+
+    def clean_segmentations(self, b):
+        b = np.ascontiguousarray(b, np.float64)
+        c, F, K = b.shape
+        out = np.empty((c, F, K), np.float64)
+        self.R.ref_clean_segmentations(b, c, F, K, out)
+        return out
+
+    def select_masks(self, b):
+        b = np.ascontiguousarray(b, np.float64)
+        c, F, K = b.shape
+        m = np.empty((c * K, F), np.float32)
+        self.R.ref_select_masks(b, c, F, K, m)
+        return m
+
+    def speaker_count(self, b, num_samples):
+        b = np.ascontiguousarray(b, np.float64)
+        c, F, K = b.shape
+        cap = c * 40 + 400
+        cnt = np.zeros(cap, np.int32)
+        win = np.zeros(4, np.float64)
+        nf = self.R.ref_speaker_count(b, c, F, K, num_samples, cnt, cap, win)
+        assert 0 <= nf <= cap
+        return cnt[:nf].copy(), win
+
+    def aggregate(self, scores, sf_start, sf_step, sf_dur, sf_ns, fr_step=FRAME_STEP, fr_dur=FRAME_STEP, missing=np.nan,
+                  skip_average=False):
+        scores = np.ascontiguousarray(scores, np.float64)
+        c, F, K = scores.shape
+        nf = self.R.ref_aggregate(scores, c, F, K, sf_start, sf_step, sf_dur, sf_ns, fr_step, fr_dur, missing, int(skip_average), None, 0)
+        out = np.empty((nf, K), np.float64)
+        self.R.ref_aggregate(scores, c, F, K, sf_start, sf_step, sf_dur, sf_ns, fr_step, fr_dur, missing, int(skip_average),
+                             out.ctypes.data, nf)
+        return out
+
+    def embedding_inputs(self, wavs, masks):
+        """-> (signals [B][L], wav_lens [B], too_short [B], all_nan)"""
+        wavs, masks = np.ascontiguousarray(wavs, np.float32), np.ascontiguousarray(masks, np.float32)
+        B, L = wavs.shape
+        sig = np.zeros((B, L), np.float32)
+        lens = np.zeros(B, np.float32)
+        ts = np.zeros(B, np.uint8)
+        an = self.R.ref_embedding_inputs(wavs, masks, B, masks.shape[1], L, sig, lens, ts)
+        return sig, lens, ts.astype(bool), bool(an)
+
+    def cluster_embeddings(self, X):
+        X = np.ascontiguousarray(X, np.float64)
+        lab = np.zeros(len(X), np.int32)
+        K = self.R.ref_cluster_embeddings(X, len(X), X.shape[1], lab)
+        return lab, K
+
+    def clustering(self, emb):
+        emb = np.ascontiguousarray(emb, np.float64)
+        c, S, d = emb.shape
+        hard = np.zeros((c, S), np.int32)
+        self.R.ref_clustering(emb, c, S, d, hard)
+        return hard
+
+    def mark_inactive(self, b, hard):
+        b = np.ascontiguousarray(b, np.float64)
+        c, F, S = b.shape
+        hard = np.ascontiguousarray(hard, np.int32).copy()
+        self.R.ref_mark_inactive(b, c, F, S, hard)
+        return hard
+
+    def reconstruct(self, seg, hard, count, cwin, n_samples):
+        seg = np.ascontiguousarray(seg, np.float32)
+        c, F, S = seg.shape
+        hard = np.ascontiguousarray(hard, np.int32)
+        count = np.ascontiguousarray(count, np.int32)
+        cwin = np.ascontiguousarray(cwin, np.float64)
+        K = C.c_int(0)
+        fr = np.zeros(3, np.float64)
+        rows = self.R.ref_reconstruct(seg, c, F, S, hard, count, len(count), cwin, n_samples, None, 0, C.byref(K), fr)
+        out = np.zeros((rows, max(K.value, 1)), np.float64)
+        self.R.ref_reconstruct(seg, c, F, S, hard, count, len(count), cwin, n_samples, out.ctypes.data, rows, C.byref(K), fr)
+        return out, fr
+
+    def to_annotation(self, binary, start, step=FRAME_STEP, dur=FRAME_STEP):
+        b = np.ascontiguousarray(binary, np.float64)
+        rows, K = b.shape
+        cap = rows * K + 8
+        buf = (Turn * cap)()
+        n = self.R.ref_to_annotation(b, rows, K, start, step, dur, buf, cap)
+        return [(buf[i].start, buf[i].end, buf[i].label) for i in range(n)]
+
+    def support(self, segs, collar=None):
+        arr = (Turn * max(len(segs), 1))()
+        for i, (a, b) in enumerate(segs):
+            arr[i] = Turn(a, b, 0)
+        n = self.R.ref_support(arr, len(segs), MIN_OFF_F32 if collar is None else collar)
+        return [(arr[i].start, arr[i].end) for i in range(n)]
+
+    def finalize(self, seg, emb, num_samples):
+        """everything of speakerDiarization() behind the two networks -> (turns sorted as finalResult sorts them, K)"""
+        seg = np.ascontiguousarray(seg, np.float32)
+        c, F, S = seg.shape
+        emb = np.ascontiguousarray(emb, np.float64).reshape(c, S, -1)
+        cap = c * 8 + 64
+        buf = (Turn * cap)()
+        K = C.c_int(0)
+        n = self.R.ref_finalize(seg, c, F, S, emb, emb.shape[2], num_samples, buf, cap, C.byref(K))
+        assert n <= cap
+        return [(buf[i].start, buf[i].end, buf[i].label) for i in range(n)], K.value
 
 
 def np_rint(v):
