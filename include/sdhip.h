@@ -190,6 +190,10 @@ int sd_stage_ms(const sd_ctx*, double* ms4);
  *   accumulation; 2 = the same with hi + lo fp16 weight planes; 3 = f32 tensors, both MFMA operands split into hi + lo fp16 halves, three
  *   products per multiply-add: f32-grade embeddings (<= 1e-7 cosine distance to mode 0) at about half of mode 0's time; a batch whose activations
  *   leave fp16's range is detected and repeated on the f32 kernels),
+ *   Mode 0 is f32 storage, f32 MFMA products and f32 accumulation; its transcendentals are the hardware forms, not libm: tanh / sigmoid of
+ *   the LSTM gates through v_exp_f32 + v_rcp_f32, the softmax of the attentive pooling through v_exp_f32 / v_rcp_f32 (each <= 1 ulp of
+ *   the f32 result, i.e. ~1e-7 relative -- three orders below the parity tolerance rtol 1e-3 / atol 1e-4, and below what a different
+ *   summation order already moves); "f32 = the reference's precision" means that class of result, not libm-bit-identical.
  * "seg_precision" (0 = f32 MFMA (default); 3 = the same operand split for PyanNet's LSTM: input projections of layers 1-3 and the recurrence;
  *   scores within 1e-6 of mode 0),
  * "rank0_permille" (sd_diarize_sharded: share of the chunks rank 0 infers itself, -1 = equal),

@@ -110,7 +110,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "conv_pn128") c->conv_pn128 = (int)v;
     else if (k == "seg_precision") { if (v != 0 && v != 3) SD_FAIL(c, SD_ERR_ARG, "seg_precision must be 0 (f32) or 3 (split fp16 operands for the LSTM)"); c->seg_precision = (int)v; }
     else if (k == "ecapa_precision") { if (v < 0 || v > 3) SD_FAIL(c, SD_ERR_ARG, "ecapa_precision must be 0 (f32), 1 (fp16), 2 (fp16, hi + lo weight planes) or 3 (f32 tensors, split fp16 operands on the wide layers)"); c->ecapa_precision = (int)v; }
-    else if (k == "ecapa_f16_hp") c->ecapa_f16_hp = (int)v;
+    else if (k == "ecapa_f16_hp") { if (v != 0 && v != 1 && v != 3) SD_FAIL(c, SD_ERR_ARG, "ecapa_f16_hp must be 0, 1 (MFA output in f32) or 3 (+ the attention branch)"); c->ecapa_f16_hp = (int)v; }
     else if (k == "ecapa_keep_cat") c->ecapa_keep_cat = v != 0;
     else if (k == "rank0_permille") c->rank0_permille = (int)v;
     else if (k == "virtual_world") c->virtual_world = (int)v;
@@ -242,7 +242,8 @@ extern "C" int sd_ecapa(sd_ctx* c, const float* h_feats, const float* h_lens, in
 // bytes of the data chunk that are really in the file.  A wav written to a pipe (ffmpeg, sox) announces 0xFFFFFFFF (or 0) because the
 // writer could not seek back; the reference trusts the header (wav.h:92-97) and would "read" two billion samples from a short file.
 // Deliberate deviation, input robustness only: what is announced beyond the end of the file is not read, and a size of
-// 0 / 0xFFFFFFFF means "up to the end of the file".
+// 0xFFFFFFFF means "up to the end of the file"; so does 0, unless what follows the empty data chunk is a well-formed chain of RIFF
+// sub-chunks (LIST, id3 ...) -- then the file really has no samples, as the reference reads it.
 static uint32_t data_bytes_present(FILE* fp, uint32_t announced)
 {
     const long cur = ftell(fp);
@@ -251,35 +252,65 @@ static uint32_t data_bytes_present(FILE* fp, uint32_t announced)
     (void)fseek(fp, cur, SEEK_SET);
     if (end < cur) return announced;
     const uint64_t remaining = (uint64_t)(end - cur);
-    if (announced == 0xFFFFFFFFu || announced == 0 || (uint64_t)announced > remaining) return (uint32_t)(remaining > 0xFFFFFFFEull ? 0xFFFFFFFEull : remaining);
+    const uint32_t to_end = (uint32_t)(remaining > 0xFFFFFFFEull ? 0xFFFFFFFEull : remaining);
+    if (announced == 0xFFFFFFFFu || (uint64_t)announced > remaining) return to_end;
+    if (announced == 0 && remaining > 0) {
+        // 0 is what some stream writers leave -- but also what a well-formed file with an EMPTY data chunk followed by LIST / id3
+        // metadata says (the reference reads 0 samples there).  Stream rule only when what follows is NOT a chain of RIFF sub-chunks
+        // that ends exactly at the end of the file.
+        long pos = cur;
+        bool chain = true;
+        while (pos < end) {
+            unsigned char t8[8];
+            if (end - pos < 8 || fseek(fp, pos, SEEK_SET) != 0 || fread(t8, 1, 8, fp) != 8) { chain = false; break; }
+            for (int q = 0; q < 4; ++q) if (t8[q] < 0x20 || t8[q] > 0x7e) chain = false;
+            uint32_t sz; memcpy(&sz, t8 + 4, 4);
+            if (!chain || (uint64_t)sz > (uint64_t)(end - pos - 8)) { chain = false; break; }
+            pos += 8 + (long)sz;
+            if (pos < end && (sz & 1) && end - pos >= 1) pos += 1;      // RIFF pad byte
+        }
+        (void)fseek(fp, cur, SEEK_SET);
+        return chain ? 0u : to_end;
+    }
     return announced;
+}
+
+// The header walk both readers share (wav.h:62-90): the 44-byte canonical header, a longer fmt chunk (75-79), LIST / fact / ...
+// sub-chunks in front of the data (85-90).  On success the file is positioned on the first data byte and *dsz holds the bytes of
+// data really present.  Returns nullptr (file closed) when the file cannot be opened or ends inside its headers.
+static FILE* wav_open_data(const char* path, uint32_t* sr, uint16_t* ch, uint16_t* bits, uint32_t* dsz)
+{
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return nullptr;                          // reference ignores this (wav.h:60) and crashes later
+    unsigned char h[44];
+    if (fread(h, 1, 44, fp) != 44) { fclose(fp); return nullptr; }
+    uint32_t fmt_size; char tag[4];
+    memcpy(&fmt_size, h + 16, 4); memcpy(ch, h + 22, 2); memcpy(sr, h + 24, 4); memcpy(bits, h + 34, 2);
+    memcpy(tag, h + 36, 4); memcpy(dsz, h + 40, 4);
+    if (fmt_size < 16) { fclose(fp); return nullptr; }
+    unsigned char t8[8];
+    if (fmt_size > 16) {                               // wav.h:75-79
+        fseek(fp, 44 - 8 + (long)fmt_size - 16, SEEK_SET);
+        if (fread(t8, 1, 8, fp) != 8) { fclose(fp); return nullptr; }
+        memcpy(tag, t8, 4); memcpy(dsz, t8 + 4, 4);
+    }
+    while (strncmp(tag, "data", 4) != 0) {             // wav.h:85-90 skip LIST/fact chunks
+        fseek(fp, (long)*dsz, SEEK_CUR);
+        if (fread(t8, 1, 8, fp) != 8) { fclose(fp); return nullptr; }
+        memcpy(tag, t8, 4); memcpy(dsz, t8 + 4, 4);
+    }
+    *dsz = data_bytes_present(fp, *dsz);
+    return fp;
 }
 
 extern "C" int sd_read_wav(const char* path, int16_t** pcm, int64_t* n, int32_t* sample_rate, int32_t* channels)
 {
     if (!path || !pcm || !n) return SD_ERR_ARG;
     *pcm = nullptr; *n = 0;
-    FILE* fp = fopen(path, "rb");
-    if (!fp) return SD_ERR_ARG;                       // reference ignores this (wav.h:60) and crashes later
-    unsigned char h[44];
-    if (fread(h, 1, 44, fp) != 44) { fclose(fp); return SD_ERR_ARG; }
-    uint32_t fmt_size, sr, dsz; uint16_t ch, bits; char tag[4];
-    memcpy(&fmt_size, h + 16, 4); memcpy(&ch, h + 22, 2); memcpy(&sr, h + 24, 4); memcpy(&bits, h + 34, 2);
-    memcpy(tag, h + 36, 4); memcpy(&dsz, h + 40, 4);
-    if (fmt_size < 16) { fclose(fp); return SD_ERR_ARG; }
-    unsigned char t8[8];
-    if (fmt_size > 16) {                               // wav.h:75-79
-        fseek(fp, 44 - 8 + (long)fmt_size - 16, SEEK_SET);
-        if (fread(t8, 1, 8, fp) != 8) { fclose(fp); return SD_ERR_ARG; }
-        memcpy(tag, t8, 4); memcpy(&dsz, t8 + 4, 4);
-    }
-    while (strncmp(tag, "data", 4) != 0) {             // wav.h:85-90 skip LIST/fact chunks
-        fseek(fp, (long)dsz, SEEK_CUR);
-        if (fread(t8, 1, 8, fp) != 8) { fclose(fp); return SD_ERR_ARG; }
-        memcpy(tag, t8, 4); memcpy(&dsz, t8 + 4, 4);
-    }
+    uint32_t sr, dsz; uint16_t ch, bits;
+    FILE* fp = wav_open_data(path, &sr, &ch, &bits, &dsz);
+    if (!fp) return SD_ERR_ARG;
     if (bits != 16) { fclose(fp); return SD_ERR_ARG; } // README.md:37: 16 kHz / mono / 16 bit only
-    dsz = data_bytes_present(fp, dsz);
     int64_t num = dsz / 2;
     int16_t* buf = (int16_t*)malloc((size_t)(num > 0 ? num : 1) * sizeof(int16_t));
     int64_t got = (int64_t)fread(buf, 2, (size_t)num, fp);
@@ -307,28 +338,11 @@ extern "C" int sd_read_wav_f32(const char* path, float** wav, int64_t* n, int32_
 {
     if (!path || !wav || !n) return SD_ERR_ARG;
     *wav = nullptr; *n = 0;
-    FILE* fp = fopen(path, "rb");
+    uint32_t sr, dsz; uint16_t ch, bits;
+    FILE* fp = wav_open_data(path, &sr, &ch, &bits, &dsz);
     if (!fp) return SD_ERR_ARG;
-    unsigned char h[44];
-    if (fread(h, 1, 44, fp) != 44) { fclose(fp); return SD_ERR_ARG; }
-    uint32_t fmt_size, sr, dsz; uint16_t ch, bits; char tag[4];
-    memcpy(&fmt_size, h + 16, 4); memcpy(&ch, h + 22, 2); memcpy(&sr, h + 24, 4); memcpy(&bits, h + 34, 2);
-    memcpy(tag, h + 36, 4); memcpy(&dsz, h + 40, 4);
-    if (fmt_size < 16) { fclose(fp); return SD_ERR_ARG; }
-    unsigned char t8[8];
-    if (fmt_size > 16) {
-        fseek(fp, 44 - 8 + (long)fmt_size - 16, SEEK_SET);
-        if (fread(t8, 1, 8, fp) != 8) { fclose(fp); return SD_ERR_ARG; }
-        memcpy(tag, t8, 4); memcpy(&dsz, t8 + 4, 4);
-    }
-    while (strncmp(tag, "data", 4) != 0) {
-        fseek(fp, (long)dsz, SEEK_CUR);
-        if (fread(t8, 1, 8, fp) != 8) { fclose(fp); return SD_ERR_ARG; }
-        memcpy(tag, t8, 4); memcpy(&dsz, t8 + 4, 4);
-    }
     if (bits != 8 && bits != 16 && bits != 32) { fclose(fp); return SD_ERR_ARG; }     // reference: exit(1), wav.h:119-121
     const int bps = bits / 8;
-    dsz = data_bytes_present(fp, dsz);
     const int64_t num = dsz / bps;
     std::vector<unsigned char> raw((size_t)(num > 0 ? num * bps : 1));
     const size_t got = fread(raw.data(), 1, (size_t)num * bps, fp);

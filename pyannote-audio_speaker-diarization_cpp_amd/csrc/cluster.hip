@@ -1273,7 +1273,10 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     if (!why) return SD_OK;
     c->stats["linkage_fallbacks"].launches += 1;
     if (c->profile_detail) fprintf(stderr, "linkage: %s at N = %lld -> k_linkage_heap\n", why, (long long)N);
-    WS(c, double, Dh, "cl_D", m);                          // the heap kernel works on the condensed matrix
+    // the heap kernel works on the condensed matrix; the square one (up to 170 GB) is given back first, so that the fallback -- exact
+    // ties are its designed trigger -- also fits right below the auto-square limit (the stream is idle: it was synchronised above)
+    { auto it = c->ws.find("cl_Dsq"); if (it != c->ws.end()) it->second.release(); }
+    WS(c, double, Dh, "cl_D", m);
     if ((rc = linkage_prepare(c, d_X, N, d, Dh, size, cid, nb, md, md2))) return rc;
     return linkage_heap(c, N, Dh, size, cid, nb, md, d_Z);
 }

@@ -207,6 +207,7 @@ extern "C" int sd_diarize_sharded_dev(sd_ctx* c, const int16_t* d_pcm_shard, int
         const int64_t need_lo = mylo * SD_HOP;
         int64_t need_hi = (myhi - 1) * SD_HOP + SD_CHUNK; if (need_hi > n) need_hi = n;
         float* w = nullptr;
+        bool played = false;                          // virt: the per-rank loop was reached (every played rank then has its own record)
         auto local = [&]() -> int {
             if (!d_pcm_shard || first_sample < 0 || shard_samples < 0 || first_sample > need_lo || first_sample + shard_samples < need_hi)
                 SD_FAIL(c, SD_ERR_ARG, "rank %d: samples [%lld,%lld) do not cover chunks [%lld,%lld)", c->rank, (long long)first_sample,
@@ -218,6 +219,7 @@ extern "C" int sd_diarize_sharded_dev(sd_ctx* c, const int16_t* d_pcm_shard, int
             if (!virt) { if (c->inject_fail_rank == c->rank) SD_FAIL(c, SD_ERR_ARG, "rank %d: injected failure (option inject_fail_rank)", c->rank);
                          r = shard_infer(c, w, n, mylo, myhi, s_seg, s_emb); }
             else for (int q = 0; q < W; ++q) {
+                played = true;
                 int rq = SD_OK;
                 if (q == c->inject_fail_rank) rq = SD_ERR_ARG;            // the played rank q "fails": what the real rank 0 would see of it
                 else if (hi[(size_t)q] > lo[(size_t)q] && !r) rq = shard_infer(c, w, n, lo[(size_t)q], hi[(size_t)q], g_seg + (size_t)q * seg_slot, g_emb + (size_t)q * emb_slot);
@@ -229,6 +231,9 @@ extern "C" int sd_diarize_sharded_dev(sd_ctx* c, const int16_t* d_pcm_shard, int
         rc = local();
         c->wav_origin = 0;
         if (rc) my_err = c->err;
+        // a failure in front of the loop (samples that do not cover the chunks, pcm_to_wav) is every played rank's failure: without a
+        // record the digest would read sequence number 0 and report "rank 0 is in another job" instead of the real code and message
+        if (virt && rc && !played) for (int q = 0; q < W; ++q) record(q, rc);
     } else if (virt) for (int q = 0; q < W; ++q) record(q, SD_OK);
     if (!virt) record(0, rc);
     // ---- the exchange: always reached

@@ -315,7 +315,8 @@ bool eval_arith(const ONode& n, const std::vector<const OTensor*>& in, OTensor& 
         const int64_t ar = A.dims.size() == 2 ? A.dims[0] : 1, ac = A.dims.size() == 2 ? A.dims[1] : A.dims[0];
         const int64_t br = B.dims.size() == 2 ? B.dims[0] : B.dims[0], bc = B.dims.size() == 2 ? B.dims[1] : 1;
         const int64_t M = tA ? ac : ar, K = tA ? ar : ac, K2 = tB ? bc : br, Nn = tB ? br : bc;
-        if (K != K2 || M <= 0 || Nn <= 0 || K <= 0 || M > LIM / Nn) return false;
+        if (K != K2 || M <= 0 || Nn <= 0 || K <= 0 || M > LIM / Nn || M * Nn > LIM / K) return false;      // bounds the work (M N K), not only the output
+        if (numel(A) != ar * ac || numel(B) != br * bc) return false;
         y.dtype = 1; y.f.assign((size_t)(M * Nn), 0.0f);
         if (A.dims.size() == 2 && B.dims.size() == 2) y.dims = {M, Nn}; else if (A.dims.size() == 1 && B.dims.size() == 2) y.dims = {Nn}; else if (A.dims.size() == 2) y.dims = {M}; else y.dims = {};
         for (int64_t i = 0; i < M; ++i)
@@ -325,8 +326,11 @@ bool eval_arith(const ONode& n, const std::vector<const OTensor*>& in, OTensor& 
                 y.f[(size_t)(i * Nn + j)] = alpha * acc;
             }
         if (op == "Gemm" && in.size() > 2 && in[2]) {
-            std::vector<const OTensor*> two = {in[2]};
-            std::vector<int64_t> od = {M, Nn}, idx(2, 0);
+            // C is unidirectionally broadcast to [M, N]: rank <= 2, every dim 1 or the target's, and it must hold what its dims say
+            OTensor tgt; tgt.dims = {M, Nn};
+            std::vector<const OTensor*> two = {in[2], &tgt};
+            std::vector<int64_t> od, idx(2, 0);
+            if (in[2]->dims.size() > 2 || numel(*in[2]) <= 0 || !broadcast_dims(two, od) || od.size() != 2 || od[0] != M || od[1] != Nn) return false;
             for (int64_t k = 0; k < M * Nn; ++k) { y.f[(size_t)k] += beta * (float)getv(*in[2], bc_offset(*in[2], od, idx)); if (++idx[1] == Nn) { idx[1] = 0; ++idx[0]; } }
         }
         return true;
@@ -349,6 +353,7 @@ bool eval_arith(const ONode& n, const std::vector<const OTensor*>& in, OTensor& 
     }
     if (op == "Range") {
         if (in.size() < 3 || !in[0] || !in[1] || !in[2]) return false;
+        for (int q = 0; q < 3; ++q) if (numel(*in[q]) != 1) return false;      // scalars (a dims = {0} tensor is sane but empty)
         const double st = getv(*in[0], 0), lim = getv(*in[1], 0), dl = getv(*in[2], 0);
         if (dl == 0.0) return false;
         const double cnt = std::ceil((lim - st) / dl);

@@ -575,6 +575,13 @@ def test_onnx_reader_under_address_and_ub_sanitizers(onnx_files, weights, tmp_pa
         "squeeze_oob": ([_node(b"Squeeze", [b"x", b"ax"], [b"y"])], [x, _tensor(b"ax", [1], ints=[7])]),
         "slice_oob": ([_node(b"Slice", [b"x", b"st", b"en", b"ax"], [b"y"])],
                       [x, _tensor(b"st", [1], ints=[-100]), _tensor(b"en", [1], ints=[1 << 40]), _tensor(b"ax", [1], ints=[9])]),
+        # round-3 advisor findings in the arithmetic evaluator: Range on an EMPTY (dims = {0}) operand, Gemm with a rank-3 C and with a C
+        # that does not broadcast to [M, N]
+        "range_empty": ([_node(b"Range", [b"e", b"lim", b"dl"], [b"y"])], [_tensor(b"e", [0], ints=[]), _tensor(b"lim", [], ints=[5]), _tensor(b"dl", [], ints=[1])]),
+        "range_empty_f": ([_node(b"Range", [b"st", b"lim", b"e"], [b"y"])], [_tensor(b"st", [], floats=[0.0]), _tensor(b"lim", [], floats=[5.0]), _tensor(b"e", [0], floats=[])]),
+        "gemm_c_rank3": ([_node(b"Gemm", [b"x", b"w", b"c"], [b"y"])], [x, _tensor(b"w", [3, 2], floats=np.arange(6)), _tensor(b"c", [1, 1, 2], floats=np.arange(2))]),
+        "gemm_c_no_bcast": ([_node(b"Gemm", [b"x", b"w", b"c"], [b"y"])], [x, _tensor(b"w", [3, 3], floats=np.arange(9)), _tensor(b"c", [2], floats=np.arange(2))]),
+        "gemm_c_ok": ([_node(b"Gemm", [b"x", b"w", b"c"], [b"y"])], [x, _tensor(b"w", [3, 3], floats=np.arange(9)), _tensor(b"c", [3], floats=np.arange(3))]),
     }
     paths = []
     for k, (n, i) in graphs.items():
