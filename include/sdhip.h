@@ -164,6 +164,27 @@ void sd_free_pcm(int16_t*);
 int sd_read_wav_f32(const char* path, float** wav, int64_t* n, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample);
 void sd_free_wav(float*);
 int sd_diarize_f32(sd_ctx*, const float* h_wav, int64_t n, sd_turn** turns, int64_t* n_turns);
+/* ---- the resample leg of SURVEY 8(f) row 2: Resampler::Resample (frontend/resampler.cc:19-36 = libsamplerate 0.2.2 src_simple,
+ * SRC_SINC_BEST_QUALITY; dormant in the reference, which reads `sample_rate` and ignores it, sd.cpp:2940-2942).  Mono float samples at
+ * in_sr -> out_sr on the GPU (k_resample: exact polyphase band-limited sinc interpolation, 64 zero crossings per wing, cutoff 0.95 of
+ * the lower Nyquist frequency, Kaiser 100 dB; csrc/resample.hip states what is and is not comparable with libsamplerate).
+ * sd_resample_len = the reference's output length, (size_t)(n * ratio) with both factors in float (resampler.cc:21-22).
+ * out == NULL: only *n_out is set. */
+int64_t sd_resample_len(int64_t n, int32_t in_sr, int32_t out_sr);
+int sd_resample(sd_ctx*, const float* wav, int64_t n, int32_t in_sr, int32_t out_sr, float* out, int64_t cap, int64_t* n_out);
+/* ---- the head of speakerDiarization() (sd.cpp:2937-2951: WavReader, / 32768) in one call, with the input checks the reference
+ * lacks (README.md:37 asks for 16 kHz / mono / 16-bit and nothing validates it).  flags = 0: a file whose sample rate is not 16 000 is
+ * REFUSED with SD_ERR_ARG (the reference would process it as if it were 16 kHz); channels are read interleaved as the reference
+ * does (wav.h:95-97).  SD_WAV_RESAMPLE: other rates go through sd_resample first.  SD_WAV_DOWNMIX: channels are averaged first. */
+/* ---- the reference's WRITE_DATA switch (debugWrite / debugWrite2d / debugWrite3d, sd.cpp:62-234 and their call sites): with a directory
+ * set, every following whole-path call (sd_diarize*, sd_finalize_dev) writes DIR/cpp_<item>.txt for the items of
+ * pipeline/script/verifyEveryStepResult.py:6-17 in the reference's text format -- DIR = "/tmp" is what that script reads.  level 1: all
+ * items but the two 15 - 25 MB-per-batch ones; level 2: + imasks<n>, batch_waveform<n>; level 0 / dir NULL: off.  csrc/stepdump.cpp says
+ * which files are GPU tensors written as they are and which are views derived from them. */
+int sd_set_dump_dir(sd_ctx*, const char* dir, int level);
+#define SD_WAV_RESAMPLE 1
+#define SD_WAV_DOWNMIX 2
+int sd_diarize_wav(sd_ctx*, const char* path, int flags, sd_turn** turns, int64_t* n_turns);
 /* ---- output formats (the reference prints raw cluster ids to stdout only, sd.cpp:3433-3441) */
 /* RTTM file of the turns ("SPEAKER <uri> 1 <start> <dur> <NA> <NA> SPEAKER_kk <NA> <conf|NA>") */
 int sd_write_rttm(const char* path, const char* uri, const sd_turn* turns, int64_t n_turns);

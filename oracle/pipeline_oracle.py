@@ -7,12 +7,15 @@ from . import nn_oracle as nn
 from . import orc
 
 
-def diarize_ref(pcm, ws, we, seg_override=None, emb_override=None, return_all=False, planted=None):
+def diarize_ref(pcm, ws, we, seg_override=None, emb_override=None, return_all=False, planted=None, wav=None):
     """pcm int16 [n] -> list of (start, end, label) sorted by start.
     seg_override / emb_override let a test inject the GPU's network outputs so the non-neural
-    stages can be compared bit-for-bit.  planted = (scores, emb) mirrors sd_set_planted: both networks run (so a timing
+    stages can be compared bit-for-bit.  wav = float samples already divided by 32768 (pcm is then ignored).  planted = (scores, emb) mirrors sd_set_planted: both networks run (so a timing
     includes them), then their outputs are replaced exactly as the library does it (NaN rows by rule are kept)."""
-    wav = (pcm.astype(np.float32) * np.float32(1.0)) / np.float32(32768.0)      # sd.cpp:2950
+    if wav is None:
+        wav = (pcm.astype(np.float32) * np.float32(1.0)) / np.float32(32768.0)  # sd.cpp:2950
+    else:
+        wav = np.ascontiguousarray(wav, np.float32)                             # 8 / 32-bit files: samples as the reader + sd.cpp:2950 leave them
     n = len(wav)
     nc, last_len = orc.num_chunks(n)
     if nc == 0:

@@ -32,7 +32,7 @@ r() { sed -n "$1,$2p" "$SD"; }
   echo '};'
   r 2044 2432                  # class Cluster, frame constants
   # getEmbedding's wav_lens rule (sd.cpp:2466-2510) between the two Helper calls and em.infer()
-  echo 'static std::vector<std::vector<double>> ref_wav_lens_block( const std::vector<std::vector<bool>>& imasks, size_t batch_size, std::vector<float>& out_lens, std::vector<bool>& out_short ) {'
+  echo 'static std::vector<std::vector<double>> ref_wav_lens_block( const std::vector<std::vector<bool>>& imasks, size_t batch_size, std::vector<float>& out_lens, std::vector<bool>& out_short, int number = 0 ) {'
   r 2466 2510
   echo '  out_lens = wav_lens; out_short = too_short; return std::vector<std::vector<double>>(); }'
   r 2563 2935                  # crop_segment, to_diarization, max_segmentation_cluster, reconstruct, to_annotation

@@ -1527,6 +1527,8 @@ int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector
     hard.assign((size_t)M, 0);
     if (soft_best) soft_best->assign((size_t)M, NAN);
     if (Kout) *Kout = 1;
+    const bool dumping = !c->dump_dir.empty();
+    c->stash.clustered = false;
     if (M <= 0) return SD_OK;
     // a10: rows whose first element is not NaN (sd.cpp:2224)
     std::vector<double> first((size_t)M);
@@ -1560,6 +1562,7 @@ int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector
     if (rc) return rc;
     int nl = 0;
     for (auto& v : lab) { v -= 1; if (v + 1 > nl) nl = v + 1; }
+    if (dumping) c->stash.clusters = lab;
     // a11: size split
     size_t mcs = std::min<size_t>(15, std::max<size_t>(1, (size_t)std::round(0.1 * (double)N)));     // sd.cpp:2308
     std::vector<int> order, off;
@@ -1634,7 +1637,7 @@ int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector
     const bool constrained_assign = c->constrained_assignment && (M % SD_SPEAKERS) == 0;
     // the full [M][K] score table only for the constrained assignment (it needs every score); the confidence needs the best score alone
     double* d_soft = nullptr; double* d_best = nullptr;
-    if (constrained_assign) { WS(c, double, t_soft, "cl_soft", (size_t)M * nl); d_soft = t_soft; }
+    if (constrained_assign || dumping) { WS(c, double, t_soft, "cl_soft", (size_t)M * nl); d_soft = t_soft; }
     if (constrained_assign || soft_best) { WS(c, double, t_best, "cl_best", M); d_best = t_best; }
     hipLaunchKernelGGL(k_assign, dim3((unsigned)M), dim3(64), 0, c->stream, d_emb, M, d, d_cen2, nl, d_hard, d_err, d_soft, d_best);
     KCHECK(c);
@@ -1662,5 +1665,14 @@ int run_clustering(sd_ctx* c, const double* d_emb, int64_t M, int d, std::vector
             for (int64_t i = 0; i < M; ++i) (*soft_best)[(size_t)i] = hard[(size_t)i] >= 0 ? hs[(size_t)i * nl + hard[(size_t)i]] : NAN;
     }
     if (Kout) *Kout = nl;
+    if (dumping) {
+        StepStash& S = c->stash;
+        S.clustered = true; S.N = N; S.K = nl; S.cluster_res = lab; S.hard_pre = hard;
+        S.X.resize((size_t)N * d); S.Xn.resize((size_t)N * d); S.soft.resize((size_t)M * nl);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(S.X.data(), X, S.X.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(S.Xn.data(), Xn, S.Xn.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(S.soft.data(), d_soft, S.soft.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return SD_OK;
 }

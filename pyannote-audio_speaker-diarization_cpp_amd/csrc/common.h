@@ -108,6 +108,16 @@ struct SegWeights {
     float* cls_w = nullptr; float* cls_b = nullptr;   // [3][128], [3]
 };
 
+// results kept for the step dumps (stepdump.cpp); filled only while dump_dir is set
+struct StepStash {
+    bool clustered = false;                    // run_clustering went past the "fewer than two rows" exit
+    int64_t N = 0; int K = 0;
+    std::vector<int> clusters, cluster_res, hard_pre;   // fcluster labels - 1, labels after the small -> large pass, [M] assignment before the inactive rule
+    std::vector<double> X, Xn, soft;           // [N][d] filtered rows, the same normalised, [M][K] scores 2 - cosine distance
+    int64_t ar0 = 0, cr0 = 0, rows = 0, crow_all = 0, nact = 0;   // to_diarization's crop ranges
+    int64_t infer_items = 0;                   // items of the last shard_infer call (masks / counts workspaces describe them)
+};
+
 struct sd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -154,6 +164,9 @@ struct sd_ctx {
     int64_t job_seq = 0;                        // sharded jobs since sd_comm_init (travels in the status record: ranks in different jobs are detected)
     int inject_fail_rank = -1;                  // test hook: this rank (a played rank under virtual_world) reports SD_ERR_ARG instead of inferring
     int rank0_permille = -1;                    // share of the chunks rank 0 infers itself (it also finalizes); -1 = equal shares
+    std::string dump_dir;                       // sd_set_dump_dir: the next finalize writes the reference's WRITE_DATA items there
+    int dump_level = 0;
+    StepStash stash;
     const float* planted_scores = nullptr;      // sd_set_planted: measurement / test hook
     const float* planted_emb = nullptr;
     int64_t planted_lo = 0, planted_n = 0;
@@ -222,7 +235,9 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
 int run_segment(sd_ctx* c, const float* d_wav, int64_t n, int64_t chunk_lo, int64_t chunk_hi, float* d_seg);
 // ---- postseg.hip
 int run_postseg(sd_ctx* c, const float* d_seg, int64_t chunks, uint8_t* d_bin, float* d_masks, int* d_nact);
-int run_count(sd_ctx* c, const uint8_t* d_bin, int64_t chunks, int32_t* d_count, int64_t n_count);
+int run_count(sd_ctx* c, const uint8_t* d_bin, int64_t chunks, int32_t* d_count, int64_t n_count, double* d_avg = nullptr);
+// ---- stepdump.cpp
+int write_step_dumps(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t chunks, int64_t n_samples, const std::vector<int>& hard_post, int K);
 int64_t count_frames_host(int64_t chunks);
 int sd_np_rint_host(double v);
 int64_t closest_frame_host(double w_start, double w_step, double w_dur, double t);

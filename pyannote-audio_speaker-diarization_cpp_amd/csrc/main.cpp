@@ -13,6 +13,12 @@
 //   --precision P   f32 (default: f32 MFMA, the reference's ORT precision) | f16 (fp16 ECAPA layers, BASELINE configs[4]) | x3 (f32 tensors, both
 //                   MFMA operands split into hi + lo fp16 halves in the ECAPA conv layers and PyanNet's LSTM: f32-grade results from the fp16 matrix
 //                   pipe) = sd_set_option "ecapa_precision" (+ "seg_precision" = 3 for x3)
+//   --resample      a wav whose sample rate is not 16 000 Hz is resampled on the GPU first (sd_resample; the dormant Resampler of the reference,
+//                   frontend/resampler.cc:19-36).  WITHOUT it such a file is refused: the reference reads the rate and ignores it (sd.cpp:2940-2942),
+//                   i.e. silently diarizes at the wrong speed
+//   --downmix       average the channels of a multi-channel wav first (default: the reference's interleaved read, wav.h:95-97)
+//   --dump-steps DIR [--dump-level 2]   the reference's WRITE_DATA switch: DIR/cpp_<item>.txt for the items of script/verifyEveryStepResult.py
+//                   (sd_set_dump_dir; DIR = /tmp is what that script reads); single-GPU runs
 //   --relabel       stdout / RTTM labels renumbered the way pyannote.audio names its output (the clusters that occur,
 //                   sorted by their string, become 0, 1, ... = SPEAKER_00, SPEAKER_01, ...); default = raw cluster ids (sd.cpp:3439)
 #include <cstdio>
@@ -25,7 +31,7 @@
 #include <unistd.h>
 #include "sdhip.h"
 
-struct Args { const char* seg = nullptr; const char* emb = nullptr; const char* wav = nullptr; const char* rttm = nullptr; int gpus = 1; bool relabel = false; int precision = 0; };
+struct Args { const char* seg = nullptr; const char* emb = nullptr; const char* wav = nullptr; const char* rttm = nullptr; int gpus = 1; bool relabel = false; int precision = 0; int wav_flags = 0; const char* dump_dir = nullptr; int dump_level = 1; };
 
 static void print_block(sd_ctx* ctx, sd_turn* turns, int64_t nt, const Args& a)
 {
@@ -46,21 +52,16 @@ static void print_block(sd_ctx* ctx, sd_turn* turns, int64_t nt, const Args& a)
 
 static int run_single(const Args& a)
 {
-    float* wav = nullptr; int64_t n = 0; int32_t sr = 0, ch = 0, bits = 0;
-    if (sd_read_wav_f32(a.wav, &wav, &n, &sr, &ch, &bits) != SD_OK) {         // 8 / 16 / 32-bit PCM like wav.h:99-122
-        fprintf(stderr, "cannot read PCM wav: %s\n", a.wav);
-        return 1;
-    }
     sd_ctx* ctx = sd_create(a.seg, a.emb, 0);
     if (!ctx) { fprintf(stderr, "sd_create failed: %s\n", sd_create_error()); return 1; }
     if (a.precision && sd_set_option(ctx, "ecapa_precision", a.precision) != SD_OK) { fprintf(stderr, "%s\n", sd_last_error(ctx)); return 1; }
     if (a.precision == 3 && sd_set_option(ctx, "seg_precision", 3) != SD_OK) { fprintf(stderr, "%s\n", sd_last_error(ctx)); return 1; }
+    if (a.dump_dir && sd_set_dump_dir(ctx, a.dump_dir, a.dump_level) != SD_OK) { fprintf(stderr, "%s\n", sd_last_error(ctx)); return 1; }
     sd_turn* turns = nullptr; int64_t nt = 0;
-    const int rc = sd_diarize_f32(ctx, wav, n, &turns, &nt);
+    const int rc = sd_diarize_wav(ctx, a.wav, a.wav_flags, &turns, &nt);      // 8 / 16 / 32-bit PCM like wav.h:99-122; rate and channels checked
     if (rc != SD_OK) { fprintf(stderr, "diarization failed (%d): %s\n", rc, sd_last_error(ctx)); return 1; }
     print_block(ctx, turns, nt, a);
     sd_free_turns(turns);
-    sd_free_wav(wav);
     sd_destroy(ctx);
     return 0;
 }
@@ -81,6 +82,11 @@ static int run_rank(const Args& a, int rank, int world, int id_rd, const std::ve
     int16_t* pcm = nullptr; int64_t n = 0; int32_t sr = 0, ch = 0;
     if (sd_read_wav(a.wav, &pcm, &n, &sr, &ch) != SD_OK) {
         fprintf(stderr, "rank %d: cannot read 16-bit PCM wav: %s (--gpus needs 16-bit samples)\n", rank, a.wav);
+        return 1;
+    }
+    if (sr != 16000 || a.wav_flags) {
+        fprintf(stderr, "rank %d: %s: %d Hz%s; --gpus shards a 16 kHz mono 16-bit recording as it is (resample / downmix it first: --resample and --downmix "
+                        "are single-GPU options)\n", rank, a.wav, sr, a.wav_flags ? ", --resample / --downmix given" : "");
         return 1;
     }
     sd_ctx* ctx = sd_create(a.seg, a.emb, rank);
@@ -127,6 +133,10 @@ int main(int argc, char* argv[])
         if (s == "--gpus" && i + 1 < argc) a.gpus = atoi(argv[++i]);
         else if (s == "--rttm" && i + 1 < argc) a.rttm = argv[++i];
         else if (s == "--relabel") a.relabel = true;
+        else if (s == "--dump-steps" && i + 1 < argc) a.dump_dir = argv[++i];
+        else if (s == "--dump-level" && i + 1 < argc) a.dump_level = atoi(argv[++i]);
+        else if (s == "--resample") a.wav_flags |= SD_WAV_RESAMPLE;
+        else if (s == "--downmix") a.wav_flags |= SD_WAV_DOWNMIX;
         else if (s == "--precision" && i + 1 < argc) {
             const std::string v(argv[++i]);
             if (v == "f32") a.precision = 0; else if (v == "f16") a.precision = 1; else if (v == "x3") a.precision = 3;

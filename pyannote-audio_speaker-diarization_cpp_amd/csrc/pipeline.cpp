@@ -205,6 +205,7 @@ int pcm_to_wav(sd_ctx* c, const int16_t* d_pcm, int64_t n, float** d_wav)
 int shard_infer(sd_ctx* c, const float* d_wav, int64_t n, int64_t lo, int64_t hi, float* d_seg, float* d_emb)
 {
     const int64_t nc = hi - lo;
+    c->stash.infer_items = nc > 0 ? nc * SD_SPEAKERS : 0;
     if (nc <= 0) return SD_OK;
     if ((lo * SD_SPEAKERS) % SD_EMB_BATCH != 0) SD_FAIL(c, SD_ERR_ARG, "shard start %lld must be a multiple of 32 chunks", (long long)lo);
     int rc;
@@ -243,7 +244,9 @@ int finalize(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t chunks, 
     WS(c, double, d_e64, "fin_e64", M * SD_EMB_DIM);
     WS(c, int, d_hard, "fin_hard", M);
     if ((rc = run_postseg(c, d_seg, chunks, d_bin, nullptr, d_nact))) return rc;
-    if ((rc = run_count(c, d_bin, chunks, d_count, nf))) return rc;
+    double* d_count_avg = nullptr;
+    if (!c->dump_dir.empty()) { WS(c, double, t_avg, "fin_count_avg", nf); d_count_avg = t_avg; }
+    if ((rc = run_count(c, d_bin, chunks, d_count, nf, d_count_avg))) return rc;
     hipLaunchKernelGGL(k_f32_to_f64, GRID1(M * SD_EMB_DIM), 0, c->stream, d_emb, d_e64, M * SD_EMB_DIM);
     KCHECK(c);
     std::vector<int> hard; int K = 1;
@@ -258,6 +261,7 @@ int finalize(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t chunks, 
     for (int h : hard) if (h > Kr) Kr = h;
     Kr += 1;                                                                  // sd.cpp:2803-2812
     if ((rc = run_reconstruct(c, d_seg, d_nact, d_hard, d_count, nf, chunks, n, Kr, v))) return rc;
+    if (!c->dump_dir.empty() && (rc = write_step_dumps(c, d_seg, d_emb, chunks, n, hard, Kr))) return rc;
     // per-turn confidence: mean soft score (2 - cosine distance to the centroid, sd.cpp:2191-2207) of the
     // (chunk, local speaker) items assigned to the turn's cluster whose 5 s chunk [0.5 c, 0.5 c + 5) overlaps the turn
     { KernelStat& ks = c->stats["clusters_K"]; ks.launches++; ks.flops += (double)Kr; ks.bytes += (double)v.size(); }       // bench: K and turns per job
@@ -368,6 +372,52 @@ extern "C" int sd_diarize_f32(sd_ctx* c, const float* h_wav, int64_t n, sd_turn*
     if ((rc = shard_infer(c, d_wav, n, 0, chunks, d_seg, d_emb))) return rc;
     std::vector<sd_turn> v;
     if ((rc = finalize(c, d_seg, d_emb, chunks, n, v))) return rc;
+    c->stage_ms[3] = now_ms() - t0;
+    return turns_out(c, v, turns, n_turns);
+}
+
+// ------------------------------------------------------------------ wav file entry: reader + rate / channel handling + the path
+int resample_dev(sd_ctx* c, const float* d_in, int64_t n, int32_t in_sr, int32_t out_sr, float* d_out, int64_t n_out);   // resample.hip
+
+extern "C" int sd_diarize_wav(sd_ctx* c, const char* path, int flags, sd_turn** turns, int64_t* n_turns)
+{
+    ENTER(c);
+    if (!path || !turns || !n_turns || (flags & ~(SD_WAV_RESAMPLE | SD_WAV_DOWNMIX))) SD_FAIL(c, SD_ERR_ARG, "sd_diarize_wav: bad argument");
+    *turns = nullptr; *n_turns = 0;
+    float* wav = nullptr; int64_t n = 0; int32_t sr = 0, ch = 0, bits = 0;
+    if (sd_read_wav_f32(path, &wav, &n, &sr, &ch, &bits) != SD_OK) SD_FAIL(c, SD_ERR_ARG, "cannot read PCM wav: %s", path);
+    struct Free { float* p; ~Free() { sd_free_wav(p); } } guard{wav};
+    if (ch > 1 && (flags & SD_WAV_DOWNMIX)) {
+        // the buffer holds all n * ch interleaved samples (the reference keeps the first n of them as "mono", wav.h:95-97)
+        for (int64_t i = 0; i < n; ++i) {
+            float s = 0.0f;
+            for (int q = 0; q < ch; ++q) s += wav[i * ch + q];
+            wav[i] = s / (float)ch;
+        }
+    }
+    if (sr == 16000) return sd_diarize_f32(c, wav, n, turns, n_turns);
+    if (!(flags & SD_WAV_RESAMPLE))
+        SD_FAIL(c, SD_ERR_ARG, "%s: sample rate %d Hz; the pipeline needs 16000 (README.md:37 of the reference, which would process the file as if it "
+                               "were 16 kHz) -- pass SD_WAV_RESAMPLE / --resample", path, sr);
+    if (n <= 0) SD_FAIL(c, SD_ERR_SHORT, "%s holds no samples", path);
+    const double t0 = now_ms();
+    const int64_t no = sd_resample_len(n, sr, 16000);
+    if (no <= 0) SD_FAIL(c, SD_ERR_SHORT, "%s: %lld samples at %d Hz give no 16 kHz sample", path, (long long)n, sr);
+    const int64_t chunks = sd_num_chunks(no, nullptr);
+    if (chunks <= 0) SD_FAIL(c, SD_ERR_SHORT, "audio of %lld samples yields no chunk", (long long)no);
+    for (int i = 0; i < 4; ++i) c->stage_ms[i] = 0;
+    WS(c, float, d_in, "rs_in", n);
+    WS(c, float, d_wav, "wav_f32", no + 512);
+    HIPCHK(c, hipMemcpyAsync(d_in, wav, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_wav + no, 0, 512 * sizeof(float), c->stream));
+    int rc;
+    if ((rc = resample_dev(c, d_in, n, sr, 16000, d_wav, no))) return rc;
+    c->wav_padded = true;
+    WS(c, float, d_seg, "dz_seg", chunks * SD_FRAMES * 3);
+    WS(c, float, d_emb, "dz_emb", chunks * 3 * SD_EMB_DIM);
+    if ((rc = shard_infer(c, d_wav, no, 0, chunks, d_seg, d_emb))) return rc;
+    std::vector<sd_turn> v;
+    if ((rc = finalize(c, d_seg, d_emb, chunks, no, v))) return rc;
     c->stage_ms[3] = now_ms() - t0;
     return turns_out(c, v, turns, n_turns);
 }

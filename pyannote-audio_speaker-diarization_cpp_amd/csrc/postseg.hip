@@ -96,7 +96,7 @@ __device__ __forceinline__ int dev_np_rint(double val)
 }
 
 __global__ void k_count(const uint8_t* __restrict__ bin, const int* __restrict__ sfr, int64_t chunks, int nl, int Ft,
-                        int32_t* __restrict__ count, int64_t n_count)
+                        int32_t* __restrict__ count, int64_t n_count, double* __restrict__ avg)
 {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_count) return;
@@ -115,6 +115,7 @@ __global__ void k_count(const uint8_t* __restrict__ bin, const int* __restrict__
     double v = sum / fmax(cnt, DBL_EPSILON);                                  // sd.cpp:1288
     if (cnt == 0.0) v = 0.0;                                                  // missing = 0.0, sd.cpp:1302-1305, 1720
     count[f] = dev_np_rint(v);                                                // sd.cpp:1734
+    if (avg) avg[f] = v;                                                      // step dumps: count_data, the value in front of np_rint (sd.cpp:1723)
 }
 
 int run_postseg(sd_ctx* c, const float* d_seg, int64_t chunks, uint8_t* d_bin, float* d_masks, int* d_nact)
@@ -126,7 +127,7 @@ int run_postseg(sd_ctx* c, const float* d_seg, int64_t chunks, uint8_t* d_bin, f
     return SD_OK;
 }
 
-int run_count(sd_ctx* c, const uint8_t* d_bin, int64_t chunks, int32_t* d_count, int64_t n_count)
+int run_count(sd_ctx* c, const uint8_t* d_bin, int64_t chunks, int32_t* d_count, int64_t n_count, double* d_avg)
 {
     if (chunks <= 0 || n_count <= 0) return SD_OK;
     const int nl = (int)floor((double)SD_FRAMES * 0.1);                        // sd.cpp:1755
@@ -143,7 +144,7 @@ int run_count(sd_ctx* c, const uint8_t* d_bin, int64_t chunks, int32_t* d_count,
     HIPCHK(c, hipMemcpyAsync(d_sfr, sfr.data(), (size_t)chunks * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));     // sfr is a stack-lifetime host vector
     ProfScope ps(c, "count", 0, (double)n_count * 4.0 + (double)chunks * SD_FRAMES * 3);
-    hipLaunchKernelGGL(k_count, dim3((unsigned)((n_count + 255) / 256)), dim3(256), 0, c->stream, d_bin, d_sfr, chunks, nl, Ft, d_count, n_count);
+    hipLaunchKernelGGL(k_count, dim3((unsigned)((n_count + 255) / 256)), dim3(256), 0, c->stream, d_bin, d_sfr, chunks, nl, Ft, d_count, n_count, d_avg);
     KCHECK(c);
     return SD_OK;
 }

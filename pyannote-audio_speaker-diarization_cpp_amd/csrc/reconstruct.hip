@@ -145,6 +145,7 @@ int run_reconstruct(sd_ctx* c, const float* d_seg, const int* /*d_nact*/, const 
                     int64_t n_count, int64_t chunks, int64_t n_samples, int K, std::vector<sd_turn>& turns)
 {
     turns.clear();
+    c->stash.rows = 0;
     if (chunks <= 0 || K <= 0) return SD_OK;
     // activations grid: frames window (0.0, step, dur) (sd.cpp:1233), chunk windows (0.0, 0.5, 5.0)
     const double target = 0.0 + 5.0 + (double)(chunks - 1) * 0.5;
@@ -173,6 +174,7 @@ int run_reconstruct(sd_ctx* c, const float* d_seg, const int* /*d_nact*/, const 
     const int64_t rows = ar1 - ar0;
     int64_t crow = cr1 - cr0;
     if (rows <= 0) return SD_OK;                      // reference would index an empty vector here (sd.cpp:2735)
+    { StepStash& S = c->stash; S.ar0 = ar0; S.cr0 = cr0; S.rows = rows; S.crow_all = crow; S.nact = nact; }      // step dumps
     if (crow > rows) crow = rows;                     // reference asserts cropped_count.size() <= rows (sd.cpp:2745)
     WS(c, uint8_t, d_binary, "rc_binary", rows * K);
     {

@@ -37,7 +37,7 @@ EXPORTS = [
     "sd_reset_stats", "sd_set_option", "sd_bench_conv", "sd_bench_barrier", "sd_convert_onnx", "sd_convert_error", "sd_read_wav_f32", "sd_free_wav", "sd_diarize_f32",
     "sd_write_rttm", "sd_set_planted", "sd_comm_unique_id", "sd_comm_init", "sd_comm_destroy", "sd_comm_info", "sd_shard_plan",
     "sd_diarize_sharded", "sd_diarize_sharded_dev", "sd_write_rttm_ex", "sd_relabel_turns", "sd_relabel_turns_ex", "sd_last_confidence",
-    "sd_debug_read_ws", "sd_test_pack_split_weights",
+    "sd_debug_read_ws", "sd_test_pack_split_weights", "sd_resample", "sd_resample_len", "sd_diarize_wav", "sd_set_dump_dir",
 ]
 COMM_ID_BYTES = 128
 
@@ -61,6 +61,11 @@ def lib():
     L.sd_num_chunks.argtypes = [i64, C.POINTER(i64)]
     L.sd_count_frames.restype = i64
     L.sd_count_frames.argtypes = [i64]
+    L.sd_set_dump_dir.argtypes = [vp, C.c_char_p, C.c_int]
+    L.sd_resample_len.restype = i64
+    L.sd_resample_len.argtypes = [i64, i32, i32]
+    L.sd_resample.argtypes = [vp, vp, i64, i32, i32, vp, i64, C.POINTER(i64)]
+    L.sd_diarize_wav.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.POINTER(Turn)), C.POINTER(i64)]
     L.sd_segment.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
     L.sd_segment_dev.argtypes = [vp, vp, i64, vp, i64]
     L.sd_postseg.argtypes = [vp, vp, i64, vp, vp, vp, i64, C.POINTER(i64)]
@@ -362,6 +367,25 @@ class Diarizer:
         n = C.c_int64(0)
         self._chk(lib().sd_diarize_f32(self._h, _ptr(wav), len(wav), C.byref(p), C.byref(n)))
         return self._turns(p, n)
+
+    def set_dump_dir(self, path, level=1):
+        """sd_set_dump_dir: the reference's WRITE_DATA items as <path>/cpp_<item>.txt from the next whole-path call on (None = off)"""
+        self._chk(lib().sd_set_dump_dir(self._h, str(path).encode() if path else None, level if path else 0))
+
+    def diarize_wav(self, path, resample=False, downmix=False):
+        """sd_diarize_wav: reader + sample-rate / channel handling + the whole path (SD_WAV_RESAMPLE = 1, SD_WAV_DOWNMIX = 2)"""
+        p = C.POINTER(Turn)()
+        n = C.c_int64(0)
+        self._chk(lib().sd_diarize_wav(self._h, str(path).encode(), (1 if resample else 0) | (2 if downmix else 0), C.byref(p), C.byref(n)))
+        return self._turns(p, n)
+
+    def resample(self, wav, in_sr, out_sr=16000):
+        wav = np.ascontiguousarray(wav, np.float32)
+        no = C.c_int64(0)
+        self._chk(lib().sd_resample(self._h, _ptr(wav), len(wav), in_sr, out_sr, None, 0, C.byref(no)))
+        out = np.zeros(max(no.value, 1), np.float32)
+        self._chk(lib().sd_resample(self._h, _ptr(wav), len(wav), in_sr, out_sr, _ptr(out), len(out), C.byref(no)))
+        return out[:no.value]
 
     def diarize_dev(self, d_pcm_ptr, n_samples):
         p = C.POINTER(Turn)()

@@ -69,6 +69,27 @@ def test_wav_reader_streamed_and_truncated_headers(tmp_path):
         assert len(pcm) == n_expect and np.array_equal(pcm, s[:n_expect].astype(np.int16)), name
 
 
+def test_wav_reader_empty_data_chunk_followed_by_metadata_has_no_samples(tmp_path):
+    """a well-formed file whose data chunk is genuinely EMPTY and is followed by LIST / id3 sub-chunks: announced size 0 is then not the
+    stream writers' "unknown" -- the metadata must not be decoded as audio (round-3 advisor); the reference's own reader says 0 samples"""
+    head = _wav_bytes(np.zeros(0), 16, extra_chunk=False)                   # ... "data" + size 0
+    assert head.endswith(b"data" + struct.pack("<I", 0))
+    tail = b"LIST" + struct.pack("<I", 11) + b"INFOabcdefg" + b"\0" + b"id3 " + struct.pack("<I", 4) + b"wxyz"
+    p = tmp_path / "empty_then_list.wav"
+    p.write_bytes(head + tail)
+    w, sr, ch, b = sdhip.read_wav_f32(str(p))
+    assert len(w) == 0 and (sr, ch, b) == (16000, 1, 16)
+    assert len(sdhip.read_wav(str(p))[0]) == 0
+    r = orc.ref_wav_read(str(p))
+    if r is not None:
+        assert len(r[0]) == 0
+    # the same size field in front of raw samples (a stream writer's file) is still read to the end
+    s = (np.arange(500) * 37 % 9000 - 4500).astype(np.int64)
+    p2 = tmp_path / "stream_0.wav"
+    p2.write_bytes(head + s.astype(np.int16).tobytes())
+    assert np.array_equal(sdhip.read_wav(str(p2))[0], s.astype(np.int16))
+
+
 def test_wav_reader_errors(tmp_path):
     p = tmp_path / "bad.wav"
     p.write_bytes(_wav_bytes(np.zeros(10), 16)[:30])
@@ -198,6 +219,41 @@ def test_gpu_diarize_f32_equals_int16_path_and_cli_rttm(diarizer, weights, tmp_p
     assert out.returncode == 0, out.stderr
     turns = diarizer.diarize(pcm)
     assert len(rttm.read_text().splitlines()) == len(turns)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 32])
+def test_gpu_diarize_f32_on_8_and_32_bit_files_against_the_oracle(diarizer, weights, tmp_path, bits):
+    """f2 on the GPU against the ORACLE (not against sd_diarize): an 8-bit and a genuinely 32-bit file are read by the REFERENCE's own
+    WavReader (oracle/_ref/libref_wav.so; the C restatement where _ref is absent), scaled as sd.cpp:2950 does, and fed to
+    pipeline_oracle; sd_read_wav_f32 must deliver the same samples and sd_diarize_f32 the oracle's turns -- bit for bit behind the
+    networks, within +-1 frame against the oracle's own torch networks (north star)"""
+    import synth
+    from oracle import pipeline_oracle
+    pcm = synth.make_pcm(24.0, seed=13)
+    if bits == 8:
+        s = (pcm.astype(np.int64) >> 8).clip(-127, 127)                     # signed char, as wav.h:103-106 reads it
+    else:
+        s = pcm.astype(np.int64) * 37 + 11                                  # beyond the int16 range: +-1.2e6 -> samples up to +-37 after / 32768
+    p = tmp_path / ("a%d.wav" % bits)
+    p.write_bytes(_wav_bytes(s, bits, extra_chunk=True, fmt_extra=2 if bits == 32 else 0))
+    r = orc.ref_wav_read(str(p))
+    raw = r[0] if r is not None else None
+    w_ref = (raw * np.float32(1.0) / np.float32(32768.0)).astype(np.float32) if raw is not None else orc.read_wav(str(p))[0]
+    w, sr, ch, b = sdhip.read_wav_f32(str(p))
+    assert b == bits and np.array_equal(w, w_ref) and np.abs(w).max() > (5 if bits == 32 else 0.0005)
+    turns = diarizer.diarize_f32(w)
+    seg = diarizer.segment(w_ref)
+    masks = orc.select_masks(orc.binarize(seg))
+    emb = diarizer.embed(w_ref, masks)
+    t1 = pipeline_oracle.diarize_ref(None, weights[2], weights[3], seg_override=seg, emb_override=emb, wav=w_ref)
+    assert turns == t1 and len(turns) >= 1
+    t2 = pipeline_oracle.diarize_ref(None, weights[2], weights[3], wav=w_ref)
+    assert len(t2) == len(turns)
+    key = lambda t: (t[2], t[0])
+    for a, c in zip(sorted(turns, key=key), sorted(t2, key=key)):
+        assert a[2] == c[2] and abs(a[0] - c[0]) <= 0.016875 + 1e-9 and abs(a[1] - c[1]) <= 0.016875 + 1e-9
+    assert diarizer.diarize_wav(p) == turns                                 # the file entry point reads the same samples
 
 
 # ------------------------------------------------------------------ f4: relabelling, confidence, RTTM confidence column
