@@ -621,6 +621,41 @@ def main():
             extra_lines["fp16"] = secondary_mode(1, a.fp16_steps, "conv_w256_f16", "conv_gemm_f16", "k_conv_gemm_w256<1> (v_mfma_f32_32x32x16_f16)",
                                                  "BASELINE configs[4]: the same job with the per-frame ECAPA layers on the fp16 MFMA (fp16 weights and activations, f32 accumulation); "
                                                  "secondary mode, never the headline value", 1)
+        if a.precision == "f32" and a.fp16_steps > 0 and planted and "fp16" in extra_lines:
+            # BASELINE configs[4]'s tolerance on a network whose SE gates are NOT saturated: the same seeded conv weights with BatchNorm statistics learnt from one
+            # calibration batch (oracle/nn_oracle.calibrated_embedding_weights; the plain pack above is the stress case: BN = identity, gates pinned at 0 / 1)
+            try:
+                wc = nn.calibrated_embedding_weights(4322)
+                nn.save_pack(os.path.join(tmp, "embedding_cal.sdw"), wc)
+                d2 = sdhip.Diarizer(os.path.join(tmp, "segment.sdw"), os.path.join(tmp, "embedding_cal.sdw"), local)
+                d2.set_planted(d_ps.data_ptr(), 0, lo, hi - lo)
+                res = {}
+                embs = {}
+                for mode, name in ((0, "f32"), (1, "fp16"), (3, "x3")):
+                    d2.set_option("ecapa_precision", mode)
+                    tt = d2.diarize_dev(d_pcm.data_ptr(), n_total)
+                    gpu_sync()
+                    t1 = time.perf_counter()
+                    tt = d2.diarize_dev(d_pcm.data_ptr(), n_total)
+                    gpu_sync()
+                    res[name] = {"ms": round((time.perf_counter() - t1) * 1e3, 1), "turns": len(tt)}
+                    embs[name] = d2.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192).astype(np.float64)
+                    res[name]["_turns"] = tt
+                lv = ~np.isnan(embs["f32"][:, 0])
+                for name in ("fp16", "x3"):
+                    e = embs[name]
+                    cd = 1.0 - (e[lv] * embs["f32"][lv]).sum(1) / np.linalg.norm(e[lv], axis=1) / np.linalg.norm(embs["f32"][lv], axis=1)
+                    res[name]["cosine_distance_to_f32_embeddings"] = {"items": int(lv.sum()), "max": float("%.3g" % cd.max()), "q99": float("%.3g" % np.quantile(cd, 0.99)),
+                                                                      "median": float("%.3g" % np.median(cd)), "above_1e-3": int((cd > 1e-3).sum()),
+                                                                      "same_nan_rows": bool(np.array_equal(np.isnan(e[:, 0]), ~lv))}
+                    res[name]["same_turns_as_f32"] = res[name]["_turns"] == res["f32"]["_turns"]
+                for name in res:
+                    res[name].pop("_turns")
+                d2.close()
+                extra_lines["fp16"]["calibrated_pack"] = {"what": "the tolerance check of BASELINE configs[4] on the calibrated seeded pack (BatchNorm statistics from one calibration batch: SE gates "
+                                                                  "unsaturated as in a trained ECAPA; same conv weights): real embeddings of the planted masks, one warm job per mode", **res}
+            except Exception as e:
+                extra_lines["fp16"]["calibrated_pack"] = {"error": str(e)[:300]}
         if a.precision == "f32" and a.x3_steps > 0:
             extra_lines["x3"] = secondary_mode(3, a.x3_steps, "conv_w256_x3", "conv_gemm_x3", "k_conv_gemm_w256<3> (v_mfma_f32_32x32x16_f16 on split operands)",
                                                "options ecapa_precision = 3 + seg_precision = 3: f32 tensors in HBM as in the headline run; every ECAPA conv layer and PyanNet's LSTM (input "

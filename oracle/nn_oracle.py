@@ -218,3 +218,52 @@ def embed_ref(signals, wav_lens, w, dtype=torch.float32):
     st = stft_ref(signals, w.get("stft.window"))
     feats = fbank_norm_ref(st, wav_lens, w["fbank.matrix"], dtype)
     return EcapaOracle(w, dtype)(feats, wav_lens)
+
+
+# ---------------------------------------------------------------- calibrated seeded pack (BASELINE configs[4]'s tolerance check)
+class _CalibratingEcapa(EcapaOracle):
+    """EcapaOracle whose BatchNorms LEARN their running statistics from the batch that passes through (per channel, over the batch and
+    the valid frames), the way training leaves them in a real speechbrain ECAPA (embeddings/threeModel.py:140-232 loads such a model)."""
+
+    def __init__(self, w, lengths):
+        super().__init__(w)
+        self.len = torch.as_tensor(lengths, dtype=torch.float32)
+
+    def _bn(self, x, p):
+        L = x.shape[-1]
+        if L > 1:
+            m = self._mask(self.len, L, x.dtype)                                     # [B,1,L]
+            n = m.sum() + 1e-9
+            mean = (x * m).sum(dim=(0, 2)) / n
+            var = (((x - mean[None, :, None]) ** 2) * m).sum(dim=(0, 2)) / n
+        else:
+            mean, var = x.mean(dim=(0, 2)), x.var(dim=(0, 2), unbiased=False)
+        self.w[p + ".running_mean"] = mean.numpy().astype(np.float32)
+        self.w[p + ".running_var"] = np.maximum(var.numpy(), 1e-6).astype(np.float32)
+        self.w[p + ".weight"] = np.ones_like(self.w[p + ".weight"])
+        self.w[p + ".bias"] = np.zeros_like(self.w[p + ".bias"])
+        return super()._bn(x, p)
+
+
+@torch.no_grad()
+def calibrated_embedding_weights(seed=4322, items=16, audio_seed=777):
+    """The seeded synthetic ECAPA with every BatchNorm's running_mean / running_var set from ONE calibration batch (synthetic audio, full
+    and partial-length items), gamma = 1, beta = 0: post-BN activations are zero-mean / unit-variance per channel, so the SE gates'
+    pre-activations are O(1) and the gates unsaturated -- the regime of a trained model, where the plain seeded pack (BN = identity on
+    log-mel inputs of order 30) has pre-activations of order 100 and gates pinned at 0 / 1 (profiles/r03_fp16_error_by_layer.txt).
+    Same conv weights as synth_embedding_weights(seed): only the 31 BatchNorms change."""
+    import synth
+    w = {k: np.array(v, copy=True) for k, v in synth_embedding_weights(seed).items()}
+    pcm = synth.make_pcm(5.0 * items / 2 + 6.0, seed=audio_seed)
+    wav = pcm.astype(np.float32) / np.float32(32768.0)
+    rng = np.random.default_rng(audio_seed)
+    sig = np.zeros((items, 80000), np.float32)
+    lens = np.ones(items, np.float32)
+    for i in range(items):
+        s0 = int(rng.integers(0, len(wav) - 80000))
+        n = 80000 if i % 2 == 0 else int(rng.integers(16000, 80000))                # half the items are partial: zero tail, wav_len < 1
+        sig[i, :n] = wav[s0:s0 + n]
+        lens[i] = n / 80000.0
+    feats = fbank_norm_ref(stft_ref(sig, w.get("stft.window")), lens, w["fbank.matrix"])
+    _CalibratingEcapa(w, lens)(feats, lens)
+    return w

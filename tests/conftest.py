@@ -40,3 +40,23 @@ def diarizer(weights):
     d = sdhip.Diarizer(weights[0], weights[1])     # raises loudly when the HIP library / GPU is missing
     yield d
     d.close()
+
+
+@pytest.fixture(scope="session")
+def weights_calibrated(tmp_path_factory, weights):
+    """the same seeded networks with the ECAPA BatchNorm statistics learnt from one calibration batch (nn_oracle.calibrated_embedding_weights):
+    unsaturated SE gates, the regime of a trained model -- the pack BASELINE configs[4]'s tolerance is asserted on"""
+    from oracle import nn_oracle as nn
+    d = tmp_path_factory.mktemp("sdw_cal")
+    wc = nn.calibrated_embedding_weights()
+    ep = str(d / "embedding_cal.sdw")
+    nn.save_pack(ep, wc)
+    return weights[0], ep, weights[2], wc
+
+
+@pytest.fixture(scope="session")
+def diarizer_calibrated(weights_calibrated):
+    import sdhip
+    d = sdhip.Diarizer(weights_calibrated[0], weights_calibrated[1])
+    yield d
+    d.close()
