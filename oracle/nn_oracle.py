@@ -31,7 +31,7 @@ if _PKG not in sys.path:
     sys.path.insert(0, _PKG)
 # container + seeded weights are plain data shared with the product side; only the arithmetic below is the oracle
 from weightpack import (N_FFT, HOP, WIN, N_BINS, N_MELS, T_FRAMES, EMB_DIM, save_pack, load_pack, mel_matrix,  # noqa: E402,F401
-                        synth_segmentation_weights, synth_embedding_weights)
+                        synth_segmentation_weights, synth_embedding_weights, calibrated_embedding_weights)
 
 
 
@@ -246,8 +246,9 @@ class _CalibratingEcapa(EcapaOracle):
 
 
 @torch.no_grad()
-def calibrated_embedding_weights(seed=4322, items=16, audio_seed=777):
-    """The seeded synthetic ECAPA with every BatchNorm's running_mean / running_var set from ONE calibration batch (synthetic audio, full
+def calibrate_embedding_weights(seed=4322, items=16, audio_seed=777):
+    """COMPUTES the calibration (tools/mint_calibrated_bn.py stores its BatchNorm tensors as package data, weightpack.calibrated_embedding_weights
+    loads them; tests/test_planted.py checks the stored ones against a fresh run).  The seeded synthetic ECAPA with every BatchNorm's running_mean / running_var set from ONE calibration batch (synthetic audio, full
     and partial-length items), gamma = 1, beta = 0: post-BN activations are zero-mean / unit-variance per channel, so the SE gates'
     pre-activations are O(1) and the gates unsaturated -- the regime of a trained model, where the plain seeded pack (BN = identity on
     log-mel inputs of order 30) has pre-activations of order 100 and gates pinned at 0 / 1 (profiles/r03_fp16_error_by_layer.txt).

@@ -25,15 +25,23 @@ extern "C" sd_ctx* sd_create(const char* seg_path, const char* emb_path, int dev
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete c; return nullptr; }
     auto fail = [&](const std::string& m) { g_create_err = m; sd_destroy(c); return (sd_ctx*)nullptr; };
+    const bool trace = getenv("SD_TRACE_CREATE") != nullptr;          // where the start-up time goes (tools/cold_start.py)
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     if (seg_path && seg_path[0]) {
         Pack p; std::string e;
         if (load_model_any(seg_path, 0, p, e)) return fail(e);
+        const double t1 = now();
         if (build_seg_weights(c, p)) return fail(c->err);
+        if (trace) fprintf(stderr, "sd_create: segmentation model read %.1f ms, layouts + upload %.1f ms\n", t1 - t0, now() - t1);
     }
+    t0 = now();
     if (emb_path && emb_path[0]) {
         Pack p; std::string e;
         if (load_model_any(emb_path, 1, p, e)) return fail(e);
+        const double t1 = now();
         if (build_ecapa_weights(c, p)) return fail(c->err);
+        if (trace) fprintf(stderr, "sd_create: embedding model read %.1f ms, layouts + upload %.1f ms\n", t1 - t0, now() - t1);
     }
     c->err.clear();
     return c;
@@ -109,7 +117,10 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "conv_w256_kmin") c->conv_w256_kmin = (int)v;
     else if (k == "conv_pn128") c->conv_pn128 = (int)v;
     else if (k == "seg_precision") { if (v != 0 && v != 3) SD_FAIL(c, SD_ERR_ARG, "seg_precision must be 0 (f32) or 3 (split fp16 operands for the LSTM)"); c->seg_precision = (int)v; }
-    else if (k == "ecapa_precision") { if (v < 0 || v > 3) SD_FAIL(c, SD_ERR_ARG, "ecapa_precision must be 0 (f32), 1 (fp16), 2 (fp16, hi + lo weight planes) or 3 (f32 tensors, split fp16 operands on the wide layers)"); c->ecapa_precision = (int)v; }
+    else if (k == "ecapa_precision") { if (v < 0 || v > 3) SD_FAIL(c, SD_ERR_ARG, "ecapa_precision must be 0 (f32), 1 (fp16), 2 (fp16, hi + lo weight planes) or 3 (f32 tensors, split fp16 operands on the wide layers)");
+                                        if (hipSetDevice(c->device) != hipSuccess) SD_FAIL(c, SD_ERR_HIP, "hipSetDevice failed");
+                                        const int rcw = ensure_ecapa_mode_weights(c, (int)v); if (rcw) return rcw;      // fp16 weight forms: built on first use of the mode
+                                        c->ecapa_precision = (int)v; }
     else if (k == "ecapa_f16_hp") { if (v != 0 && v != 1 && v != 3) SD_FAIL(c, SD_ERR_ARG, "ecapa_f16_hp must be 0, 1 (MFA output in f32) or 3 (+ the attention branch)"); c->ecapa_f16_hp = (int)v; }
     else if (k == "ecapa_keep_cat") c->ecapa_keep_cat = v != 0;
     else if (k == "rank0_permille") c->rank0_permille = (int)v;

@@ -91,6 +91,10 @@ struct EcapaWeights {
     struct SERes { ConvLayer tdnn1, res[7], tdnn2, se1, se2; int dil; } blk[3];
     ConvLayer mfa, asp_tdnn_x, asp_tdnn_ms, asp_conv, fc;
     int C = 1024;
+    // the fp16 copies of the per-frame conv layers are built ON THE GPU from the f32 weights the first time a mode that reads them is
+    // selected (weights.cpp: ensure_ecapa_mode_weights): the default f32 mode pays nothing for them at start-up
+    std::vector<ConvLayer*> conv16;   // layers that have fp16 forms
+    bool have16 = false, have16x = false;
 };
 
 struct SegWeights {
@@ -125,6 +129,7 @@ struct sd_ctx {
     EcapaWeights ew;
     SegWeights sw;
     std::vector<void*> owned;                  // device allocations freed in sd_destroy
+    char* warena_cur = nullptr; size_t warena_left = 0;   // weights.cpp: bump allocator over 64 MB device blocks
     std::map<std::string, DevBuf> ws;          // named workspaces
     std::map<std::string, KernelStat> stats;
     bool profile = false;
@@ -210,6 +215,7 @@ int load_pack(const char* path, Pack& out, std::string& err);
 int load_model_any(const char* path, int kind, Pack& out, std::string& err);   // onnx_reader.cpp: .sdw pack or .onnx (kind 0 seg, 1 emb)
 int build_ecapa_weights(sd_ctx* c, const Pack& p);
 int build_seg_weights(sd_ctx* c, const Pack& p);
+int ensure_ecapa_mode_weights(sd_ctx* c, int ecapa_precision);   // builds W16 (modes 1, 2) / W16x (mode 3) on first use
 // ---- frontend.hip
 int frontend_prepare(sd_ctx* c, const float* d_masks, int64_t items, int64_t first_item, float* d_wav_lens, int* d_nnorm, int* d_nvalid,
                      int* d_flags, bool compact, int* h_n_active, int* d_cidx, std::vector<int>* h_nvalid = nullptr);

@@ -22,6 +22,7 @@
 //   --relabel       stdout / RTTM labels renumbered the way pyannote.audio names its output (the clusters that occur,
 //                   sorted by their string, become 0, 1, ... = SPEAKER_00, SPEAKER_01, ...); default = raw cluster ids (sd.cpp:3439)
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -50,19 +51,32 @@ static void print_block(sd_ctx* ctx, sd_turn* turns, int64_t nt, const Args& a)
     fflush(stdout);
 }
 
+static double wall_ms()
+{
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static const bool g_trace = getenv("SD_TRACE_CREATE") != nullptr;     // start-up breakdown on stderr (tools/cold_start.py)
+static double g_t_main = 0;
+#define TRACE(what) do { if (g_trace) fprintf(stderr, "cli: +%.1f ms %s\n", wall_ms() - g_t_main, what); } while (0)
+
 static int run_single(const Args& a)
 {
+    TRACE("run_single");
     sd_ctx* ctx = sd_create(a.seg, a.emb, 0);
     if (!ctx) { fprintf(stderr, "sd_create failed: %s\n", sd_create_error()); return 1; }
+    TRACE("sd_create done");
     if (a.precision && sd_set_option(ctx, "ecapa_precision", a.precision) != SD_OK) { fprintf(stderr, "%s\n", sd_last_error(ctx)); return 1; }
     if (a.precision == 3 && sd_set_option(ctx, "seg_precision", 3) != SD_OK) { fprintf(stderr, "%s\n", sd_last_error(ctx)); return 1; }
     if (a.dump_dir && sd_set_dump_dir(ctx, a.dump_dir, a.dump_level) != SD_OK) { fprintf(stderr, "%s\n", sd_last_error(ctx)); return 1; }
     sd_turn* turns = nullptr; int64_t nt = 0;
     const int rc = sd_diarize_wav(ctx, a.wav, a.wav_flags, &turns, &nt);      // 8 / 16 / 32-bit PCM like wav.h:99-122; rate and channels checked
     if (rc != SD_OK) { fprintf(stderr, "diarization failed (%d): %s\n", rc, sd_last_error(ctx)); return 1; }
+    TRACE("sd_diarize_wav done");
     print_block(ctx, turns, nt, a);
     sd_free_turns(turns);
     sd_destroy(ctx);
+    TRACE("sd_destroy done");
     return 0;
 }
 
@@ -126,6 +140,7 @@ static int run_rank(const Args& a, int rank, int world, int id_rd, const std::ve
 
 int main(int argc, char* argv[])
 {
+    g_t_main = wall_ms();
     Args a;
     std::vector<const char*> pos;
     for (int i = 1; i < argc; ++i) {

@@ -384,6 +384,13 @@ extern "C" int sd_diarize_wav(sd_ctx* c, const char* path, int flags, sd_turn** 
     ENTER(c);
     if (!path || !turns || !n_turns || (flags & ~(SD_WAV_RESAMPLE | SD_WAV_DOWNMIX))) SD_FAIL(c, SD_ERR_ARG, "sd_diarize_wav: bad argument");
     *turns = nullptr; *n_turns = 0;
+    {   // the common case -- 16-bit, 16 kHz, nothing to mix -- stays int16 up to the GPU (k_pcm_to_f32 does the reference's / 32768 there)
+        int16_t* pcm = nullptr; int64_t np = 0; int32_t sr16 = 0, ch16 = 0;
+        if (sd_read_wav(path, &pcm, &np, &sr16, &ch16) == SD_OK) {
+            struct FreePcm { int16_t* p; ~FreePcm() { sd_free_pcm(p); } } g{pcm};
+            if (sr16 == 16000 && !(ch16 > 1 && (flags & SD_WAV_DOWNMIX))) return sd_diarize(c, pcm, np, turns, n_turns);
+        }
+    }
     float* wav = nullptr; int64_t n = 0; int32_t sr = 0, ch = 0, bits = 0;
     if (sd_read_wav_f32(path, &wav, &n, &sr, &ch, &bits) != SD_OK) SD_FAIL(c, SD_ERR_ARG, "cannot read PCM wav: %s", path);
     struct Free { float* p; ~Free() { sd_free_wav(p); } } guard{wav};

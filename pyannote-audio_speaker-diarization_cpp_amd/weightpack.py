@@ -155,3 +155,19 @@ def synth_embedding_weights(seed=4322, C=1024):
     w["fc.weight"] = _conv_w(rng, EMB_DIM, 6 * C, 1, 1.0)
     w["fc.bias"] = (0.1 * rng.standard_normal(EMB_DIM)).astype(np.float32)
     return w
+
+
+def calibrated_embedding_weights(seed=4322):
+    """synth_embedding_weights(seed) with the 31 BatchNorms' running_mean / running_var (gamma = 1, beta = 0) learnt from one calibration batch
+    -- unsaturated SE gates, the regime of a trained ECAPA; the pack BASELINE configs[4]'s tolerance is asserted on.  The statistics are
+    package data (calibrated_bn_<seed>.npz, minted by tools/mint_calibrated_bn.py through the torch oracle; a CPU test re-derives them)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "calibrated_bn_%d.npz" % seed)
+    if not os.path.exists(path):
+        raise RuntimeError("no calibrated BatchNorm statistics for seed %d: run tools/mint_calibrated_bn.py" % seed)
+    w = dict(synth_embedding_weights(seed))
+    z = np.load(path)
+    for k in z.files:
+        assert k in w and w[k].shape == z[k].shape, k
+        w[k] = z[k].astype(np.float32)
+    return w

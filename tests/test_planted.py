@@ -265,9 +265,12 @@ def test_fp16_weight_rounding_on_the_calibrated_pack_is_harmless():
     pcm, scores, assign, emb_planted = planted_case(600.0, 1234)
     b, masks, counts, bad = nan_rule(scores)
     wav = pcm.astype(np.float32) / np.float32(32768.0)
-    wc = nn.calibrated_embedding_weights()
+    wc = nn.calibrated_embedding_weights()                                  # package data (weightpack.py + calibrated_bn_4322.npz)
     w0 = nn.synth_embedding_weights()
     assert all(np.array_equal(wc[k], w0[k]) for k in w0 if not (k.endswith("running_mean") or k.endswith("running_var") or ".norm." in k or k.startswith("asp_bn")))
+    fresh = nn.calibrate_embedding_weights()                                # the stored statistics are what the calibration computes
+    for k in w0:
+        np.testing.assert_allclose(wc[k], fresh[k], rtol=1e-4, atol=1e-5, err_msg=k)
     sig = np.zeros((32, 80000), np.float32)
     cn = np.zeros(32, np.int64)
     for j, i in enumerate(range(2496, 2528)):
