@@ -152,6 +152,7 @@ struct sd_ctx {
     int conv_w256_kmin = 0;                     // 256 x 256 kernel: shortest contraction Cin * KT it takes (0 = built-in: 1024 f32, 256 fp16); tuning
     int conv_pn = 0;                            // 256 x 256 kernel: column tiles per super-block (0 = 8); tuning
     bool conv_h256 = true;                      // fp16 mode: 256 x 256 tile kernel for the wide layers (conv_gemm_h.hip)
+    bool conv_glds = true;                      // fp16 mode: ... staged by LDS-DMA (conv_gemm_g.hip) instead of through registers; tuning / A-B
     bool skip_dead_rows = true;                 // ECAPA: skip row panels beyond nvalid + receptive field
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
     int64_t linkage_square = -1;               // -1 auto (full N x N distance matrix while it fits), 0 condensed, 1 square
@@ -206,6 +207,8 @@ void sd_flush_profile(sd_ctx* c);   // api.cpp: resolves pending event pairs int
 int launch_conv_gemm(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- conv_gemm_h.hip (fp16 mode, Cout >= 256: 256 x 256 tile; returns 1 = not applicable)
 int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& a, const char* tag);
+// ---- conv_gemm_g.hip (fp16 mode, Cout >= 256: the same tile with LDS-DMA staging; returns 1 = not applicable)
+int launch_conv_gemm_g256(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- conv_narrow.hip (f32, Cout <= 96, "valid" convs of SincNet: tile as wide as the layer; returns 1 = not applicable)
 int launch_conv_narrow(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- weights.cpp

@@ -1,0 +1,380 @@
+// conv_gemm_g.hip -- the fp16 mode's wide layers (Cout >= 256) with LDS-DMA staging (round 4).
+//
+// conv_gemm_h.hip's fp16 form stages its operands through registers (buffer_load -> VGPRs -> ds_write, one K-step ahead).  Here
+// `buffer_load_dwordx4 ... lds` writes them straight into LDS: no staging registers, no ds_write instructions, no VALU, and the
+// request for step s + 2 goes out the moment its stage is released (right behind the barrier inside step s) with a whole K-step to land.
+// What that bought, measured (profiles/r04_g256_ablation.txt): nothing on the big layers (MFA 991 -> 1 000 TF), 5 - 10 % on block0 -- the
+// loop is not bound by the issue -> land latency, as round 3 believed, but by the CU's vector-memory INGEST rate: 64 KB per K-step
+// arrive at 16 - 17 bytes per clock and CU whichever way they are requested (the same loop without MFMAs takes the same 3 900 cycles
+// per step; without the DMAs 2 257 = the matrix pipe 91 % busy).  With a 256 x 256 tile the fp16 pipe needs 32 B / clk / CU: the kernel
+// runs at ~ 85 % of what its memory path allows.  It stays the default fp16 form (fewer registers and instructions, same bits).
+//
+// Geometry as before: 256 x 256 tile, K-step of 64 halves (128 bytes of every row), 8 waves of 64 x 128 (2 x 4 tiles of
+// v_mfma_f32_32x32x16_f16, 128 accumulator registers), persistent super-blocks per XCD, the load stream runs across tile boundaries.
+// LDS: 2 stages x (256 + 256) rows x 128 B = 128 KB (+ 32 KB of epilogue strips = the CU's 160 KB).  An LDS-DMA wave instruction
+// writes 64 x 16 consecutive bytes = eight whole rows, so rows cannot be padded; bank conflicts of the fragment reads are removed by a
+// swizzle instead: the 16-byte chunk c of row R lives at chunk position c ^ ((R >> 1) & 7).  Every 16-lane group of a ds_read_b128
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... MI355X_MICROARCH.md, LDS) then reads sixteen different (128-byte half, chunk) slots
+// of the 256-byte bank row: conflict-free.  The swizzle is applied on the SOURCE side (the DMA's per-lane global address picks the
+// logical chunk its LDS slot holds) and in the fragment address.
+//
+// Ordering (MI355X_MICROARCH.md item 7, cdna_hip_programming.md "Read a staged buffer one phase AFTER the wait that retires it"):
+// a wave waits for its own DMAs (vmcnt) and for its outstanding fragment reads of the buffer about to be re-filled (lgkmcnt(0)),
+// then joins a raw s_barrier; the next buffer is read, and the released one re-filled, only behind that barrier.
+// Same arithmetic as the register-staged form: every output element sums the same products in the same order, so the two kernels
+// give the same bits (tests/test_gpu_parity.py::test_ecapa_fp16_lds_dma_staged_kernel_gives_the_same_bits).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+#define GM 256
+#define GN 256
+#define G_STAGE 65536          // bytes per stage: 256 A rows + 256 B rows of 128 B
+#define G_BOFF 32768
+#define G_STRIP 4096           // epilogue strip per wave: 16 rows x 128 channels of fp16 (128 + 32 KB = all of the CU's LDS)
+
+#ifndef SD_G_ABLATE
+#define SD_G_ABLATE 0          // diagnostic builds only: 1 no output stores, 2 no DMA in the loop, 4 no MFMA, 8 no A-operand DMA, 16 no W-operand DMA
+#endif
+typedef __attribute__((address_space(3))) char lds_char;
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA wave instruction: 64 x 16 bytes from the buffer `rs` (per-lane byte offset `vo`, scalar byte offset `so`) to the 1 KB of LDS at
+// `ldsaddr`.  Written as inline assembly on purpose: hipcc's waitcnt pass treats an LDS-DMA it knows about as a pending LDS store that ANY later
+// ds_read may alias and puts `s_waitcnt vmcnt(0)` in front of the next fragment read -- which would serialise exactly the overlap this
+// kernel exists for.  The waits that order these DMAs against the fragment reads are the explicit ones at the barrier (see the loop).
+__device__ __forceinline__ void lds_dma_b128(v4i rs, unsigned ldsaddr, unsigned vo, unsigned so)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(ldsaddr), "v"(vo), "s"(rs), "s"(so) : "memory");      // (m0 is reserved: the compiler does not keep values in it across statements)
+}
+
+__global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    const int w = blockIdx.x, G = gridDim.x;         // G is a multiple of 8
+    const int xcd = w & 7, wl = w >> 3, wpx = G >> 3;
+    const int mx = (a.m_tiles - xcd + 7) >> 3;       // row panels of this XCD: m = xcd + 8 j
+    const int pnmax = a.sched > 0 ? a.sched : 4;
+    const int PN = a.n_tiles < pnmax ? a.n_tiles : pnmax;
+    const int PM = wpx / PN > 0 ? wpx / PN : 1;
+    const int pm = wl / PN, pn = wl - pm * PN;
+    if (pm >= PM) return;
+    const int n_groups = (a.n_tiles + PN - 1) / PN, m_groups = (mx + PM - 1) / PM;
+    const int sb_end = n_groups * m_groups;
+    auto sb_valid = [&](int sb, int& j, int& nt) -> bool {
+        const int mg = sb / n_groups, ng = sb - mg * n_groups;
+        j = mg * PM + pm; nt = ng * PN + pn;
+        return j < mx && nt < a.n_tiles;
+    };
+    auto next_sb = [&](int sb) -> int {
+        int j, nt;
+        for (++sb; sb < sb_end; ++sb) if (sb_valid(sb, j, nt)) return sb;
+        return sb_end;
+    };
+    const int q0 = next_sb(-1);
+    if (q0 >= sb_end) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;           // wave tile: rows wr * 64, columns wc * 128
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int kcs = a.Cin / 64;
+    const int S = a.KT * kcs;
+    const int ktr = a.kt_real > 0 ? a.kt_real : a.KT;      // taps that shift rows (split-weight mode: KT = 2 * ktr planes)
+    const int half = ktr / 2;
+    const size_t in_rows = (size_t)(a.in_rows > 0 ? a.in_rows : a.M);
+
+    // loader: wave `wid` fills rows [32 wid, 32 wid + 32) of both operands, eight rows per DMA instruction; lane l writes LDS bytes
+    // [16 l, 16 l + 16) of the instruction's 1 KB: row Rp = 32 wid + 8 p + (l >> 3), chunk POSITION l & 7, which holds the logical
+    // chunk (l & 7) ^ ((Rp >> 1) & 7)
+    const int lrow = lane >> 3, pc = lane & 7;
+    auto l_row = [&](int p) { return wid * 32 + p * 8 + lrow; };
+    auto l_chunk = [&](int p) { return pc ^ ((((p & 1) << 2) + (lane >> 4)) & 7); };          // ((Rp >> 1) & 7) = 4 (p & 1) + (lane >> 4)
+    int rrel[4], tt[4], nd[4];
+    unsigned voA[4], voB[4];
+    int2 pre[4]; int pre_base = 0;
+    auto prefetch_tab = [&](int sb) {
+        int j, nt;
+        (void)sb_valid(sb, j, nt);
+        const int m0 = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * GM);
+        pre_base = a.rowtab[m0 < a.M ? m0 : a.M - 1].x;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { int g = m0 + l_row(p); if (g > a.M - 1) g = a.M - 1; pre[p] = a.rowtab[g]; }
+    };
+    // raw buffer resource {base[31:0], base[47:32] (stride 0), bytes, flags} -- the words __builtin_amdgcn_make_buffer_rsrc builds
+    auto make_rsrc = [&](const void* base, size_t bytes) {
+        const unsigned long long b = (unsigned long long)base;
+        v4i r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+        r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xffffu));
+        r[2] = __builtin_amdgcn_readfirstlane((int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes));
+        r[3] = 0x00020000;
+        return r;
+    };
+    v4i rA = make_rsrc(a.X, 0);
+    const v4i rB = make_rsrc(a.W16, (size_t)a.KT * a.Cout * a.w_ld * 2);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)(l_row(p) * a.w_ld * 2 + l_chunk(p) * 16);
+    int l_q = q0, l_kk = 0, l_kc = 0, m0l = 0, n0l = 0;
+    unsigned sK = 0, sB = 0;
+    auto set_tile = [&](int sb) {
+        int j, nt;
+        (void)sb_valid(sb, j, nt);
+        m0l = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * GM);
+        n0l = __builtin_amdgcn_readfirstlane(nt * GN);
+        const int base = __builtin_amdgcn_readfirstlane(pre_base);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { rrel[p] = pre[p].x - base; tt[p] = ROWTAB_T(pre[p].y); nd[p] = ROWTAB_LAST(pre[p].y); }
+        rA = make_rsrc((const char*)a.X + (size_t)base * a.x_ld * 2, (in_rows - base) * a.x_ld * 2);
+    };
+    auto set_tap = [&](int kk) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int qr = tt[p] + ((kk >= ktr ? kk - ktr : kk) - half) * a.dil;
+            if (qr < 0) qr = -qr;
+            if (qr >= a.Tin) qr = 2 * (a.Tin - 1) - qr;
+            if (qr < 0) qr = 0;
+            if (qr > nd[p]) qr = nd[p];
+            voA[p] = (unsigned)(rrel[p] + qr) * (unsigned)a.x_ld * 2 + (unsigned)l_chunk(p) * 16;
+        }
+        sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * 2);
+    };
+    auto advance = [&]() {
+        if (++l_kc < kcs) { sK += 128; return; }
+        l_kc = 0; sK = 0;
+        if (++l_kk == a.KT) {
+            l_kk = 0;
+            const int nq = next_sb(l_q);
+            if (nq < sb_end) {
+                l_q = nq; set_tile(l_q);
+                const int nq2 = next_sb(l_q);
+                if (nq2 < sb_end) prefetch_tab(nq2);
+            }
+        }
+        set_tap(l_kk);
+    };
+    // eight LDS-DMA instructions per wave and K-step: four 1 KB pieces of A, four of B
+    const unsigned lds0 = (unsigned)(size_t)(lds_char*)lds;
+    auto dma = [&](int st) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE + wid * 4096));
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (!(SD_G_ABLATE & 8)) lds_dma_b128(rA, base + p * 1024, voA[p], sK);
+            if (!(SD_G_ABLATE & 16)) lds_dma_b128(rB, base + G_BOFF + p * 1024, voB[p], sB + sK);
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragments: lane (li, lh) reads k = 16 kb + 8 lh .. + 7 (logical chunk 2 kb + lh) of row li of every 32-row block
+    const int swz = (li >> 1) & 7;
+    const char* const Afr = lds + (wr * 64 + li) * 128;
+    const char* const Bfr = lds + G_BOFF + (wc * 128 + li) * 128;
+    float4 ha[2][2], hb[2][4];
+    auto hfrag = [&](int st, int kb, int fbuf) {
+        const int co = ((2 * kb + lh) ^ swz) * 16 + st * G_STAGE;
+        ha[fbuf][0] = *(const float4*)(Afr + co);
+        ha[fbuf][1] = *(const float4*)(Afr + co + 32 * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hb[fbuf][j] = *(const float4*)(Bfr + co + j * 32 * 128);
+    };
+    auto hmma = [&](int fbuf) {
+        if (SD_G_ABLATE & 4) {          // ablation (diagnostic builds only): fragment reads without the matrix pipe
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { asm volatile("" :: "v"(hb[fbuf][j].x), "v"(hb[fbuf][j].y), "v"(hb[fbuf][j].z), "v"(hb[fbuf][j].w)); }
+            asm volatile("" :: "v"(ha[fbuf][0].x), "v"(ha[fbuf][0].w), "v"(ha[fbuf][1].x), "v"(ha[fbuf][1].w));
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ha[fbuf][0]), __builtin_bit_cast(half8, hb[fbuf][j]), acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ha[fbuf][1]), __builtin_bit_cast(half8, hb[fbuf][j]), acc[1][j], 0, 0, 0);
+        }
+    };
+
+    // prologue: steps 0 and 1 of the first tile are requested; step 0 has to be there
+    prefetch_tab(l_q);
+    set_tile(l_q);
+    { const int nq2 = next_sb(l_q); if (nq2 < sb_end) prefetch_tab(nq2); }
+    set_tap(0);
+    int m0c = m0l, n0c = n0l;
+    dma(0);
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    dma(1);
+    advance();
+    hfrag(0, 0, 0);
+
+    int q = q0, s = 0, buf = 0;
+#ifdef SD_G_STAMPS        // diagnostic build only (make libsdhip_gstamps.so): where a workgroup's cycles go -- K-loop, epilogue -- printed by one workgroup
+    unsigned long long t_loop = 0, t_epi = 0, t_mark = __builtin_amdgcn_s_memtime(); int n_tiles_done = 0;
+#endif
+    while (true) {
+#define W_PAIR(mask, n) do { _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); } } while (0)
+        // K-groups 0..2 of step s from stage `buf`; each group's fragments were read while the group before ran
+        hfrag(buf, 1, 1);
+        hmma(0);
+        W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        hfrag(buf, 2, 0);
+        hmma(1);
+        W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        hfrag(buf, 3, 1);
+        hmma(0);
+        W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // stage `buf` has been read out (this wave's last fragments of it are in registers once lgkmcnt reaches 0) and this wave's
+        // share of step s + 1 has landed in the other stage (vmcnt(0)): behind the barrier that holds for every wave
+        // (the counter retires in issue order.  Right behind an epilogue the wave's 16 output stores are YOUNGER than the eight DMAs
+        // this barrier needs: vmcnt(16) lets them drain under the new tile's first K-step instead of in front of its first barrier)
+        if (s == 0 && q != q0 && !a.y_f32) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(SD_G_ABLATE & 2)) dma(buf);            // step s + 2 into the stage just released
+        hfrag(buf ^ 1, 0, 0);
+        hmma(1);
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+
+        if (s == S - 1) {
+#ifdef SD_G_STAMPS
+            { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t; }
+#endif
+            // ---- epilogue.  C layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+            // The wave's 64 x 128 outputs pass through a wave-private 4 KB LDS strip, sixteen rows at a time: written as the accumulators lie
+            // after the 4 x 4 quad transpose (8 bytes per lane), read back as whole 256-byte rows and stored 16 bytes per lane -- 16 store
+            // instructions per wave, each four complete rows (the register-staged kernel: 32 stores of eight 64-byte segments).
+            // [Tried: the weight fragment as the MFMA's first operand, which hands every lane four consecutive channels of one row and
+            // needs no cross-lane transposes -- but then a lane needs the bias / BatchNorm parameters of 64 channels instead of 4, and
+            // fetching them inside the loop (3 dependent float4 loads per register group) cost more than the 3 VALU per value it saved.]
+            const float slope = (a.act1 == 1) ? 0.0f : ((a.act1 == 2) ? 0.01f : 1.0f);
+            const int lq = lane & 3;
+            _Float16* const Y = (_Float16*)a.Y;
+            char* const strip = lds + 2 * G_STAGE + wid * G_STRIP;               // [16 rows][256 bytes], 16-byte chunk c of row r at c ^ r
+            float cb[4], cs[4], ch[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cc = n0c + wc * 128 + j * 32 + li;
+                cb[j] = a.bias ? a.bias[cc] : 0.0f;
+                cs[j] = a.scale ? a.scale[cc] : 1.0f; ch[j] = a.scale ? a.shift[cc] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {                                    // sixteen rows: gq = 2 hq, 2 hq + 1
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int gq = 2 * hq + g2;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float x[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = acc[i][j][4 * gq + e] + cb[j];
+                                acc[i][j][4 * gq + e] = 0.0f;
+                                v = fmaxf(v, v * slope);
+                                x[e] = v * cs[j] + ch[j];
+                            }
+                            // 4 x 4 transpose across the lane quad (two butterfly stages on DPP quad_perm)
+                            float s0 = (lq & 1) ? x[0] : x[1];
+                            float s1 = (lq & 1) ? x[2] : x[3];
+                            float r0_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xF, 0xF, true));
+                            float r1_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xF, 0xF, true));
+                            if (lq & 1) { x[0] = r0_; x[2] = r1_; } else { x[1] = r0_; x[3] = r1_; }
+                            s0 = (lq & 2) ? x[0] : x[2];
+                            s1 = (lq & 2) ? x[1] : x[3];
+                            r0_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0x4E, 0xF, 0xF, true));
+                            r1_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0x4E, 0xF, 0xF, true));
+                            if (lq & 2) { x[0] = r0_; x[1] = r1_; } else { x[2] = r0_; x[3] = r1_; }
+                            // the lane now holds row 8 g2 + 4 lh + lq of the strip, columns 32 j + (li & ~3) .. + 3
+                            if (a.y_f32) {
+                                const int g = m0c + wr * 64 + i * 32 + 8 * gq + 4 * lh + lq;
+                                const int co = n0c + wc * 128 + j * 32 + (li & ~3);
+                                if (g < a.M) *(float4*)(a.Y + (size_t)g * a.y_ld + co) = make_float4(x[0], x[1], x[2], x[3]);
+                            } else {
+                                const half4 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+                                const int sr = 8 * g2 + 4 * lh + lq;
+                                *(half4*)(strip + sr * 256 + (((j * 4 + (li >> 3)) ^ sr) * 16) + ((li >> 2) & 1) * 8) = hv;
+                            }
+                        }
+                    }
+                    if (!a.y_f32) {
+                        // whole rows back: lane reads 16 bytes of row 4 t + (lane >> 4); the wave's LDS operations execute in order, so these
+                        // reads see the writes above and the next strip's writes come behind them
+                        const int c16 = lane & 15, rr = lane >> 4;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float4 v = *(const float4*)(strip + (4 * t + rr) * 256 + ((c16 ^ (4 * t + rr)) * 16));
+                            const int g = m0c + wr * 64 + i * 32 + 16 * hq + 4 * t + rr;
+                            if (g < a.M) *(float4*)(Y + (size_t)g * a.y_ld + n0c + wc * 128 + c16 * 8) = v;
+                        }
+                    }
+                }
+            }
+#ifdef SD_G_STAMPS
+            { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); t_epi += t - t_mark; t_mark = t; ++n_tiles_done; }
+#endif
+            q = next_sb(q);
+            if (q >= sb_end) break;
+            { int j_, nt_; (void)sb_valid(q, j_, nt_); m0c = __builtin_amdgcn_readfirstlane((xcd + 8 * j_) * GM); n0c = __builtin_amdgcn_readfirstlane(nt_ * GN); }
+            s = 0;
+        } else {
+            ++s;
+        }
+        buf ^= 1;
+    }
+#ifdef SD_G_STAMPS
+    if (blockIdx.x == 8 && tid == 0) printf("g256 M %d K %d N %d: %d tiles x %d steps; K-loop %llu cycles (%llu per step), epilogue %llu (%llu per tile = %.1f steps)\n", a.M, a.Cin * a.KT, a.Cout,
+                                            n_tiles_done, S, t_loop, t_loop / (unsigned long long)(n_tiles_done * S), t_epi, t_epi / (unsigned long long)n_tiles_done,
+                                            (double)t_epi / n_tiles_done / ((double)t_loop / (n_tiles_done * S)));
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the load stream runs past the last tile: nothing may be in flight when the LDS is given back
+}
+
+// returns 1 when the layer does not fit this kernel (the caller then uses the register-staged forms)
+int launch_conv_gemm_g256(sd_ctx* c, const ConvArgs& in, const char* tag)
+{
+    ConvArgs a = in;
+    if (a.prec != 1 || !a.rowtab || !a.W16 || a.X2 || a.item_bias || a.R || a.act2 || a.pad_mode != 0 || a.Cout < 256 || (a.Cout % GN) != 0 || (a.y_ld & 3) ||
+        a.Cin % 64 != 0 || a.M < 8 * GM || (a.x_ld & 7)) return 1;
+    if ((int64_t)a.Cin * (a.kt_real > 0 ? a.kt_real : a.KT) < (c->conv_w256_kmin > 0 ? c->conv_w256_kmin : 256)) return 1;
+    static bool attr_set = false;
+    const size_t lds_bytes = (size_t)2 * G_STAGE + 8 * G_STRIP;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_gemm_g256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        attr_set = true;
+    }
+    if (a.w_ld <= 0) a.w_ld = a.Cin;
+    a.m_tiles = (a.M + GM - 1) / GM;
+    a.n_tiles = (a.Cout + GN - 1) / GN;
+    a.sched = c->conv_pn;
+    int grid = (c->num_cu / 8) * 8;
+    if (grid < 8) grid = 8;
+    const int lx_max = ((a.m_tiles + 7) / 8) * a.n_tiles;
+    if (grid / 8 > lx_max) grid = lx_max * 8;
+    const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
+    const double flops = 2.0 * (double)a.M * a.Cout * cin * (a.kt_real > 0 ? a.kt_real : a.KT);
+    const double bytes = 2.0 * ((double)a.M * cin + (double)a.M * a.Cout + (double)a.Cout * cin * a.KT);
+    {
+        ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
+        ProfScope ps16(c, "conv_gemm_f16", flops, bytes);
+        ProfScope psw(c, "conv_w256_f16", flops, bytes);
+        ProfScope pss(c, "conv_w256_ecapa", flops, bytes);
+        hipLaunchKernelGGL(k_conv_gemm_g256, dim3(grid), dim3(512), lds_bytes, c->stream, a);
+    }
+    if (hipGetLastError() != hipSuccess) SD_FAIL(c, SD_ERR_HIP, "k_conv_gemm_g256 launch failed (%s)", tag);
+    return SD_OK;
+}

@@ -363,6 +363,27 @@ def test_ecapa_fp16_wide_tile_kernel_gives_the_same_bits(diarizer):
     assert np.isfinite(e_wide).all() and np.array_equal(e_wide, e_128)
 
 
+def test_ecapa_fp16_lds_dma_staged_kernel_gives_the_same_bits(diarizer):
+    """fp16 mode: the LDS-DMA staged 256 x 256 kernel (conv_gemm_g.hip: buffer_load ... lds into a swizzled, unpadded LDS image, two
+    K-steps in flight) against the register-staged one (conv_gemm_h.hip): same k-blocks into the same MFMA chain in the same order --
+    bit-identical embeddings on ragged items (row tables, reflect padding, clamped taps, partly filled last tiles), run twice (a DMA
+    that lands late would show as a run-to-run difference)"""
+    rng = np.random.default_rng(31)
+    lens = np.array([1.0, 0.5, 0.25, 0.9, 0.7, 0.33, 1.0, 0.6, 0.8, 0.45, 0.12, 1.0, 0.77, 0.05, 0.95, 0.5, 0.61, 1.0, 0.29, 0.83], np.float32)
+    feats = (3.0 * rng.standard_normal((len(lens), 501, 80))).astype(np.float32)
+    diarizer.set_option("ecapa_precision", 1)
+    try:
+        diarizer.set_option("conv_glds", 1)
+        e_dma = diarizer.ecapa(feats, lens)
+        e_dma2 = diarizer.ecapa(feats, lens)
+        diarizer.set_option("conv_glds", 0)
+        e_reg = diarizer.ecapa(feats, lens)
+    finally:
+        diarizer.set_option("conv_glds", 1)
+        diarizer.set_option("ecapa_precision", 0)
+    assert np.isfinite(e_dma).all() and np.array_equal(e_dma, e_reg) and np.array_equal(e_dma, e_dma2)
+
+
 def test_ecapa_f32_wide_tile_kernel_gives_the_same_bits(diarizer):
     """f32: the 256 x 256 kernel (TDNN, MFA) sums K in conv_gemm.hip's order: bit-identical embeddings"""
     rng = np.random.default_rng(29)
