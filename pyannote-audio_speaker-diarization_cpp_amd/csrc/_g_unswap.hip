@@ -220,8 +220,8 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float bv = e == 0 ? hb[fbuf][j].x : e == 1 ? hb[fbuf][j].y : e == 2 ? hb[fbuf][j].z : hb[fbuf][j].w;
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, a0[e], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, a1[e], acc[1][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bv, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bv, acc[1][j], 0, 0, 0);
                 }
         } else {
 #pragma unroll
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float bv = e == 0 ? hb[1][j].x : e == 1 ? hb[1][j].y : e == 2 ? hb[1][j].z : hb[1][j].w;
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, a0[e], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, a1[e], acc[1][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bv, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bv, acc[1][j], 0, 0, 0);
                     if ((j & 1) == 1) { __builtin_amdgcn_sched_barrier(0); dma_piece(buf, e * 2 + (j >> 1)); __builtin_amdgcn_sched_barrier(0); }
                 }
         } else {

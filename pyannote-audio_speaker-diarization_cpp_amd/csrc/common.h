@@ -152,6 +152,7 @@ struct sd_ctx {
     int conv_w256_kmin = 0;                     // 256 x 256 kernel: shortest contraction Cin * KT it takes (0 = built-in: 1024 f32, 256 fp16); tuning
     int conv_pn = 0;                            // 256 x 256 kernel: column tiles per super-block (0 = 8); tuning
     bool conv_h256 = true;                      // fp16 mode: 256 x 256 tile kernel for the wide layers (conv_gemm_h.hip)
+    bool conv_glds_f32 = false;                 // f32: the LDS-DMA staged form of the wide tile (conv_gemm_g.hip, P = 0): bit-identical, measured slower; A-B only
     bool conv_glds = true;                      // fp16 mode: ... staged by LDS-DMA (conv_gemm_g.hip) instead of through registers; tuning / A-B
     bool skip_dead_rows = true;                 // ECAPA: skip row panels beyond nvalid + receptive field
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups

@@ -629,7 +629,9 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     if (f16 && !a.W16) SD_FAIL(c, SD_ERR_ARG, "conv_gemm(%s): fp16 mode without fp16 weights", tag);
     if (a.Cin % (f16 ? 64 : BK) != 0) SD_FAIL(c, SD_ERR_ARG, "conv_gemm(%s): Cin=%d not a multiple of %d", tag, a.Cin, f16 ? 64 : BK);
     if (a.M <= 0) return SD_OK;
-    if (f16 && c->conv_h256 && c->conv_glds) { const int r = launch_conv_gemm_g256(c, a, tag); if (r != 1) return r; }      // LDS-DMA staged form (conv_gemm_g.hip)
+    // LDS-DMA staged form (conv_gemm_g.hip): the default for fp16; for f32 it measured 5 % SLOWER than the register-staged, pinned kernel
+    // (MFA 147 -> 140 TF, tdnn 140 -> 131: profiles/r04_g256_ablation.txt) and is only taken with option conv_glds_f32 = 1
+    if ((f16 && c->conv_h256 && c->conv_glds) || (!f16 && a.prec == 0 && c->conv_w256_f32 && c->conv_glds_f32)) { const int r = launch_conv_gemm_g256(c, a, tag); if (r != 1) return r; }
     if ((f16 && c->conv_h256) || (!f16 && c->conv_w256_f32) || a.prec == 3) { const int r = launch_conv_gemm_h256(c, a, tag); if (r != 1) return r; }
     const bool x3 = a.prec == 3 && a.W16x != nullptr;      // a layer the wide kernel does not take (X2, per-item bias, Cout = 128): the 128 x 128 form of the split
     if (a.prec == 3 && !x3) a.prec = 0;
