@@ -219,7 +219,8 @@ int load_pack(const char* path, Pack& out, std::string& err);
 int load_model_any(const char* path, int kind, Pack& out, std::string& err);   // onnx_reader.cpp: .sdw pack or .onnx (kind 0 seg, 1 emb)
 int build_ecapa_weights(sd_ctx* c, const Pack& p);
 int build_seg_weights(sd_ctx* c, const Pack& p);
-int ensure_ecapa_mode_weights(sd_ctx* c, int ecapa_precision);   // builds W16 (modes 1, 2) / W16x (mode 3) on first use
+void* weight_alloc(sd_ctx* c, size_t bytes);                      // weights.cpp: bump allocator over 64 MB device blocks (freed by sd_destroy)
+int ensure_ecapa_mode_weights(sd_ctx* c, int ecapa_precision);   // weights_gpu.hip: builds W16 (modes 1, 2) / W16x (mode 3) on first use
 // ---- frontend.hip
 int frontend_prepare(sd_ctx* c, const float* d_masks, int64_t items, int64_t first_item, float* d_wav_lens, int* d_nnorm, int* d_nvalid,
                      int* d_flags, bool compact, int* h_n_active, int* d_cidx, std::vector<int>* h_nvalid = nullptr);
