@@ -599,14 +599,21 @@ def main():
             cosd = None
             if True:
                 # accuracy on the REAL embeddings (planted workload: the planted ones replace them in the timed jobs, so: scores planted, embeddings kept)
+                # (segmentation + embedding stages only, sd_shard_infer_dev: the real embeddings of a random-weight network carry exact
+                # duplicates, which would send the finalize stage down its 0.8 s tie fallback four times for nothing)
                 if planted:
                     d.set_planted(d_ps.data_ptr(), 0, lo, hi - lo)
-                step()
-                em = d.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192).astype(np.float64)
+                seg_t = torch.zeros((C, 293, 3), dtype=torch.float32, device=dev)
+                emb_t = torch.zeros((C * 3, 192), dtype=torch.float32, device=dev)
+                d.shard_infer_dev(d_pcm.data_ptr(), 0, n_total, n_total, 0, C, seg_t.data_ptr(), emb_t.data_ptr())
+                gpu_sync()
+                em = emb_t.cpu().numpy().astype(np.float64)
                 d.set_option("ecapa_precision", 0)
                 d.set_option("seg_precision", 0)
-                step()
-                e32 = d.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192).astype(np.float64)
+                d.shard_infer_dev(d_pcm.data_ptr(), 0, n_total, n_total, 0, C, seg_t.data_ptr(), emb_t.data_ptr())
+                gpu_sync()
+                e32 = emb_t.cpu().numpy().astype(np.float64)
+                del seg_t, emb_t
                 if planted:
                     d.set_planted(d_ps.data_ptr(), d_pe.data_ptr(), lo, hi - lo)
                 lv = ~np.isnan(e32[:, 0])
@@ -642,16 +649,19 @@ def main():
                 d2.set_planted(d_ps.data_ptr(), 0, lo, hi - lo)
                 res = {}
                 embs = {}
+                seg2 = torch.zeros((C, 293, 3), dtype=torch.float32, device=dev)
+                emb2 = torch.zeros((C * 3, 192), dtype=torch.float32, device=dev)
                 for mode, name in ((0, "f32"), (1, "fp16"), (3, "x3")):
                     d2.set_option("ecapa_precision", mode)
-                    tt = d2.diarize_dev(d_pcm.data_ptr(), n_total)
+                    # inference only (sd_shard_infer_dev): the REAL embeddings of a random-weight network carry exact duplicates, which send the
+                    # finalize stage down its tie fallback -- not what this object is about
+                    d2.shard_infer_dev(d_pcm.data_ptr(), 0, n_total, n_total, 0, C, seg2.data_ptr(), emb2.data_ptr())
                     gpu_sync()
                     t1 = time.perf_counter()
-                    tt = d2.diarize_dev(d_pcm.data_ptr(), n_total)
+                    d2.shard_infer_dev(d_pcm.data_ptr(), 0, n_total, n_total, 0, C, seg2.data_ptr(), emb2.data_ptr())
                     gpu_sync()
-                    res[name] = {"ms": round((time.perf_counter() - t1) * 1e3, 1), "turns": len(tt)}
-                    embs[name] = d2.read_ws("dz_emb", np.float32, C * 3 * 192).reshape(-1, 192).astype(np.float64)
-                    res[name]["_turns"] = tt
+                    res[name] = {"inference_ms": round((time.perf_counter() - t1) * 1e3, 1)}
+                    embs[name] = emb2.cpu().numpy().astype(np.float64)
                 lv = ~np.isnan(embs["f32"][:, 0])
                 for name in ("fp16", "x3"):
                     e = embs[name]
@@ -659,12 +669,9 @@ def main():
                     res[name]["cosine_distance_to_f32_embeddings"] = {"items": int(lv.sum()), "max": float("%.3g" % cd.max()), "q99": float("%.3g" % np.quantile(cd, 0.99)),
                                                                       "median": float("%.3g" % np.median(cd)), "above_1e-3": int((cd > 1e-3).sum()),
                                                                       "same_nan_rows": bool(np.array_equal(np.isnan(e[:, 0]), ~lv))}
-                    res[name]["same_turns_as_f32"] = res[name]["_turns"] == res["f32"]["_turns"]
-                for name in res:
-                    res[name].pop("_turns")
                 d2.close()
                 extra_lines["fp16"]["calibrated_pack"] = {"what": "the tolerance check of BASELINE configs[4] on the calibrated seeded pack (BatchNorm statistics from one calibration batch: SE gates "
-                                                                  "unsaturated as in a trained ECAPA; same conv weights): real embeddings of the planted masks, one warm job per mode", **res}
+                                                                  "unsaturated as in a trained ECAPA; same conv weights): real embeddings of the planted masks, segmentation + embedding stages only, one warm pass per mode (turns: tests/test_planted.py)", **res}
             except Exception as e:
                 extra_lines["fp16"]["calibrated_pack"] = {"error": str(e)[:300]}
         if a.precision == "f32" and a.x3_steps > 0:

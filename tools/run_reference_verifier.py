@@ -20,6 +20,29 @@ R.ref_finalize.restype = C.c_long
 R.ref_finalize.argtypes = [orc.c_fp, C.c_long, C.c_int, C.c_int, orc.c_dp, C.c_int, C.c_long, C.POINTER(orc.Turn), C.c_long, C.POINTER(C.c_int)]
 buf = (orc.Turn * (nc * 8 + 64))(); K = C.c_int(0)
 nt = R.ref_finalize(np.ascontiguousarray(seg), nc, 293, 3, np.ascontiguousarray(emb.astype(np.float64)), 192, n, buf, len(buf), C.byref(K))
+# getEmbedding's per-batch files (masks<n>, imasks<n>, wav_lens<n>): the reference's Helper::interpolate / padSequence / wav_lens rule on the batches
+# speakerDiarization() forms (sd.cpp:3047-3107) from the same scores; the audio is regenerated here (seeded synthetic, or the golden 1-min wav)
+R.ref_embedding_inputs.restype = C.c_int
+R.ref_embedding_inputs.argtypes = [orc.c_fp, orc.c_fp, C.c_int, C.c_int, C.c_long, orc.c_fp, orc.c_fp, orc.c_bp]
+R.ref_set_batch_number.argtypes = [C.c_int]
+import synth, sdhip
+if "planted" in src:
+    pcm = synth.make_pcm(180.0, seed=77)
+else:
+    pcm = sdhip.read_wav(os.path.join(ROOT, "tests", "golden", "multi-speaker_1min.wav"))[0]
+assert len(pcm) == n
+wav = pcm.astype(np.float32) / np.float32(32768.0)
+masks = orc.select_masks(orc.binarize(seg))
+number = 0
+for b0 in range(0, nc * 3, 32):
+    items = list(range(b0, min(nc * 3, b0 + 32)))
+    wavs = np.stack([orc.crop(wav, (i // 3) * 8000) for i in items])
+    R.ref_set_batch_number(number)
+    sig = np.zeros_like(wavs); lens = np.zeros(len(items), np.float32); ts = np.zeros(len(items), np.uint8)
+    if not R.ref_embedding_inputs(np.ascontiguousarray(wavs), np.ascontiguousarray(masks[items]), len(items), 293, 80000, sig, lens, ts):
+        number += 1                       # `number++` sits behind the early return of an all-too-short batch (sd.cpp:2479-2519)
+for f in glob.glob("/tmp/cpp_imasks*.txt"):                # 15 MB each, written by this build only at dump level 2
+    os.remove(f)
 for f in glob.glob("/tmp/cpp_*.txt"):                      # the reference's own dumps play the script's "py" side
     shutil.move(f, f.replace("/tmp/cpp_", "/tmp/py_"))
 mine = sorted(glob.glob(os.path.join(src, "cpp_*.txt")))
