@@ -636,7 +636,10 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     const bool x3 = a.prec == 3 && a.W16x != nullptr;      // a layer the wide kernel does not take (X2, per-item bias, Cout = 128): the 128 x 128 form of the split
     if (a.prec == 3 && !x3) a.prec = 0;
     if (x3) a.w_ld = 2 * a.Cin;
-    if (a.prec == 0 && a.KT == 1 && a.M <= 2048 && a.TpIn == a.M && a.TpOut == a.M && a.T == a.M && a.Tin == a.M && !a.X2 && !a.item_bias && !a.R && !a.rowtab &&
+    // (4 096 >= ROWTAB_MAX_ITEMS: the per-utterance layers of an ECAPA batch ALWAYS take this kernel.  Round 4 found the limit at 2 048 while a batch
+    // could hold up to 4 095 short items: above it the 128 x 128 kernel took over, whose K order differs in the last bits, so a result depended on
+    // how many items shared a batch -- tests/test_planted.py asserts batch-size independence bit for bit)
+    if (a.prec == 0 && a.KT == 1 && a.M <= 4096 && a.TpIn == a.M && a.TpOut == a.M && a.T == a.M && a.Tin == a.M && !a.X2 && !a.item_bias && !a.R && !a.rowtab &&
         (a.x_ld & 3) == 0 && (a.w_ld & 3) == 0) {
         const int cinr = a.cin_real > 0 ? a.cin_real : a.Cin;
         ProfScope ps(c, c->profile_detail ? std::string("skinny_gemm:") + tag : std::string("skinny_gemm"), 2.0 * a.M * a.Cout * cinr,

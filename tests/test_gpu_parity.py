@@ -384,6 +384,28 @@ def test_ecapa_fp16_lds_dma_staged_kernel_gives_the_same_bits(diarizer):
     assert np.isfinite(e_dma).all() and np.array_equal(e_dma, e_reg) and np.array_equal(e_dma, e_dma2)
 
 
+def test_ecapa_bits_do_not_depend_on_how_many_items_share_a_batch(diarizer):
+    """2 100 short items: one batch under the default row budget (more than 2 048 items: the per-utterance layers -- SE, ASP bias, fc -- must
+    still take the kernel they take in small batches) against batches of 96: bit-identical embeddings in f32, x3 and fp16 mode.  (Round 4:
+    above 2 048 items per batch those layers fell to the 128 x 128 kernel, whose K order differs in the last bits.)"""
+    rng = np.random.default_rng(41)
+    n = 2100
+    lens = np.full(n, 0.06, np.float32)
+    lens[::7] = 0.2
+    feats = (3.0 * rng.standard_normal((n, 501, 80))).astype(np.float32)
+    try:
+        for mode in (0, 3, 1):
+            diarizer.set_option("ecapa_precision", mode)
+            diarizer.set_option("emb_batch_items", 96)
+            e_small = diarizer.ecapa(feats, lens)
+            diarizer.set_option("emb_batch_items", 3072)
+            e_big = diarizer.ecapa(feats, lens)
+            assert np.isfinite(e_big).all() and np.array_equal(e_big, e_small), mode
+    finally:
+        diarizer.set_option("emb_batch_items", 3072)
+        diarizer.set_option("ecapa_precision", 0)
+
+
 def test_ecapa_f32_lds_dma_staged_kernel_gives_the_same_bits(diarizer):
     """f32: the LDS-DMA staged form of the wide tile (conv_gemm_g.hip P = 0: weights as the MFMA's first operand -> transposed accumulators,
     16-byte output stores that drain under the next tile, parameters through LDS) against the default register-staged kernel: bit-identical

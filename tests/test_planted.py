@@ -177,7 +177,7 @@ def test_whole_path_with_planted_scores_and_real_embeddings(diarizer, weights):
     try:
         e_small_batches = diarizer.embed(big_wav, big_masks)
     finally:
-        diarizer.set_option("emb_batch_items", 768)
+        diarizer.set_option("emb_batch_items", 3072)
     assert np.array_equal(e_small_batches, emb[3 * c0:3 * c0 + 960], equal_nan=True)
     sigs = np.zeros((96, 80000), np.float32)
     cnts = np.zeros(96, np.int64)
@@ -369,7 +369,7 @@ def test_x3_mode_at_scale_is_f32_grade(diarizer):
         ex = diarizer.embed(wav, masks)
         diarizer.set_option("emb_batch_items", 96)
         ex_small = diarizer.embed(wav[:(319 * 8000 + 80000)], masks[:960])
-        diarizer.set_option("emb_batch_items", 768)
+        diarizer.set_option("emb_batch_items", 3072)
         diarizer.set_planted(d_sc.data_ptr(), 0, 0, nc)
         real_x = diarizer.diarize_dev(d_pcm.data_ptr(), n)
         diarizer.set_planted(d_sc.data_ptr(), d_em.data_ptr(), 0, nc)
@@ -380,7 +380,7 @@ def test_x3_mode_at_scale_is_f32_grade(diarizer):
         real_32 = diarizer.diarize_dev(d_pcm.data_ptr(), n)
     finally:
         diarizer.set_planted(0, 0, 0, 0)
-        diarizer.set_option("emb_batch_items", 768)
+        diarizer.set_option("emb_batch_items", 3072)
         diarizer.set_option("ecapa_precision", 0)
     assert np.array_equal(np.isnan(ex[:, 0]), bad) and np.array_equal(np.isnan(e32[:, 0]), bad)
     live = ~bad
