@@ -75,6 +75,7 @@ struct ConvArgs {
                            // 3 = f32 tensors, split fp16 operands on the matrix pipe (W16x; wide layers only, conv_gemm_h.hip)
     const void* W16x;      // prec 3: split weights (ConvLayer::W16x)
     float acc_scale;       // prec 3: 1 / weight scale, applied to the accumulator in the epilogue
+    int stagger;           // 128 x 128 f32 kernel, short contractions: 0 = all workgroups start together, 1 / 2 = half of them start half a tile late (conv_gemm.hip)
 };
 #define ROWTAB_T(y) ((y) & 1023)
 #define ROWTAB_LAST(y) (((y) >> 10) & 1023)
@@ -152,6 +153,7 @@ struct sd_ctx {
     int conv_w256_kmin = 0;                     // 256 x 256 kernel: shortest contraction Cin * KT it takes (0 = built-in: 1024 f32, 256 fp16); tuning
     int conv_pn = 0;                            // 256 x 256 kernel: column tiles per super-block (0 = 8); tuning
     bool conv_h256 = true;                      // fp16 mode: 256 x 256 tile kernel for the wide layers (conv_gemm_h.hip)
+    int conv_stagger = 0;                       // 128 x 128 f32 kernel: start half of the workgroups half a tile late (0 off, 1 odd, 2 upper half); tuning
     bool conv_glds_f32 = false;                 // f32: the LDS-DMA staged form of the wide tile (conv_gemm_g.hip, P = 0): bit-identical, measured slower; A-B only
     bool conv_glds = true;                      // fp16 mode: ... staged by LDS-DMA (conv_gemm_g.hip) instead of through registers; tuning / A-B
     bool skip_dead_rows = true;                 // ECAPA: skip row panels beyond nvalid + receptive field

@@ -322,6 +322,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvArgs a)
         // tile late lets one workgroup's epilogue overlap the other's MFMAs (a 16-MFMA K-step is only ~512 cycles here).
         if (a.sched == 3 && (wl & 1)) for (int i_ = 0; i_ < S * 4; ++i_) __builtin_amdgcn_s_sleep(1);
     }
+    if constexpr (PR == 0) {
+        // f32, short contractions (Res2Net: 12 K-steps of 4 096 cycles per tile, then an epilogue bound by its stores): the same lockstep.
+        // a.stagger (tuning, option conv_stagger): 1 = every second workgroup of an XCD, 2 = the second half of an XCD's workgroups
+        // start half a tile late
+        if (a.stagger && S <= 16) {
+            const bool late = a.stagger == 1 ? (wl & 1) : (wl >= (wpx >> 1));
+            if (late) for (int i_ = 0; i_ < S / 4; ++i_) __builtin_amdgcn_s_sleep(127);
+        }
+    }
 
     int q = q0, s = 0, buf = 0;
     while (true) {
@@ -651,6 +660,7 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     a.m_tiles = (a.M + BM - 1) / BM;
     a.n_tiles = (a.Cout + BN - 1) / BN;
     a.sched = c->conv_pn128 > 0 ? 100 + c->conv_pn128 : SD_CONV_SCHED_DEFAULT;
+    a.stagger = c->conv_stagger;
     const int grid = conv_grid(c, a);
     // algorithmic work: valid rows only (T of every TpOut), un-padded input channels
     const double rows = a.rowtab ? (double)a.M
