@@ -101,7 +101,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
 {
     if (!c || !key) return SD_ERR_ARG;
     std::string k(key);
-    if (k == "emb_batch_items") c->emb_batch_items = v;
+    if (k == "emb_batch_items") { c->emb_batch_items = v; c->emb_batch_explicit = true; }
     else if (k == "seg_batch_chunks") c->seg_batch_chunks = v;
     else if (k == "linkage_wgs") c->linkage_wgs = v;
     else if (k == "linkage_threads") c->linkage_threads = v;

@@ -138,6 +138,9 @@ struct sd_ctx {
     std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t, double, double>> pending;
     double stage_ms[4] = {0, 0, 0, 0};
     int64_t emb_batch_items = 3072;            // multiple of 96; row budget of a batch = this many full-length items (a batch also holds at most 4 095 items): ~57 GB of activation workspaces at the 1-h size, 1 % faster than 768 (fewer partly filled tile rounds and launch tails)
+    bool emb_batch_explicit = false;            // set through sd_set_option: then it holds from the first call on
+    int64_t embed_calls = 0;                    // run_embed calls of this context: the FIRST one plans 768-item batches (16 GB) unless the option was set --
+                                                // a one-shot CLI user does not pay ~0.5 s of first-touch hipMalloc for a 57 GB arena; a context that sees more work grows it
     int64_t seg_batch_chunks = 4096;           // 128 LSTM workgroups per direction: one full wave of CUs
     int num_clusters = -1, min_clusters = -1, max_clusters = -1;   // optional constraints for the whole-path entry points
     int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation, 2 = the same with hi + lo fp16 weight planes, 3 = f32 tensors, hi + lo split of BOTH operands on the fp16 MFMA (wide layers; the others stay f32)

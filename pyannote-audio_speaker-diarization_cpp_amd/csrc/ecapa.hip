@@ -408,6 +408,8 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
 {
     if (items <= 0) return SD_OK;
     int64_t nb = c->emb_batch_items;
+    if (!c->emb_batch_explicit && c->embed_calls == 0 && nb > 768) nb = 768;      // first call of a context: the small arena (common.h)
+    c->embed_calls++;
     nb = (nb / 96) * 96; if (nb < 96) nb = 96;
     int rc;
     // front end for the whole range first: items that are NaN by rule (sd.cpp:2479-2549) are dropped here, so the
