@@ -261,7 +261,11 @@ int finalize(sd_ctx* c, const float* d_seg, const float* d_emb, int64_t chunks, 
     for (int h : hard) if (h > Kr) Kr = h;
     Kr += 1;                                                                  // sd.cpp:2803-2812
     if ((rc = run_reconstruct(c, d_seg, d_nact, d_hard, d_count, nf, chunks, n, Kr, v))) return rc;
-    if (!c->dump_dir.empty() && (rc = write_step_dumps(c, d_seg, d_emb, chunks, n, hard, Kr))) return rc;
+    if (!c->dump_dir.empty()) {
+        rc = write_step_dumps(c, d_seg, d_emb, chunks, n, hard, Kr);
+        c->stash.infer_items = 0;            // the per-batch files describe the inference that led to THIS finalize only
+        if (rc) return rc;
+    }
     // per-turn confidence: mean soft score (2 - cosine distance to the centroid, sd.cpp:2191-2207) of the
     // (chunk, local speaker) items assigned to the turn's cluster whose 5 s chunk [0.5 c, 0.5 c + 5) overlaps the turn
     { KernelStat& ks = c->stats["clusters_K"]; ks.launches++; ks.flops += (double)Kr; ks.bytes += (double)v.size(); }       // bench: K and turns per job
