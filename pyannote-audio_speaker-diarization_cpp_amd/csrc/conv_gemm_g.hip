@@ -36,7 +36,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define G_STRIP 4096           // epilogue strip per wave: 16 rows x 128 channels of fp16 (128 + 32 KB = all of the CU's LDS)
 
 #ifndef SD_G_ABLATE
-#define SD_G_ABLATE 0          // diagnostic builds only: 1 no output stores, 2 no DMA in the loop, 4 no MFMA, 8 no A-operand DMA, 16 no W-operand DMA
+#define SD_G_ABLATE 0          // diagnostic builds only: 1 no output stores, 2 no DMA in the loop, 4 no MFMA, 8 no A-operand DMA, 16 no W-operand DMA, 32 no fragment reads
 #endif
 typedef __attribute__((address_space(3))) char lds_char;
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -103,6 +103,17 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
     const int lrow = lane >> 3, pc = lane & 7;
     auto l_row = [&](int p) { return wid * 32 + p * 8 + lrow; };
     auto l_chunk = [&](int p) { return pc ^ ((((p & 1) << 2) + (lane >> 4)) & 7); };          // ((Rp >> 1) & 7) = 4 (p & 1) + (lane >> 4)
+    // Activation rows (option conv_rot, same LDS image): piece p of wave `wid` covers rows 64 ((rot + p) & 3) + 8 wid + (l >> 3), so the
+    // eight waves' p-th pieces together are one 64-row quarter of the tile, and the PN workgroups that share a row panel (same XCD, same
+    // K-step) start with DIFFERENT quarters: each line of the panel is first requested by one of them and is on its way (or in the L2)
+    // when the others ask -- a CU keeps ~16 KB of requests in flight, so what a K-step costs is the latency its lines see.  Measured on the
+    // planted hour (profiles/r04_g256_request_order.txt): tdnn 749 -> 812 TF on one box, 883 -> 922 on another; MFA + 1 %.  [Requesting the own
+    // quarter of step s + 3 one step early on top of it (into the idle strip area, only to warm the L2): no further gain.]
+    const int rot = a.stagger ? pn : 0;
+    auto a_quarter = [&](int p) { return a.stagger ? ((rot + p) & 3) : -1; };
+    auto l_rowA = [&](int p) { return a.stagger ? a_quarter(p) * 64 + wid * 8 + lrow : l_row(p); };
+    auto l_chunkA = [&](int p) { return a.stagger ? pc ^ ((((wid & 1) << 2) + (lane >> 4)) & 7) : l_chunk(p); };
+    auto a_lds = [&](int p) { return a.stagger ? (unsigned)(a_quarter(p) * 8192 + wid * 1024) : (unsigned)(wid * 4096 + p * 1024); };
     int rrel[4], tt[4], nd[4];
     unsigned voA[4], voB[4];
     int2 pre[4]; int pre_base = 0;
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
         const int m0 = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * GM);
         pre_base = a.rowtab[m0 < a.M ? m0 : a.M - 1].x;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { int g = m0 + l_row(p); if (g > a.M - 1) g = a.M - 1; pre[p] = a.rowtab[g]; }
+        for (int p = 0; p < 4; ++p) { int g = m0 + l_rowA(p); if (g > a.M - 1) g = a.M - 1; pre[p] = a.rowtab[g]; }
     };
     // raw buffer resource {base[31:0], base[47:32] (stride 0), bytes, flags} -- the words __builtin_amdgcn_make_buffer_rsrc builds
     auto make_rsrc = [&](const void* base, size_t bytes) {
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
             if (qr >= a.Tin) qr = 2 * (a.Tin - 1) - qr;
             if (qr < 0) qr = 0;
             if (qr > nd[p]) qr = nd[p];
-            voA[p] = (unsigned)(rrel[p] + qr) * (unsigned)a.x_ld * ES + (unsigned)l_chunk(p) * 16;
+            voA[p] = (unsigned)(rrel[p] + qr) * (unsigned)a.x_ld * ES + (unsigned)l_chunkA(p) * 16;
         }
         sB = (unsigned)(((size_t)kk * a.Cout + n0l) * a.w_ld * ES);
     };
@@ -170,14 +181,14 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
     const unsigned lds0 = (unsigned)(size_t)(lds_char*)lds;
     auto dma_piece = [&](int st, int p) {            // piece p of 8: A pieces 0..3, W pieces 4..7
         const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE + wid * 4096));
-        if (p < 4) lds_dma_b128(rA, base + p * 1024, voA[p], sK);
+        if (p < 4) lds_dma_b128(rA, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE) + a_lds(p)), voA[p], sK);
         else lds_dma_b128(rB, base + G_BOFF + (p - 4) * 1024, voB[p - 4], sB + sK);
     };
     auto dma = [&](int st) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE + wid * 4096));
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            if (!(SD_G_ABLATE & 8)) lds_dma_b128(rA, base + p * 1024, voA[p], sK);
+            if (!(SD_G_ABLATE & 8)) lds_dma_b128(rA, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE) + a_lds(p)), voA[p], sK);
             if (!(SD_G_ABLATE & 16)) lds_dma_b128(rB, base + G_BOFF + p * 1024, voB[p], sB + sK);
         }
     };
@@ -197,6 +208,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
     const char* const Bfr = lds + G_BOFF + (wc * 128 + li) * 128;
     float4 ha[2][2], hb[2][4];
     auto hfrag = [&](int st, int kb, int fbuf) {
+        if (SD_G_ABLATE & 32) return;   // ablation (diagnostic builds only): no fragment reads, the matrix pipe runs on whatever the registers hold
         const int co = ((P == 0 ? 4 * lh + kb : 2 * kb + lh) ^ swz) * 16 + st * G_STAGE;
         ha[fbuf][0] = *(const float4*)(Afr + co);
         ha[fbuf][1] = *(const float4*)(Afr + co + 32 * 128);
@@ -465,6 +477,7 @@ int launch_conv_gemm_g256(sd_ctx* c, const ConvArgs& in, const char* tag)
     a.m_tiles = (a.M + GM - 1) / GM;
     a.n_tiles = (a.Cout + GN - 1) / GN;
     a.sched = c->conv_pn;
+    a.stagger = c->conv_rot;
     int grid = (c->num_cu / 8) * 8;
     if (grid < 8) grid = 8;
     const int lx_max = ((a.m_tiles + 7) / 8) * a.n_tiles;

@@ -363,6 +363,9 @@ def test_ecapa_fp16_wide_tile_kernel_gives_the_same_bits(diarizer):
     assert np.isfinite(e_wide).all() and np.array_equal(e_wide, e_128)
 
 
+CONV_ROT_DEFAULT = 1
+
+
 def test_ecapa_fp16_lds_dma_staged_kernel_gives_the_same_bits(diarizer):
     """fp16 mode: the LDS-DMA staged 256 x 256 kernel (conv_gemm_g.hip: buffer_load ... lds into a swizzled, unpadded LDS image, two
     K-steps in flight) against the register-staged one (conv_gemm_h.hip): same k-blocks into the same MFMA chain in the same order --
@@ -376,12 +379,19 @@ def test_ecapa_fp16_lds_dma_staged_kernel_gives_the_same_bits(diarizer):
         diarizer.set_option("conv_glds", 1)
         e_dma = diarizer.ecapa(feats, lens)
         e_dma2 = diarizer.ecapa(feats, lens)
+        e_rot = []
+        for rot in (0, 1):          # request order of a row panel's quarters / the early request of the own quarter: the same LDS image
+            diarizer.set_option("conv_rot", rot)
+            e_rot += [diarizer.ecapa(feats, lens), diarizer.ecapa(feats, lens)]
         diarizer.set_option("conv_glds", 0)
         e_reg = diarizer.ecapa(feats, lens)
     finally:
         diarizer.set_option("conv_glds", 1)
+        diarizer.set_option("conv_rot", CONV_ROT_DEFAULT)
         diarizer.set_option("ecapa_precision", 0)
     assert np.isfinite(e_dma).all() and np.array_equal(e_dma, e_reg) and np.array_equal(e_dma, e_dma2)
+    for e in e_rot:
+        assert np.array_equal(e, e_reg)
 
 
 def test_ecapa_bits_do_not_depend_on_how_many_items_share_a_batch(diarizer):
