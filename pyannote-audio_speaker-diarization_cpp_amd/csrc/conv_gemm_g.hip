@@ -109,11 +109,20 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
     // when the others ask -- a CU keeps ~16 KB of requests in flight, so what a K-step costs is the latency its lines see.  Measured on the
     // planted hour (profiles/r04_g256_request_order.txt): tdnn 749 -> 812 TF on one box, 883 -> 922 on another; MFA + 1 %.  [Requesting the own
     // quarter of step s + 3 one step early on top of it (into the idle strip area, only to warm the L2): no further gain.]
-    const int rot = a.stagger ? pn : 0;
-    auto a_quarter = [&](int p) { return a.stagger ? ((rot + p) & 3) : -1; };
-    auto l_rowA = [&](int p) { return a.stagger ? a_quarter(p) * 64 + wid * 8 + lrow : l_row(p); };
-    auto l_chunkA = [&](int p) { return a.stagger ? pc ^ ((((wid & 1) << 2) + (lane >> 4)) & 7) : l_chunk(p); };
-    auto a_lds = [&](int p) { return a.stagger ? (unsigned)(a_quarter(p) * 8192 + wid * 1024) : (unsigned)(wid * 4096 + p * 1024); };
+    const int rot = (a.stagger & 1) ? pn : 0;
+    auto a_quarter = [&](int p) { return (a.stagger & 1) ? ((rot + p) & 3) : -1; };
+    auto l_rowA = [&](int p) { return (a.stagger & 1) ? a_quarter(p) * 64 + wid * 8 + lrow : l_row(p); };
+    auto l_chunkA = [&](int p) { return (a.stagger & 1) ? pc ^ ((((wid & 1) << 2) + (lane >> 4)) & 7) : l_chunk(p); };
+    // the same for the weight rows among the PM workgroups that share a column panel (MFA's 6 MB column panel does not stay in a 4 MB L2: + 1.5 - 2 % there)
+    const bool rotB = (a.stagger & 1) != 0;
+    auto b_quarter = [&](int p) { return (pm + p) & 3; };
+    auto l_rowB = [&](int p) { return rotB ? b_quarter(p) * 64 + wid * 8 + lrow : l_row(p); };
+    auto l_chunkB = [&](int p) { return rotB ? pc ^ ((((wid & 1) << 2) + (lane >> 4)) & 7) : l_chunk(p); };
+    auto b_lds = [&](int p) { return rotB ? (unsigned)(b_quarter(p) * 8192 + wid * 1024) : (unsigned)(wid * 4096 + p * 1024); };
+    auto a_lds = [&](int p) { return (a.stagger & 1) ? (unsigned)(a_quarter(p) * 8192 + wid * 1024) : (unsigned)(wid * 4096 + p * 1024); };
+    unsigned a_off[4], b_off[4];          // wave-uniform LDS offsets of the pieces inside a stage (SGPRs)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { a_off[p] = __builtin_amdgcn_readfirstlane(a_lds(p)); b_off[p] = __builtin_amdgcn_readfirstlane((unsigned)G_BOFF + b_lds(p)); }
     int rrel[4], tt[4], nd[4];
     unsigned voA[4], voB[4];
     int2 pre[4]; int pre_base = 0;
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
     v4i rA = make_rsrc(a.X, 0);
     const v4i rB = make_rsrc(P == 0 ? (const void*)a.W : a.W16, (size_t)a.KT * a.Cout * a.w_ld * ES);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)(l_row(p) * a.w_ld * ES + l_chunk(p) * 16);
+    for (int p = 0; p < 4; ++p) voB[p] = (unsigned)(l_rowB(p) * a.w_ld * ES + l_chunkB(p) * 16);
     int l_q = q0, l_kk = 0, l_kc = 0, m0l = 0, n0l = 0;
     unsigned sK = 0, sB = 0;
     auto set_tile = [&](int sb) {
@@ -180,16 +189,16 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
     // eight LDS-DMA instructions per wave and K-step: four 1 KB pieces of A, four of B
     const unsigned lds0 = (unsigned)(size_t)(lds_char*)lds;
     auto dma_piece = [&](int st, int p) {            // piece p of 8: A pieces 0..3, W pieces 4..7
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE + wid * 4096));
-        if (p < 4) lds_dma_b128(rA, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE) + a_lds(p)), voA[p], sK);
-        else lds_dma_b128(rB, base + G_BOFF + (p - 4) * 1024, voB[p - 4], sB + sK);
+        const unsigned stb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE));
+        if (p < 4) lds_dma_b128(rA, stb + a_off[p], voA[p], sK);
+        else lds_dma_b128(rB, stb + b_off[p - 4], voB[p - 4], sB + sK);
     };
     auto dma = [&](int st) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE + wid * 4096));
+        const unsigned stb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE));
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            if (!(SD_G_ABLATE & 8)) lds_dma_b128(rA, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE) + a_lds(p)), voA[p], sK);
-            if (!(SD_G_ABLATE & 16)) lds_dma_b128(rB, base + G_BOFF + p * 1024, voB[p], sB + sK);
+            if (!(SD_G_ABLATE & 8)) lds_dma_b128(rA, stb + a_off[p], voA[p], sK);
+            if (!(SD_G_ABLATE & 16)) lds_dma_b128(rB, stb + b_off[p], voB[p], sB + sK);
         }
     };
 
