@@ -111,7 +111,8 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "conv_h256") c->conv_h256 = v != 0;
     else if (k == "conv_glds") c->conv_glds = v != 0;
     else if (k == "conv_glds_f32") c->conv_glds_f32 = v != 0;
-    else if (k == "conv_rot") { if (v < 0 || v > 1) return SD_ERR_ARG; c->conv_rot = (int)v; }
+    else if (k == "conv_mfma16") { if (v < 0 || v > 1) return SD_ERR_ARG; c->conv_mfma16 = (int)v; }
+    else if (k == "conv_rot") { if (v < 0 || v > 3) return SD_ERR_ARG; c->conv_rot = (int)v; }
     else if (k == "conv_stagger") { if (v < 0 || v > 2) return SD_ERR_ARG; c->conv_stagger = (int)v; }
     else if (k == "conv_w256_f32") c->conv_w256_f32 = v != 0;
     else if (k == "conv_pn") c->conv_pn = (int)v;

@@ -156,7 +156,8 @@ struct sd_ctx {
     int conv_w256_kmin = 0;                     // 256 x 256 kernel: shortest contraction Cin * KT it takes (0 = built-in: 1024 f32, 256 fp16); tuning
     int conv_pn = 0;                            // 256 x 256 kernel: column tiles per super-block (0 = 8); tuning
     bool conv_h256 = true;                      // fp16 mode: 256 x 256 tile kernel for the wide layers (conv_gemm_h.hip)
-    int conv_rot = 1;                           // LDS-DMA wide kernel: the workgroups that share a row panel request its quarters in rotated order (conv_gemm_g.hip); tuning
+    int conv_mfma16 = 1;                        // fp16 LDS-DMA wide kernel on v_mfma_f32_16x16x32_f16 (higher clock under load) instead of 32x32x16; conv_gemm_g.hip
+    int conv_rot = 3;                           // LDS-DMA wide kernel: the workgroups that share a row panel request its quarters in rotated order (conv_gemm_g.hip); tuning
     int conv_stagger = 0;                       // 128 x 128 f32 kernel: start half of the workgroups half a tile late (0 off, 1 odd, 2 upper half); tuning
     bool conv_glds_f32 = false;                 // f32: the LDS-DMA staged form of the wide tile (conv_gemm_g.hip, P = 0): bit-identical, measured slower; A-B only
     bool conv_glds = true;                      // fp16 mode: ... staged by LDS-DMA (conv_gemm_g.hip) instead of through registers; tuning / A-B

@@ -26,6 +26,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
@@ -36,7 +37,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define G_STRIP 4096           // epilogue strip per wave: 16 rows x 128 channels of fp16 (128 + 32 KB = all of the CU's LDS)
 
 #ifndef SD_G_ABLATE
-#define SD_G_ABLATE 0          // diagnostic builds only: 1 no output stores, 2 no DMA in the loop, 4 no MFMA, 8 no A-operand DMA, 16 no W-operand DMA, 32 no fragment reads
+#define SD_G_ABLATE 0          // diagnostic builds only: 1 no output stores, 2 no DMA in the loop, 4 no MFMA, 8 no A-operand DMA, 16 no W-operand DMA, 32 no fragment reads, 64 the DMAs of a K-step issued by four waves instead of eight
 #endif
 typedef __attribute__((address_space(3))) char lds_char;
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -110,16 +111,22 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
     // planted hour (profiles/r04_g256_request_order.txt): tdnn 749 -> 812 TF on one box, 883 -> 922 on another; MFA + 1 %.  [Requesting the own
     // quarter of step s + 3 one step early on top of it (into the idle strip area, only to warm the L2): no further gain.]
     const int rot = (a.stagger & 1) ? pn : 0;
-    auto a_quarter = [&](int p) { return (a.stagger & 1) ? ((rot + p) & 3) : -1; };
-    auto l_rowA = [&](int p) { return (a.stagger & 1) ? a_quarter(p) * 64 + wid * 8 + lrow : l_row(p); };
+    // bit 1: a wave's pieces 0, 1 (and 2, 3) lie 32 rows apart in ONE quarter, waves 0-3 and 4-7 take different quarters.  With the DMAs alone in the
+    // loop (no MFMA, no fragment reads) a K-step of the tdnn layers takes 3 390 cycles in this order against 4 180 (MFA 2 910 / 3 400); the whole
+    // kernel gains 2 - 5 % on tdnn (profiles/r04_g256_request_order.txt, section 6)
+    const bool pairmap = (a.stagger & 2) != 0;
+    auto qidx = [&](int p) { return pairmap ? (wid >> 2) + 2 * (p >> 1) : p; };
+    auto rinq = [&](int p) { return pairmap ? 8 * (wid & 3) + 32 * (p & 1) : 8 * wid; };
+    auto a_quarter = [&](int p) { return (rot + qidx(p)) & 3; };
+    auto l_rowA = [&](int p) { return (a.stagger & 1) ? a_quarter(p) * 64 + rinq(p) + lrow : l_row(p); };
     auto l_chunkA = [&](int p) { return (a.stagger & 1) ? pc ^ ((((wid & 1) << 2) + (lane >> 4)) & 7) : l_chunk(p); };
     // the same for the weight rows among the PM workgroups that share a column panel (MFA's 6 MB column panel does not stay in a 4 MB L2: + 1.5 - 2 % there)
     const bool rotB = (a.stagger & 1) != 0;
-    auto b_quarter = [&](int p) { return (pm + p) & 3; };
-    auto l_rowB = [&](int p) { return rotB ? b_quarter(p) * 64 + wid * 8 + lrow : l_row(p); };
+    auto b_quarter = [&](int p) { return (pm + qidx(p)) & 3; };
+    auto l_rowB = [&](int p) { return rotB ? b_quarter(p) * 64 + rinq(p) + lrow : l_row(p); };
     auto l_chunkB = [&](int p) { return rotB ? pc ^ ((((wid & 1) << 2) + (lane >> 4)) & 7) : l_chunk(p); };
-    auto b_lds = [&](int p) { return rotB ? (unsigned)(b_quarter(p) * 8192 + wid * 1024) : (unsigned)(wid * 4096 + p * 1024); };
-    auto a_lds = [&](int p) { return (a.stagger & 1) ? (unsigned)(a_quarter(p) * 8192 + wid * 1024) : (unsigned)(wid * 4096 + p * 1024); };
+    auto b_lds = [&](int p) { return rotB ? (unsigned)(b_quarter(p) * 8192 + rinq(p) * 128) : (unsigned)(wid * 4096 + p * 1024); };
+    auto a_lds = [&](int p) { return (a.stagger & 1) ? (unsigned)(a_quarter(p) * 8192 + rinq(p) * 128) : (unsigned)(wid * 4096 + p * 1024); };
     unsigned a_off[4], b_off[4];          // wave-uniform LDS offsets of the pieces inside a stage (SGPRs)
 #pragma unroll
     for (int p = 0; p < 4; ++p) { a_off[p] = __builtin_amdgcn_readfirstlane(a_lds(p)); b_off[p] = __builtin_amdgcn_readfirstlane((unsigned)G_BOFF + b_lds(p)); }
@@ -195,6 +202,18 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
     };
     auto dma = [&](int st) {
         const unsigned stb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(st * G_STAGE));
+        if (SD_G_ABLATE & (64 | 128 | 256)) {   // ablation (diagnostic builds only; meaningful with 4 + 32): the 64 DMAs of a K-step issued by 4 / 2 / 1 waves instead of eight
+            constexpr int NW = (SD_G_ABLATE & 64) ? 4 : (SD_G_ABLATE & 128) ? 2 : 1;
+            if (wid < NW) {
+#pragma unroll
+                for (int it = 0; it < 4 * (8 / NW); ++it) {
+                    const int k = (SD_G_ABLATE & 512) ? it % (8 / NW) : it / 4, p = (SD_G_ABLATE & 512) ? it / (8 / NW) : it % 4;      // 512: piece-major order
+                    lds_dma_b128(rA, stb + a_off[p] + k * NW * 1024, voA[p] + (unsigned)(k * NW * 8) * (unsigned)a.x_ld * ES, sK);
+                    lds_dma_b128(rB, stb + b_off[p] + k * NW * 1024, voB[p] + (unsigned)(k * NW * 8) * (unsigned)a.w_ld * ES, sB + sK);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if (!(SD_G_ABLATE & 8)) lds_dma_b128(rA, stb + a_off[p], voA[p], sK);
@@ -216,15 +235,54 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
     const char* const Afr = lds + (wr * 64 + li) * 128;
     const char* const Bfr = lds + G_BOFF + (wc * 128 + li) * 128;
     float4 ha[2][2], hb[2][4];
+    // P = 2: v_mfma_f32_16x16x32_f16 (the chip holds 2.09 GHz on it against 1.79 on the 32x32x16 shape, tools/mfma_shape_clock.hip).  The wave's
+    // 64 x 128 tile is 4 x 8 blocks of 16 x 16 (acc16, 128 registers); a K-step is two k-groups of 32 halves, each walked in two phases of
+    // 4 x 4 blocks: phase kb = 2 g + h reads the weight fragments of blocks 4 h .. 4 h + 3 (and, for h = 0, the four activation fragments
+    // of group g, kept for both phases).  Lane l reads k = 32 g + 8 (l >> 4) .. + 7 (logical chunk 4 g + (l >> 4)) of row l & 15 of a block;
+    // with the stage's swizzle every 16-lane group of the ds_read_b128 covers the sixteen (128-byte half, chunk) slots once.
+    f32x4 acc16[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc16[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const char* const Afr16 = lds + (wr * 64 + l15) * 128;
+    const char* const Bfr16 = lds + G_BOFF + (wc * 128 + l15) * 128;
+    float4 qa[2][4], qb[2][4];
     auto hfrag = [&](int st, int kb, int fbuf) {
         if (SD_G_ABLATE & 32) return;   // ablation (diagnostic builds only): no fragment reads, the matrix pipe runs on whatever the registers hold
+        if constexpr (P == 2) {
+            const int g = kb >> 1, h = kb & 1;
+            const int co = ((4 * g + l4) ^ ((l15 >> 1) & 7)) * 16 + st * G_STAGE;
+            if (h == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qa[g][i] = *(const float4*)(Afr16 + co + i * 16 * 128);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) qb[fbuf][jj] = *(const float4*)(Bfr16 + co + (4 * h + jj) * 16 * 128);
+            return;
+        }
         const int co = ((P == 0 ? 4 * lh + kb : 2 * kb + lh) ^ swz) * 16 + st * G_STAGE;
         ha[fbuf][0] = *(const float4*)(Afr + co);
         ha[fbuf][1] = *(const float4*)(Afr + co + 32 * 128);
 #pragma unroll
         for (int j = 0; j < 4; ++j) hb[fbuf][j] = *(const float4*)(Bfr + co + j * 32 * 128);
     };
-    auto hmma = [&](int fbuf) {
+    auto hmma = [&](int fbuf, int kb) {
+        if constexpr (P == 2) {
+            if (SD_G_ABLATE & 4) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { asm volatile("" :: "v"(qb[fbuf][jj].x), "v"(qb[fbuf][jj].w), "v"(qa[kb >> 1][jj].x), "v"(qa[kb >> 1][jj].w)); }
+                return;
+            }
+            const int g = kb >> 1, h = kb & 1;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc16[i][4 * h + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, qa[g][i]), __builtin_bit_cast(half8, qb[fbuf][jj]), acc16[i][4 * h + jj], 0, 0, 0);
+            return;
+        }
         if (SD_G_ABLATE & 4) {          // ablation (diagnostic builds only): fragment reads without the matrix pipe
 #pragma unroll
             for (int j = 0; j < 4; ++j) { asm volatile("" :: "v"(hb[fbuf][j].x), "v"(hb[fbuf][j].y), "v"(hb[fbuf][j].z), "v"(hb[fbuf][j].w)); }
@@ -278,7 +336,8 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
     while (true) {
 #define W_PAIR(mask, n) do { _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); } } while (0)
         // K-groups 0..2 of step s from stage `buf`; each group's fragments were read while the group before ran
-        constexpr int REST = P == 0 ? 26 : 2;        // MFMAs of a K-group behind the six that carry the next group's fragment reads
+        // MFMAs of a phase: the first carry the next phase's fragment reads (P = 2: four reads when the next phase keeps its activation fragments, eight otherwise)
+        constexpr int NM = P == 0 ? 32 : P == 1 ? 8 : 16, NR_ODD = P == 2 ? 4 : 6, NR_EVEN = P == 2 ? 8 : 6;
         if constexpr (P == 0) {
             if (s == S - 1 && wid < 4) {
                 const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(2 * G_STAGE + wid * 256));
@@ -288,16 +347,16 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
             }
         }
         hfrag(buf, 1, 1);
-        hmma(0);
-        W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
+        hmma(0, 0);
+        W_PAIR(0x100, NR_ODD); __builtin_amdgcn_sched_group_barrier(0x008, NM - NR_ODD, 0);
         __builtin_amdgcn_sched_barrier(0);
         hfrag(buf, 2, 0);
-        hmma(1);
-        W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
+        hmma(1, 1);
+        W_PAIR(0x100, NR_EVEN); __builtin_amdgcn_sched_group_barrier(0x008, NM - NR_EVEN, 0);
         __builtin_amdgcn_sched_barrier(0);
         hfrag(buf, 3, 1);
-        hmma(0);
-        W_PAIR(0x100, 6); __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
+        hmma(0, 2);
+        W_PAIR(0x100, NR_ODD); __builtin_amdgcn_sched_group_barrier(0x008, NM - NR_ODD, 0);
         __builtin_amdgcn_sched_barrier(0);
         // stage `buf` has been read out (this wave's last fragments of it are in registers once lgkmcnt reaches 0) and this wave's
         // share of step s + 1 has landed in the other stage (vmcnt(0)): behind the barrier that holds for every wave
@@ -325,7 +384,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
         } else {
             if (!(SD_G_ABLATE & 2)) dma(buf);            // step s + 2 into the stage just released
             hfrag(buf ^ 1, 0, 0);
-            hmma(1);
+            hmma(1, 3);
         }
         __builtin_amdgcn_sched_barrier(0);
         advance();
@@ -370,6 +429,64 @@ __global__ __launch_bounds__(512) void k_conv_gemm_g256(ConvArgs a)
                         }
                         const unsigned vo = (unsigned)(wr * 64 + i * 32 + li) * ybytes + (unsigned)(n0c + cl) * 4u;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rY, vo, 0, 0);
+                    }
+                }
+            }
+            } else if constexpr (P == 2) {
+            // ---- epilogue, 16 x 16 blocks.  C layout: register r of acc16[i][j], lane l = row 16 i + 4 (l >> 4) + r, column 16 j + (l & 15).
+            // Same passage as the 32 x 32 form below: bias / activation / BatchNorm per value, a 4 x 4 transpose across the lane quad (four
+            // consecutive columns of one row per lane), the wave's 4 KB strip sixteen rows (one i) at a time, whole rows back, 16-byte stores.
+            const float slope = (a.act1 == 1) ? 0.0f : ((a.act1 == 2) ? 0.01f : 1.0f);
+            const int lq = lane & 3;
+            _Float16* const Y = (_Float16*)a.Y;
+            char* const strip = lds + 2 * G_STAGE + wid * G_STRIP;               // [16 rows][256 bytes], 16-byte chunk c of row r at c ^ r
+            float cb[8], cs[8], ch[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int cc = n0c + wc * 128 + j * 16 + l15;
+                cb[j] = a.bias ? a.bias[cc] : 0.0f;
+                cs[j] = a.scale ? a.scale[cc] : 1.0f; ch[j] = a.scale ? a.shift[cc] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc16[i][j][e] + cb[j];
+                        acc16[i][j][e] = 0.0f;
+                        v = fmaxf(v, v * slope);
+                        x[e] = v * cs[j] + ch[j];
+                    }
+                    float s0 = (lq & 1) ? x[0] : x[1];
+                    float s1 = (lq & 1) ? x[2] : x[3];
+                    float r0_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xF, 0xF, true));
+                    float r1_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xF, 0xF, true));
+                    if (lq & 1) { x[0] = r0_; x[2] = r1_; } else { x[1] = r0_; x[3] = r1_; }
+                    s0 = (lq & 2) ? x[0] : x[2];
+                    s1 = (lq & 2) ? x[1] : x[3];
+                    r0_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0x4E, 0xF, 0xF, true));
+                    r1_ = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0x4E, 0xF, 0xF, true));
+                    if (lq & 2) { x[0] = r0_; x[1] = r1_; } else { x[2] = r0_; x[3] = r1_; }
+                    // the lane now holds row 4 (l >> 4) + lq of the block, columns 16 j + (l15 & ~3) .. + 3
+                    const int sr = 4 * l4 + lq;
+                    if (a.y_f32) {
+                        const int g = m0c + wr * 64 + i * 16 + sr;
+                        const int co = n0c + wc * 128 + j * 16 + (l15 & ~3);
+                        if (g < a.M) *(float4*)(a.Y + (size_t)g * a.y_ld + co) = make_float4(x[0], x[1], x[2], x[3]);
+                    } else {
+                        const half4 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+                        *(half4*)(strip + sr * 256 + (((2 * j + (l15 >> 3)) ^ sr) * 16) + ((l15 >> 2) & 1) * 8) = hv;
+                    }
+                }
+                if (!a.y_f32) {
+                    const int c16 = lane & 15, rr = lane >> 4;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float4 v = *(const float4*)(strip + (4 * t + rr) * 256 + ((c16 ^ (4 * t + rr)) * 16));
+                        const int g = m0c + wr * 64 + i * 16 + 4 * t + rr;
+                        if (g < a.M) *(float4*)(Y + (size_t)g * a.y_ld + n0c + wc * 128 + c16 * 8) = v;
                     }
                 }
             }
@@ -479,6 +596,7 @@ int launch_conv_gemm_g256(sd_ctx* c, const ConvArgs& in, const char* tag)
     const size_t lds_bytes = (size_t)2 * G_STAGE + 8 * G_STRIP;       // (f32: 3 KB of parameters where the fp16 form keeps its strips)
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)k_conv_gemm_g256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_gemm_g256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_conv_gemm_g256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
         attr_set = true;
     }
@@ -499,7 +617,8 @@ int launch_conv_gemm_g256(sd_ctx* c, const ConvArgs& in, const char* tag)
         ProfScope ps16(c, h ? "conv_gemm_f16" : "conv_gemm_f32", flops, bytes);
         ProfScope psw(c, h ? "conv_w256_f16" : "conv_w256_f32", flops, bytes);         // this tile form alone (bench.py's roofline object)
         ProfScope pss(c, strcmp(tag, "lstm_ih") == 0 ? "conv_w256_seg" : "conv_w256_ecapa", flops, bytes);
-        if (h) hipLaunchKernelGGL(k_conv_gemm_g256<1>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
+        if (h && c->conv_mfma16) hipLaunchKernelGGL(k_conv_gemm_g256<2>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
+        else if (h) hipLaunchKernelGGL(k_conv_gemm_g256<1>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
         else hipLaunchKernelGGL(k_conv_gemm_g256<0>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
     }
     if (hipGetLastError() != hipSuccess) SD_FAIL(c, SD_ERR_HIP, "k_conv_gemm_g256 launch failed (%s)", tag);

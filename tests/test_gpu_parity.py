@@ -363,35 +363,48 @@ def test_ecapa_fp16_wide_tile_kernel_gives_the_same_bits(diarizer):
     assert np.isfinite(e_wide).all() and np.array_equal(e_wide, e_128)
 
 
-CONV_ROT_DEFAULT = 1
+CONV_ROT_DEFAULT = 3
 
 
 def test_ecapa_fp16_lds_dma_staged_kernel_gives_the_same_bits(diarizer):
     """fp16 mode: the LDS-DMA staged 256 x 256 kernel (conv_gemm_g.hip: buffer_load ... lds into a swizzled, unpadded LDS image, two
-    K-steps in flight) against the register-staged one (conv_gemm_h.hip): same k-blocks into the same MFMA chain in the same order --
-    bit-identical embeddings on ragged items (row tables, reflect padding, clamped taps, partly filled last tiles), run twice (a DMA
-    that lands late would show as a run-to-run difference)"""
+    K-steps in flight) in its 32x32x16 form (conv_mfma16 = 0) against the register-staged one (conv_gemm_h.hip): same k-blocks into the
+    same MFMA chain in the same order -- bit-identical embeddings on ragged items (row tables, reflect padding, clamped taps, partly
+    filled last tiles), run twice (a DMA that lands late would show as a run-to-run difference).  The default form runs the same stages
+    through v_mfma_f32_16x16x32_f16 (32 k per instruction instead of 16: the f32 accumulation is grouped differently, so its bits are its
+    own): bit-identical to itself across runs and across the request orders of conv_rot, and within rounding of the 32x32x16 form."""
     rng = np.random.default_rng(31)
     lens = np.array([1.0, 0.5, 0.25, 0.9, 0.7, 0.33, 1.0, 0.6, 0.8, 0.45, 0.12, 1.0, 0.77, 0.05, 0.95, 0.5, 0.61, 1.0, 0.29, 0.83], np.float32)
     feats = (3.0 * rng.standard_normal((len(lens), 501, 80))).astype(np.float32)
     diarizer.set_option("ecapa_precision", 1)
     try:
         diarizer.set_option("conv_glds", 1)
+        diarizer.set_option("conv_mfma16", 0)
         e_dma = diarizer.ecapa(feats, lens)
         e_dma2 = diarizer.ecapa(feats, lens)
-        e_rot = []
-        for rot in (0, 1):          # request order of a row panel's quarters / the early request of the own quarter: the same LDS image
-            diarizer.set_option("conv_rot", rot)
-            e_rot += [diarizer.ecapa(feats, lens), diarizer.ecapa(feats, lens)]
+        e_rot = {0: [], 1: []}
+        for m16 in (0, 1):
+            diarizer.set_option("conv_mfma16", m16)
+            for rot in (0, 1, 3):          # request order of a panel's quarters / which rows a wave's pieces cover: the same LDS image
+                diarizer.set_option("conv_rot", rot)
+                e_rot[m16] += [diarizer.ecapa(feats, lens), diarizer.ecapa(feats, lens)]
         diarizer.set_option("conv_glds", 0)
         e_reg = diarizer.ecapa(feats, lens)
     finally:
         diarizer.set_option("conv_glds", 1)
+        diarizer.set_option("conv_mfma16", 1)
         diarizer.set_option("conv_rot", CONV_ROT_DEFAULT)
         diarizer.set_option("ecapa_precision", 0)
     assert np.isfinite(e_dma).all() and np.array_equal(e_dma, e_reg) and np.array_equal(e_dma, e_dma2)
-    for e in e_rot:
+    for e in e_rot[0]:
         assert np.array_equal(e, e_reg)
+    e16 = e_rot[1][0]
+    for e in e_rot[1]:
+        assert np.array_equal(e, e16)
+    assert np.isfinite(e16).all()
+    cosd = 1.0 - (e16 * e_reg).sum(1) / np.sqrt((e16 * e16).sum(1) * (e_reg * e_reg).sum(1))
+    print("16x16x32 against 32x32x16: max cosine distance %.2e, max |diff| / max |e| %.2e" % (cosd.max(), np.abs(e16 - e_reg).max() / np.abs(e_reg).max()))
+    assert cosd.max() < 1e-5 and np.abs(e16 - e_reg).max() < 2e-3 * np.abs(e_reg).max()
 
 
 def test_ecapa_bits_do_not_depend_on_how_many_items_share_a_batch(diarizer):
