@@ -495,7 +495,10 @@ def main():
             fence()
         else:
             share_note = "balanced share %d per mille needs chunks outside what a rank synthesised: equal shares kept" % pm_new
-    for _ in range(max(0, a.warmup - 1)):
+    # W untimed warm-up steps BEHIND the cold job (which is a measurement of its own, `value_cold`, not a warm-up: a context's first embedding call plans
+    # small batches so that a one-shot CLI process does not pay ~1.6 s of hipMalloc for the full activation arena, and the SECOND job grows it --
+    # + 8 ms at 1 h, + 1.7 s at the 8-h size; with the cold job counted as a warm-up that growth fell into the first timed step of `--warmup 1` runs)
+    for _ in range(max(0, a.warmup)):
         step()
     d.set_option("profile", 1)
     d.reset_stats()
