@@ -653,7 +653,7 @@ def main():
                                                  "profiles/r04_g256_ablation.txt, r04_g256_request_order.txt)",
                                                  "BASELINE configs[4]: the same job with the per-frame ECAPA layers on the fp16 MFMA (fp16 weights and activations, f32 accumulation); "
                                                  "secondary mode, never the headline value", 1)
-        if a.precision == "f32" and a.fp16_steps > 0 and planted and "fp16" in extra_lines:
+        if a.precision == "f32" and a.fp16_steps > 0 and planted and "fp16" in extra_lines and a.hours_per_gpu <= 2.0:        # (a second context: beside an 8-h job's 80 GB distance matrix the two activation arenas run the GPU out of memory)
             # BASELINE configs[4]'s tolerance on a network whose SE gates are NOT saturated: the same seeded conv weights with BatchNorm statistics learnt from one
             # calibration batch (oracle/nn_oracle.calibrated_embedding_weights; the plain pack above is the stress case: BN = identity, gates pinned at 0 / 1)
             try:
