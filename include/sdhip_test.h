@@ -47,6 +47,8 @@ int sd_test_pack_split_weights(const float* w, int K, int Cout, int CinPad, int 
  * "seg_shared_conv0" (1 = SincNet's first convolution once over the waveform instead of once per overlapping chunk), "seg_wide_ih" (1 = LSTM input
  * projections of layers 1-3 on the 256 x 256 tile), "linkage_square" (-1 auto, 0 condensed, 1 full N x N distance matrix), "ecapa_f16_hp" /
  * "ecapa_keep_cat" (precision diagnostics of tools/diag_fp16_layers.py). */
+/* environment (diagnostic): SD_TRACE_CREATE=1 prints where sd_create's time goes; SD_TRACE_WS=1 makes sd_diarize_dev print the job's stage times and what the
+ * process's workspace hipMalloc / hipFree calls have cost so far (count, GB, ms) with every workspace of 256 MB or more. */
 /* tuning hooks (tools/): time one conv_gemm shape on scratch data (dbg selects an ablation); time a grid barrier */
 int sd_bench_barrier(sd_ctx*, int workgroups, int iters, int dirty_doubles, double* us_per_barrier);
 int sd_bench_conv(sd_ctx*, int64_t items, int Tp, int T, int Cin, int Cout, int KT, int dil, int has_x2, int dbg, int reps, double* ms_per_launch);

@@ -1,6 +1,7 @@
 // common.h -- internal declarations shared by the HIP translation units of libsdhip.so
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -18,14 +19,23 @@
 
 struct KernelStat { double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
 
+// SD_TRACE_WS=1 (diagnostic): what the workspace allocations of a job cost -- hipMalloc / hipFree time and bytes, printed by sd_diarize*
+inline double g_ws_alloc_ms = 0.0, g_ws_free_ms = 0.0;
+inline size_t g_ws_alloc_bytes = 0, g_ws_allocs = 0;
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return 0;
+        const auto t0 = std::chrono::steady_clock::now();
         if (p) (void)hipFree(p);
+        const auto t1 = std::chrono::steady_clock::now();
         p = nullptr; cap = 0;
         size_t want = bytes + (bytes >> 3) + 256;
         if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return 1; }
+        const auto t2 = std::chrono::steady_clock::now();
+        g_ws_free_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        g_ws_alloc_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
+        g_ws_alloc_bytes += want; ++g_ws_allocs;
         cap = want; return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }

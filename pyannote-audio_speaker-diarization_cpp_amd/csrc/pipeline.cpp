@@ -344,6 +344,11 @@ extern "C" int sd_diarize_dev(sd_ctx* c, const int16_t* d_pcm, int64_t n, sd_tur
     std::vector<sd_turn> v;
     if ((rc = finalize(c, d_seg, d_emb, chunks, n, v))) return rc;
     c->stage_ms[3] = now_ms() - t0;
+    if (getenv("SD_TRACE_WS")) {
+        fprintf(stderr, "[sdhip] job %.1f ms (segmentation %.1f, embedding %.1f, finalize %.1f); workspace allocations so far in this process: %zu hipMalloc, %.2f GB, %.1f ms (+ %.1f ms hipFree)\n",
+                c->stage_ms[3], c->stage_ms[0], c->stage_ms[1], c->stage_ms[2], g_ws_allocs, (double)g_ws_alloc_bytes / 1e9, g_ws_alloc_ms, g_ws_free_ms);
+        for (const auto& kv : c->ws) if (kv.second.cap >= ((size_t)256 << 20)) fprintf(stderr, "[sdhip]   %-16s %8.2f GB\n", kv.first.c_str(), (double)kv.second.cap / 1e9);
+    }
     return turns_out(c, v, turns, n_turns);
 }
 
