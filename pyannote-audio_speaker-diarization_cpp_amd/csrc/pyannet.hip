@@ -405,14 +405,16 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
     }
     const int F = P2 > SD_FRAMES ? SD_FRAMES : P2;
     const int64_t CB = cnt;
-    WS(c, float, p0, "sg_p0", CB * P0 * 96);
-    WS(c, float, c1, "sg_c1", CB * L1 * 60);
+    // the five largest buffers of this stage share their memory with the embedding stage's activation arena (ecapa.hip: the stages never overlap --
+    // shard_infer runs them one after the other on one stream): 17 GB less to allocate on a context's first job, 16 GB less held afterwards
+    WS(c, float, p0, "ec_mfa", CB * P0 * 96);
+    WS(c, float, c1, "ec_tr", CB * L1 * 60);
     WS(c, float, p1, "sg_p1", CB * P1 * 64);
     WS(c, float, c2, "sg_c2", CB * L2 * 60);
     WS(c, float, p2, "sg_p2", CB * P2 * 64);
-    WS(c, float, G, "sg_G", CB * F * 1024);
-    WS(c, float, Ha, "sg_Ha", CB * F * 256);
-    WS(c, float, Hb, "sg_Hb", CB * F * 256);
+    WS(c, float, G, "ec_cat", CB * F * 1024);
+    WS(c, float, Ha, "ec_t2", CB * F * 256);
+    WS(c, float, Hb, "ec_x0", CB * F * 256);
     WS(c, float, y0, "sg_y0", CB * F * 128);
     WS(c, float, y1, "sg_y1", CB * F * 128);
     int rc;
