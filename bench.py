@@ -739,7 +739,7 @@ def main():
                                    "stream, clustering on rank 0, which infers %.1f %% of the chunks" % (ranges[:8], per, 100.0 * (ranges[0][1] - ranges[0][0]) / max(C, 1)),
                        "stage_ms_last_step_rank0": {"segmentation": round(stages[0], 1), "embedding": round(stages[1], 1), "finalize (count+clustering+reconstruction)": round(stages[2], 1)},
                        "cold_ms": round(cold_ms, 1),
-                       "cold_ms_covers": "sd_create (weights -> HBM; fp16 weight forms only when their mode is selected), PCM upload, %sfirst job with cold workspaces (hipMalloc of ~16 GB activations, first launches)" % ("RCCL communicator, " if use_dist else ""),
+                       "cold_ms_covers": "sd_create (weights -> HBM; fp16 weight forms only when their mode is selected), PCM upload, %sfirst job with cold workspaces (hipMalloc of ~28 GB of workspaces, first launches)" % ("RCCL communicator, " if use_dist else ""),
                        "single_job_ms": single_job_ms,
                        "single_job_note": None if world == 1 else "one recording at a time (barrier after every job): infer + all-gather + finalize in series; `value` is the "
                                           "pipelined rate of back-to-back jobs (rank 0 finalizes job k while the others infer job k+1)"},
