@@ -65,6 +65,14 @@ int64_t sd_num_chunks(int64_t n_samples, int64_t* last_chunk_len);
 int sd_segment(sd_ctx*, const float* h_wav, int64_t n, float* h_out, int64_t* chunks);
 int sd_segment_dev(sd_ctx*, const float* d_wav, int64_t n, float* d_out, int64_t chunks);
 
+/* ---- a3 alone: SegmentModel::infer exactly as the reference declares it (sd.cpp:1352-1404: "input: batch size x samples count,
+ * output: batch size x 293 x 3") for a host that keeps the reference's own slide() (sd.cpp:1407-1504) and swaps only the model call.
+ * h_chunks [rows][T] separate waveforms (T = 80000 in slide(); a shorter last chunk is what sd.cpp:1457-1480 passes), any number of rows
+ * (the reference fills its fixed batch of 32, sd.cpp:1356-1364).  h_out [rows][293][3]; *frames (may be NULL) = the frames the network
+ * yields for T samples, 293 for T = 80000; frames beyond it are zero (slide()'s padding, sd.cpp:1473-1479).  Bit-identical to sd_segment
+ * on the same samples. */
+int sd_segment_chunks(sd_ctx*, const float* h_chunks, int64_t rows, int64_t T, float* h_out, int32_t* frames);
+
 /* ---- a4-a6: binarize_swf, speaker_count, cleanSegmentations + mask choice
  * (sd.cpp:1506-1639, 1665-1738, 710-743, 3047-3078).
  * seg [chunks][293][3] -> binarized u8 [chunks][293][3], masks f32 [chunks*3][293],
@@ -83,6 +91,14 @@ int sd_embed(sd_ctx*, const float* h_wav, int64_t n, const float* h_masks,
 int sd_embed_dev(sd_ctx*, const float* d_wav, int64_t n, const float* d_masks,
                  int64_t items, int64_t first_item, float* d_emb);
 
+/* ---- a8+a9 alone: EmbeddingModel1::infer exactly as the reference declares it (sd.cpp:1977-2040 "input: batch size x waveform, wave
+ * lens; output: embedding", with _infer sd.cpp:1889-1970) for a host that keeps the reference's own getEmbedding() (sd.cpp:2436-2561:
+ * interpolate, padSequence, wav_lens, NaN rule) and swaps only the model call.  h_signals [B][80000] compacted zero-padded signals,
+ * h_wav_lens [B] relative lengths in (0, 1] (sd.cpp:2499-2510), any B (the reference pads its batch to 32 with lens 1.0, sd.cpp:1898-1899).
+ * h_emb [B][192]; no NaN rule here -- getEmbedding applies it to what infer returns (sd.cpp:2540-2556).  Rows that sd_embed computes
+ * come out bit-identical. */
+int sd_embed_signals(sd_ctx*, const float* h_signals, const float* h_wav_lens, int64_t B, float* h_emb);
+
 /* ---- a8 + head of a9 alone (operator seam for parity tests): compaction +
  * STFT + power + mel + dB + mean-norm.  signals-level inputs as for sd_embed;
  * out feats [items][501][80] f32, wav_lens [items] f32 (reference layout). */
@@ -95,6 +111,10 @@ int sd_ecapa(sd_ctx*, const float* h_feats, const float* h_wav_lens, int64_t ite
 int sd_linkage(sd_ctx*, const double* h_X, int64_t N, int d, double* h_Z);
 /* ---- a12+a13: Clustering::cluster (cl.h:7, cl.cpp:459-468): 1-based labels */
 int sd_cluster(sd_ctx*, const double* h_X, int64_t N, int d, double cutoff, int32_t* h_labels1);
+/* ---- a13 alone: Clustering::fcluster (cl.h:9-10, cl.cpp:442-457; criterion "distance", cl.cpp:121-232): Z [N-1][4] of N observations
+ * -> 1-based labels [N], numbered as the reference numbers them.  Host arithmetic only: no GPU work, the context may be NULL.  A Z that
+ * is not a dendrogram of N observations (the reference indexes with its entries unchecked) returns SD_ERR_ARG. */
+int sd_fcluster(sd_ctx*, const double* h_Z, int64_t N, double cutoff, int32_t* h_labels1);
 /* ---- a10+a11+a14: Cluster::clustering (sd.cpp:2063-2116): emb [chunks][3][d]
  * f64 with NaN rows -> hard clusters i32 [chunks][3]; *n_clusters = K */
 int sd_clustering(sd_ctx*, const double* h_emb, int64_t chunks, int d, int32_t* h_hard, int32_t* n_clusters);
@@ -175,7 +195,8 @@ int sd_resample(sd_ctx*, const float* wav, int64_t n, int32_t in_sr, int32_t out
 /* ---- the head of speakerDiarization() (sd.cpp:2937-2951: WavReader, / 32768) in one call, with the input checks the reference
  * lacks (README.md:37 asks for 16 kHz / mono / 16-bit and nothing validates it).  flags = 0: a file whose sample rate is not 16 000 is
  * REFUSED with SD_ERR_ARG (the reference would process it as if it were 16 kHz); channels are read interleaved as the reference
- * does (wav.h:95-97).  SD_WAV_RESAMPLE: other rates go through sd_resample first.  SD_WAV_DOWNMIX: channels are averaged first. */
+ * does (wav.h:95-97).  SD_WAV_RESAMPLE: other rates go through sd_resample first.  SD_WAV_DOWNMIX: channels are averaged first.
+ * SD_WAV_ASSUME_16K: drop-in parity with the reference on off-rate files -- the rate in the header is ignored as the reference ignores it. */
 /* ---- the reference's WRITE_DATA switch (debugWrite / debugWrite2d / debugWrite3d, sd.cpp:62-234 and their call sites): with a directory
  * set, every following whole-path call (sd_diarize*, sd_finalize_dev) writes DIR/cpp_<item>.txt for the items of
  * pipeline/script/verifyEveryStepResult.py:6-17 in the reference's text format -- DIR = "/tmp" is what that script reads.  level 1: all
@@ -184,6 +205,7 @@ int sd_resample(sd_ctx*, const float* wav, int64_t n, int32_t in_sr, int32_t out
 int sd_set_dump_dir(sd_ctx*, const char* dir, int level);
 #define SD_WAV_RESAMPLE 1
 #define SD_WAV_DOWNMIX 2
+#define SD_WAV_ASSUME_16K 4   /* the reference's behaviour on a file whose rate is not 16 000: process the samples as if it were (sd.cpp:2940-2942) */
 int sd_diarize_wav(sd_ctx*, const char* path, int flags, sd_turn** turns, int64_t* n_turns);
 /* ---- output formats (the reference prints raw cluster ids to stdout only, sd.cpp:3433-3441) */
 /* RTTM file of the turns ("SPEAKER <uri> 1 <start> <dur> <NA> <NA> SPEAKER_kk <NA> <conf|NA>") */

@@ -30,3 +30,13 @@ void Clustering::linkage(const std::vector<std::vector<double>>& input, std::vec
     dendrogram.assign((size_t)(N > 1 ? N - 1 : 0), std::vector<double>(4));
     for (size_t k = 0; k + 1 < (size_t)N; ++k) for (int q = 0; q < 4; ++q) dendrogram[k][q] = Z[k * 4 + q];
 }
+
+void Clustering::fcluster(const std::vector<std::vector<double>>& Z, double cutoff, std::vector<int>& clusters)
+{
+    const int64_t N = (int64_t)Z.size() + 1;                   // clustering.cpp:445
+    std::vector<double> flat(Z.size() * 4);
+    for (size_t k = 0; k < Z.size(); ++k) for (int q = 0; q < 4; ++q) flat[k * 4 + q] = Z[k][q];
+    std::vector<int32_t> T((size_t)N);
+    sd_fcluster(g_ctx, flat.data(), N, cutoff, T.data());      // host arithmetic only; 1-based labels in the reference's numbering
+    clusters.assign(T.begin(), T.end());
+}

@@ -103,6 +103,8 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     std::string k(key);
     if (k == "emb_batch_items") { c->emb_batch_items = v; c->emb_batch_explicit = true; }
     else if (k == "seg_batch_chunks") c->seg_batch_chunks = v;
+    else if (k == "ws_limit_mb") g_ws_limit.store(v > 0 ? (size_t)v << 20 : 0);      // test hook, process-wide (sdhip_test.h)
+    else if (k == "emb_batch_default") { c->emb_batch_items = 3072; c->emb_batch_explicit = false; c->embed_calls = v; }   // test hook: back to the implicit plan (v = calls already made)
     else if (k == "linkage_wgs") c->linkage_wgs = v;
     else if (k == "linkage_threads") c->linkage_threads = v;
     else if (k == "linkage_one_xcd") c->linkage_one_xcd = v;
@@ -251,6 +253,61 @@ extern "C" int sd_ecapa(sd_ctx* c, const float* h_feats, const float* h_lens, in
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(h_emb, de.p, items * SD_EMB_DIM * sizeof(float), hipMemcpyDeviceToHost));
+    return SD_OK;
+}
+
+// EmbeddingModel1::infer as the reference declares it (sd.cpp:1977-2040, calling _infer sd.cpp:1889-1970): B already compacted, zero-padded
+// signals of 80000 samples and their relative lengths -> [B][192].  No NaN rule here (getEmbedding applies it to the result, sd.cpp:2479-2549);
+// the STFT / fbank run over all 501 frames of every row as the reference's do, the network over the frames wav_lens leaves valid + its reach.
+extern "C" int sd_embed_signals(sd_ctx* c, const float* h_signals, const float* h_wav_lens, int64_t B, float* h_emb)
+{
+    ENTER(c);
+    if (!h_signals || !h_wav_lens || !h_emb || B <= 0) SD_FAIL(c, SD_ERR_ARG, "sd_embed_signals: bad argument");
+    if (!c->ew.loaded) SD_FAIL(c, SD_ERR_MODEL, "embedding model not loaded");
+    std::vector<int> nv((size_t)B), nn((size_t)B);
+    for (int64_t i = 0; i < B; ++i) {
+        if (!(h_wav_lens[i] > 0.0f) || h_wav_lens[i] > 1.0f) SD_FAIL(c, SD_ERR_ARG, "sd_embed_signals: wav_lens[%lld] = %g (relative length in (0, 1])", (long long)i, (double)h_wav_lens[i]);
+        const float lt = h_wav_lens[i] * (float)SD_T;                       // float32 product as in torch (k_wav_lens)
+        nn[(size_t)i] = (int)rintf(lt);                                      // torch.round, threeModel.py:358
+        int v = (int)ceilf(lt); if (v > SD_T) v = SD_T; if (v < 1) v = 1;    // arange(L) < len * L
+        nv[(size_t)i] = v;
+        if (nn[(size_t)i] < 1) SD_FAIL(c, SD_ERR_ARG, "sd_embed_signals: wav_lens[%lld] = %g leaves no frame to normalise over", (long long)i, (double)h_wav_lens[i]);
+    }
+    const int64_t ns = B * (int64_t)SD_CHUNK;
+    DTMP(c, dw, (ns + 512) * sizeof(float)); DTMP(c, dv, B * sizeof(int)); DTMP(c, dn, B * sizeof(int));
+    DTMP(c, dr, EC_SPACES * (B + 1) * sizeof(int)); DTMP(c, de, B * SD_EMB_DIM * sizeof(float));
+    HIPCHK(c, hipMemcpy(dw.p, h_signals, ns * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset((float*)dw.p + ns, 0, 512 * sizeof(float)));
+    HIPCHK(c, hipMemcpy(dv.p, nv.data(), B * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dn.p, nn.data(), B * sizeof(int), hipMemcpyHostToDevice));
+    EcapaRowPlan plan;
+    int rc = ecapa_row_plan(c, nv.data(), B, plan, (int*)dr.p);
+    if (rc) return rc;
+    const std::vector<int>& rowoff = plan.off[0];
+    DTMP(c, df, (size_t)rowoff[(size_t)B] * SD_FEAT_LD * sizeof(float));
+    if ((rc = frontend_prepare_signals(c, B))) return rc;
+    const int64_t origin = c->wav_origin;
+    c->wav_origin = 0; c->fe_bill_samples = -1;
+    rc = frontend_features(c, (const float*)dw.p, ns, 0, B, false, (const int*)dn.p, (const int*)dr.p, (float*)df.p, true);
+    c->wav_origin = origin;
+    if (rc) return rc;
+    int64_t nb = (c->emb_batch_items / 96) * 96; if (nb < 96) nb = 96;
+    if (nb > 768 && !c->emb_batch_explicit) nb = 768;                        // an operator-level call: the small arena
+    const int64_t cap_rows = nb * SD_TP;
+    rc = ecapa_run_batches(c, [&]() -> int {
+        for (int64_t a0 = 0; a0 < B;) {
+            int64_t a1 = a0;
+            while (a1 < B && a1 - a0 < ROWTAB_MAX_ITEMS && rowoff[(size_t)a1 + 1] - rowoff[(size_t)a0] <= cap_rows) ++a1;
+            if (a1 == a0) a1 = a0 + 1;
+            const int r = run_ecapa(c, (const float*)df.p, (const int*)dv.p, plan, a0, a1, (float*)de.p);
+            if (r) return r;
+            a0 = a1;
+        }
+        return SD_OK;
+    });
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h_emb, de.p, B * SD_EMB_DIM * sizeof(float), hipMemcpyDeviceToHost));
     return SD_OK;
 }
 

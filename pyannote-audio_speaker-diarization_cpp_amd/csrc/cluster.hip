@@ -676,7 +676,8 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     };
     MinIdx none; none.v = INFINITY; none.i = -1;
 #ifdef SD_LINKAGE_STAMPS
-    unsigned long long tS = __builtin_amdgcn_s_memrealtime(), acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tS = __builtin_amdgcn_s_memrealtime(), acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned fix_lanes = 0, fix_waves = 0;
 #define STAMP2(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); acc[i] += t_ - tS; tS = t_; } while (0)
 #else
 #define STAMP2(i) do { } while (0)
@@ -770,6 +771,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
     // matrix, bounds): whoever sees the slot may read them.
     auto publish = [&](Min2 q, Cand m, int nL, const Min2* rows, int row_tie = 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP2(12);
         __syncthreads();
         ++bar;
         MwGran* sl = gran + ((size_t)par * G + g) * SLOT_WORDS;
@@ -1007,15 +1009,20 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
                 }
                 nbz[u] = l_nb[pc]; mdz[u] = l_md[pc]; md2z[u] = l_md2[pc];
             }
+            STAMP2(8);
             if constexpr (SQ) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (zz[u] < 0) continue;
                     const int tz = l_ty[zz[u] - z0];
+#ifdef SD_LINKAGE_STAMPS
+                    { const bool fx = (txm < tz) || (tym < tz); const unsigned long long bm = __ballot(fx); fix_lanes += fx ? 1u : 0u; if (lane == 0 && bm) fix_waves += 1; }
+#endif
                     if (txm < tz) dzx[u] = LDG(&D[(int64_t)zz[u] * N + x]);        // z's row was written after x's: the current {z, x} is there
                     if (tym < tz) dzy[u] = LDG(&D[(int64_t)zz[u] * N + y]);
                 }
             }
+            STAMP2(9);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int z = zz[u];
@@ -1045,6 +1052,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         }
         STAMP2(6);
         block_min_qc(q, m, sh, shc, NW);
+        STAMP2(10);
         row_tie = __syncthreads_or(row_tie);
         write_Z();
         if (tid == 0) { size[x] = 0; size[y] = nx + ny; }     // (every thread is past the pass and has used the old sizes)
@@ -1060,6 +1068,7 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
             act[p] = last; pos[last / G] = p; s_cnt = c2;
             l_md[p] = l_md[c2]; l_md2[p] = l_md2[c2]; l_nb[p] = l_nb[c2]; l_fr[p] = l_fr[c2];
         }
+        STAMP2(11);
         publish(q, m, 0, s_row, row_tie);
         STAMP2(7);
         if (!consume(11)) return;
@@ -1091,7 +1100,8 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         prefetch_pair();
     }
 #ifdef SD_LINKAGE_STAMPS
-    if (g == 0 && tid == 0) for (int i = 0; i < 8; ++i) sync[8 + i] = (unsigned)(acc[i] / 100);   // microseconds
+    if (g == 0 && tid == 0) for (int i = 0; i < 16; ++i) sync[8 + i] = (unsigned)(acc[i] / 100);   // microseconds
+    atomicAdd(&sync[24], fix_lanes); if (lane == 0) atomicAdd(&sync[25], fix_waves);
 #endif
 }
 
@@ -1229,8 +1239,8 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     WS(c, int, size_all, "cl_size_all", priv);
     hipLaunchKernelGGL(k_fill_size_ty, dim3((unsigned)((priv + 255) / 256)), dim3(256), 0, c->stream, size_all, N, priv, square ? 1 : 0);
     KCHECK(c);
-    WS(c, unsigned, sync, "cl_sync", 16);
-    HIPCHK(c, hipMemsetAsync(sync, 0, 16 * sizeof(unsigned), c->stream));
+    WS(c, unsigned, sync, "cl_sync", 32);
+    HIPCHK(c, hipMemsetAsync(sync, 0, 32 * sizeof(unsigned), c->stream));
     const char* why = nullptr;
     {
         ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
@@ -1252,13 +1262,14 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         if (!onex) le = hipLaunchCooperativeKernel(f_all, dim3(G), dim3(TH), args, (size_t)cap * 32, c->stream);
         if (le != hipSuccess) { (void)hipGetLastError(); why = "cooperative launch refused"; }
     }
-    unsigned h[16] = {0};
+    unsigned h[32] = {0};
     if (!why) {
         HIPCHK(c, hipMemcpyAsync(h, sync, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->stats["linkage_retry_rounds"].flops += (double)h[2];
 #ifdef SD_LINKAGE_STAMPS
-        fprintf(stderr, "linkage stamps (us): retry-scan %u retry-argmin %u barrier %u digest %u pick %u bookkeeping %u lw %u reductions %u\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
+        fprintf(stderr, "linkage stamps (us): retry-scan %u retry-argmin %u barrier %u digest %u pick %u bookkeeping %u lw-compute+stores %u publish-stores %u | lw-issue %u lw-fixup %u block-min %u tie+Z %u drain %u | fix-up lanes %u waves %u\n",
+                h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[16], h[17], h[18], h[19], h[20], h[24], h[25]);
 #endif
         if (h[1] && onex) {
             // too few workgroups found themselves on XCC 0 (dispatch not round-robin?): never again in this context; the

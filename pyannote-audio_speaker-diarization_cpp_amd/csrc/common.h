@@ -1,11 +1,13 @@
 // common.h -- internal declarations shared by the HIP translation units of libsdhip.so
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <functional>
 #include <vector>
@@ -20,8 +22,12 @@
 struct KernelStat { double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
 
 // SD_TRACE_WS=1 (diagnostic): what the workspace allocations of a job cost -- hipMalloc / hipFree time and bytes, printed by sd_diarize*
-inline double g_ws_alloc_ms = 0.0, g_ws_free_ms = 0.0;
-inline size_t g_ws_alloc_bytes = 0, g_ws_allocs = 0;
+// (process-wide, touched by every context's allocations: atomics)
+inline std::atomic<long long> g_ws_alloc_us{0}, g_ws_free_us{0};
+inline std::atomic<size_t> g_ws_alloc_bytes{0}, g_ws_allocs{0};
+inline std::atomic<size_t> g_ws_limit{0};          // test hook (option ws_limit_mb): a workspace request above this many bytes fails like an exhausted GPU; 0 = off
+// per-device "dynamic-LDS attribute set" masks of the wide conv kernels (the attribute belongs to the device's code object, the launch to a context)
+inline std::atomic<unsigned> g_attr_w256{0}, g_attr_g256{0};
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int reserve(size_t bytes) {
@@ -31,10 +37,11 @@ struct DevBuf {
         const auto t1 = std::chrono::steady_clock::now();
         p = nullptr; cap = 0;
         size_t want = bytes + (bytes >> 3) + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return 1; }
+        const size_t lim = g_ws_limit.load(std::memory_order_relaxed);
+        if ((lim && bytes > lim) || hipMalloc(&p, want) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return 1; }      // (the failure must not surface again at the next kernel-launch check)
         const auto t2 = std::chrono::steady_clock::now();
-        g_ws_free_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
-        g_ws_alloc_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
+        g_ws_free_us += (long long)std::chrono::duration<double, std::micro>(t1 - t0).count();
+        g_ws_alloc_us += (long long)std::chrono::duration<double, std::micro>(t2 - t1).count();
         g_ws_alloc_bytes += want; ++g_ws_allocs;
         cap = want; return 0;
     }
@@ -142,6 +149,7 @@ struct sd_ctx {
     std::vector<void*> owned;                  // device allocations freed in sd_destroy
     char* warena_cur = nullptr; size_t warena_left = 0;   // weights.cpp: bump allocator over 64 MB device blocks
     std::map<std::string, DevBuf> ws;          // named workspaces
+    std::set<std::string> rs_taps_filled;      // resample.hip: tap tables whose upload has completed
     std::map<std::string, KernelStat> stats;
     bool profile = false;
     bool profile_detail = false;               // also bracket conv_gemm per layer tag (option profile=2)
@@ -242,7 +250,8 @@ int ensure_ecapa_mode_weights(sd_ctx* c, int ecapa_precision);   // weights_gpu.
 int frontend_prepare(sd_ctx* c, const float* d_masks, int64_t items, int64_t first_item, float* d_wav_lens, int* d_nnorm, int* d_nvalid,
                      int* d_flags, bool compact, int* h_n_active, int* d_cidx, std::vector<int>* h_nvalid = nullptr);
 int frontend_features(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_item, int64_t run_items, bool compact, const int* d_nnorm,
-                      const int* d_rowoff, float* d_feats /*[rowoff[run_items]][96]*/);
+                      const int* d_rowoff, float* d_feats /*[rowoff[run_items]][96]*/, bool sig_mode = false);
+int frontend_prepare_signals(sd_ctx* c, int64_t items);       // sd_embed_signals: identity gather tables for [items][80000] signal rows
 // ---- ecapa.hip
 // Compact row spaces of the embedding network: space s stores the frames t < min(501, nvalid + EC_MARGIN[s]) of every item.
 // A layer is only computed where a later valid frame can see it (ecapa.hip): block0 / block 1 run in space 0, block 2 in space 1,
@@ -261,6 +270,7 @@ int ecapa_run_batches(sd_ctx* c, const std::function<int()>& batches);      // x
 int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, int64_t items, int64_t first_item, float* d_emb);
 // ---- pyannet.hip
 int run_segment(sd_ctx* c, const float* d_wav, int64_t n, int64_t chunk_lo, int64_t chunk_hi, float* d_seg);
+int run_segment_rows(sd_ctx* c, const float* d_rows, int64_t rows, int T, float* d_seg, int* frames);   // SegmentModel::infer as declared (sd.cpp:1352)
 // ---- postseg.hip
 int run_postseg(sd_ctx* c, const float* d_seg, int64_t chunks, uint8_t* d_bin, float* d_masks, int* d_nact);
 int run_count(sd_ctx* c, const uint8_t* d_bin, int64_t chunks, int32_t* d_count, int64_t n_count, double* d_avg = nullptr);

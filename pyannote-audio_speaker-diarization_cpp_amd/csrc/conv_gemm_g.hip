@@ -592,13 +592,13 @@ int launch_conv_gemm_g256(sd_ctx* c, const ConvArgs& in, const char* tag)
         (a.y_ld & 3) || a.Cin % (h ? 64 : 32) != 0 || a.M < 8 * GM || (a.x_ld & (h ? 7 : 3)) || (!h && a.y_f32)) return 1;
     if ((int64_t)a.Cin * (a.kt_real > 0 ? a.kt_real : a.KT) < (c->conv_w256_kmin > 0 ? c->conv_w256_kmin : (h ? 256 : 128))) return 1;
     if (((size_t)a.X & 15) || ((size_t)(h ? a.W16 : (const void*)a.W) & 15)) return 1;
-    static bool attr_set = false;
     const size_t lds_bytes = (size_t)2 * G_STAGE + 8 * G_STRIP;       // (f32: 3 KB of parameters where the fp16 form keeps its strips)
-    if (!attr_set) {
+    const unsigned dev_bit = 1u << (c->device & 31);
+    if (!(g_attr_g256.load(std::memory_order_acquire) & dev_bit)) {        // once per device (a second thread that gets here meanwhile sets the same values)
         if (hipFuncSetAttribute((const void*)k_conv_gemm_g256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_conv_gemm_g256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_conv_gemm_g256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
-        attr_set = true;
+        g_attr_g256.fetch_or(dev_bit, std::memory_order_release);
     }
     if (a.w_ld <= 0) a.w_ld = a.Cin;
     a.m_tiles = (a.M + GM - 1) / GM;

@@ -451,13 +451,13 @@ int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& in, const char* tag)
     // fp16: the shortest contraction (ASP conv, K = 128) stays on the 128 x 128 form (measured); f32 takes every wide layer since the
     // K-groups are pinned (block0 K = 400: 92 -> 102 TF, ASP conv K = 128: 95 -> 105 TF)
     if (!x3 && (int64_t)a.Cin * (a.kt_real > 0 ? a.kt_real : a.KT) < (c->conv_w256_kmin > 0 ? c->conv_w256_kmin : (h ? 256 : 128))) return 1;
-    static bool attr_set = false;
     const size_t lds_bytes = (size_t)2 * (HM + HN) * HLDP * sizeof(float);
-    if (!attr_set) {
+    const unsigned dev_bit = 1u << (c->device & 31);
+    if (!(g_attr_w256.load(std::memory_order_acquire) & dev_bit)) {        // once per device (a second thread that gets here meanwhile sets the same values)
         if (hipFuncSetAttribute((const void*)k_conv_gemm_w256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_conv_gemm_w256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_conv_gemm_w256<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
-        attr_set = true;
+        g_attr_w256.fetch_or(dev_bit, std::memory_order_release);
     }
     if (a.w_ld <= 0) a.w_ld = a.Cin;
     if (x3) a.w_ld = 2 * a.Cin;              // halves: eight hi, eight lo, eight hi, ... (weights.cpp)

@@ -450,6 +450,10 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
         // ceil(ceil(M / 256) / 64) rounds of 64 row panels (8 XCDs x 8 panels per super-block) per group of column tiles, and the
         // last round is only as full as M happens to leave it; the four row spaces have different M, so the best compromise is
         // searched over the last few dozen items (results do not depend on the batching: every row's bits are placement-free).
+        // A batch plan whose activation arena cannot be allocated (a second context on the GPU, an 8-h job beside the 80 GB distance matrix: the
+        // default plan asks for ~57 GB at the 1-h size) is repeated with a smaller one -- 768 items (16 GB), then 96: every row's bits are
+        // batch-independent (tests/test_planted.py), so only time is lost.  Any other failure is returned as it is.
+        for (int attempt = 0;; ++attempt) {
         const int64_t cap_rows = nb * SD_TP;
         auto batch_efficiency = [&](int64_t a0, int64_t a1) -> double {
             // {row space, weight = K x groups of 4 column tiles} of the 256 x 256 launches: block0, tdnn1 / tdnn2 of the three blocks, MFA,
@@ -490,6 +494,17 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
         }
         return rc;
         });
+        if (rc == SD_ERR_HIP && nb > 96 && c->err.find("hipMalloc of workspace") != std::string::npos) {
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipGetLastError();
+            for (const char* k : {"ec_x0", "ec_tr", "ec_t2", "ec_cat", "ec_mfa", "ec_hid", "ec_logits", "ec_mfa32", "ec_hid32", "ec_feats16"}) { auto it = c->ws.find(k); if (it != c->ws.end()) it->second.release(); }
+            nb = nb > 768 ? 768 : 96;
+            c->stats["emb_arena_retries"].launches += 1;
+            c->err.clear();
+            continue;
+        }
+        break;
+        }
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_scatter_emb, GRID1(items * SD_EMB_DIM), 0, c->stream, emb_c, cidx, d_emb, items);

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_fbank(
     const float* __restrict__ window, const double* __restrict__ twc, const double* __restrict__ twns,
     const float* __restrict__ mel_w, const int* __restrict__ mel_lo, const int* __restrict__ mel_cnt, const int* __restrict__ mel_off,
     int mel_nnz, const int* __restrict__ alist, const int* __restrict__ rowoff, const int* __restrict__ nnorm, int run_items,
-    float* __restrict__ scratch /*[gridDim.x][501][80]*/, float* __restrict__ feats)
+    float* __restrict__ scratch /*[gridDim.x][501][80]*/, float* __restrict__ feats, int sig_mode)
 {
     __shared__ __attribute__((aligned(16))) double2 Y[16 * 13 * YK];
     __shared__ __attribute__((aligned(16))) float sigpw[16 * PW_LD > SIGP ? 16 * PW_LD : SIGP];    // signal tile, then the power spectra of the tile
@@ -128,13 +128,16 @@ __global__ __launch_bounds__(256, 2) void k_stft_fbank(
     for (int slot = blockIdx.x; slot < run_items; slot += gridDim.x) {
         const int item = alist ? alist[slot] : slot;
         const int64_t gitem = first_item + item;
-        const int64_t chunk_start = (gitem / SD_SPEAKERS) * (int64_t)SD_HOP;     // crop(), sd.cpp:1643
+        // sig_mode (sd_embed_signals = EmbeddingModel1::infer as declared, sd.cpp:1977): item i is row i of a [B][80000] signal matrix, already
+        // compacted by the caller; the dB maximum runs over all 501 frames as the reference's does (nothing is known about the samples behind wav_lens)
+        const int64_t chunk_start = sig_mode ? gitem * (int64_t)SD_CHUNK : (gitem / SD_SPEAKERS) * (int64_t)SD_HOP;     // crop(), sd.cpp:1643
         const int cnt = counts[item];
         const int row0 = rowoff[slot], need = rowoff[slot + 1] - row0;
         __syncthreads();                                       // previous item's phase 2 is done with pre / mean / db
         for (int k = tid; k < 296; k += 256) pre[k] = prefix[(size_t)item * 296 + k];
         float vmax = -INFINITY;
-        for (int t0 = 0; t0 < need; t0 += 16) {
+        const int t_end = sig_mode ? SD_T : need;
+        for (int t0 = 0; t0 < t_end; t0 += 16) {
             __syncthreads();                                   // pre is loaded; the previous tile's mel pass is done with pw
             // ---- gather the compacted samples [160 t0 - 200, +2800): each thread a run of 11 consecutive ones
             {
@@ -313,7 +316,7 @@ int frontend_prepare(sd_ctx* c, const float* d_masks, int64_t items, int64_t fir
 // Phase B: compaction gather + STFT + mel + dB, then top-dB clamp and mean normalisation into the compact feature rows
 // d_feats [rowoff[run_items]][96] (item's frame t at row d_rowoff[item] + t; frames beyond an item's rows are not computed).
 int frontend_features(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_item, int64_t run_items, bool compact, const int* d_nnorm,
-                      const int* d_rowoff, float* d_feats)
+                      const int* d_rowoff, float* d_feats, bool sig_mode)
 {
     if (run_items <= 0) return SD_OK;
     const EcapaWeights& E = c->ew;
@@ -334,8 +337,27 @@ int frontend_features(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_it
         const double fr = c->fe_bill_samples >= 0 ? (double)c->fe_bill_frames : (double)run_items * SD_T;
         ProfScope ps(c, "stft_mel", fr * (15000.0 + 201.0 * 80 * 2), by);
         hipLaunchKernelGGL(k_stft_fbank, dim3(grid), dim3(256), 0, c->stream, d_wav, c->wav_origin, n, d_prefix, d_counts, first_item, E.window, E.tw_cos, E.tw_nsin,
-                           E.mel_w, E.mel_lo, E.mel_cnt, E.mel_off, E.mel_nnz, alist, d_rowoff, d_nnorm, (int)run_items, d_scratch, d_feats);
+                           E.mel_w, E.mel_lo, E.mel_cnt, E.mel_off, E.mel_nnz, alist, d_rowoff, d_nnorm, (int)run_items, d_scratch, d_feats, sig_mode ? 1 : 0);
         KCHECK(c);
     }
+    return SD_OK;
+}
+
+// sd_embed_signals: the rows are already compacted (Helper::padSequence, sd.cpp:2463), so the gather of k_stft_fbank is the identity:
+// every mask frame selected, prefix[f] = first sample of frame f, 80000 samples per item
+__global__ void k_identity_prefix(int* __restrict__ prefix, int* __restrict__ counts, int items)
+{
+    const int item = blockIdx.x, tid = threadIdx.x;
+    if (tid <= SD_FRAMES) prefix[(size_t)item * 296 + tid] = frame_start(tid);
+    if (tid == 0) counts[item] = SD_CHUNK;
+}
+int frontend_prepare_signals(sd_ctx* c, int64_t items)
+{
+    if (!c->ew.loaded) SD_FAIL(c, SD_ERR_MODEL, "embedding model not loaded");
+    if (c->ew.mel_nnz > MEL_MAX_NNZ) SD_FAIL(c, SD_ERR_MODEL, "mel filterbank too dense (%d non-zeros)", c->ew.mel_nnz);
+    WS(c, int, d_prefix, "fe_prefix", items * 296);
+    WS(c, int, d_counts, "fe_counts", items);
+    hipLaunchKernelGGL(k_identity_prefix, dim3((unsigned)items), dim3(512), 0, c->stream, d_prefix, d_counts, (int)items);
+    KCHECK(c);
     return SD_OK;
 }

@@ -16,6 +16,8 @@
 //   --resample      a wav whose sample rate is not 16 000 Hz is resampled on the GPU first (sd_resample; the dormant Resampler of the reference,
 //                   frontend/resampler.cc:19-36).  WITHOUT it such a file is refused: the reference reads the rate and ignores it (sd.cpp:2940-2942),
 //                   i.e. silently diarizes at the wrong speed
+//   --assume-16k    the reference's own behaviour on such a file: the samples are processed as if they were 16 kHz whatever the header says
+//                   (parity runs on off-rate files; SD_WAV_ASSUME_16K)
 //   --downmix       average the channels of a multi-channel wav first (default: the reference's interleaved read, wav.h:95-97)
 //   --dump-steps DIR [--dump-level 2]   the reference's WRITE_DATA switch: DIR/cpp_<item>.txt for the items of script/verifyEveryStepResult.py
 //                   (sd_set_dump_dir; DIR = /tmp is what that script reads); single-GPU runs
@@ -152,6 +154,7 @@ int main(int argc, char* argv[])
         else if (s == "--dump-level" && i + 1 < argc) a.dump_level = atoi(argv[++i]);
         else if (s == "--resample") a.wav_flags |= SD_WAV_RESAMPLE;
         else if (s == "--downmix") a.wav_flags |= SD_WAV_DOWNMIX;
+        else if (s == "--assume-16k") a.wav_flags |= SD_WAV_ASSUME_16K;
         else if (s == "--precision" && i + 1 < argc) {
             const std::string v(argv[++i]);
             if (v == "f32") a.precision = 0; else if (v == "f16") a.precision = 1; else if (v == "x3") a.precision = 3;

@@ -82,6 +82,27 @@ extern "C" int sd_segment(sd_ctx* c, const float* h_wav, int64_t n, float* h_out
     return SD_OK;
 }
 
+// SegmentModel::infer as the reference declares it (sd.cpp:1352-1404): [rows][T] separate waveforms -> [rows][293][3]; *frames = the
+// frames the network yields for T samples (293 for T = 80000), the rest of each row's 293 is zero (slide()'s padding, sd.cpp:1473-1479)
+extern "C" int sd_segment_chunks(sd_ctx* c, const float* h_chunks, int64_t rows, int64_t T, float* h_out, int32_t* frames)
+{
+    ENTER(c);
+    if (!h_chunks || !h_out || rows <= 0 || T < 1 || T > SD_CHUNK) SD_FAIL(c, SD_ERR_ARG, "sd_segment_chunks: bad argument (rows >= 1, 1 <= T <= %d)", SD_CHUNK);
+    DTMP(c, dw, (rows * T + 512) * sizeof(float)); DTMP(c, ds, rows * SD_FRAMES * 3 * sizeof(float));
+    HIPCHK(c, hipMemcpy(dw.p, h_chunks, rows * T * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset((float*)dw.p + rows * T, 0, 512 * sizeof(float)));
+    const bool padded = c->wav_padded;
+    c->wav_padded = true;
+    int fr = 0;
+    const int rc = run_segment_rows(c, (const float*)dw.p, rows, (int)T, (float*)ds.p, &fr);
+    c->wav_padded = padded;
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h_out, ds.p, rows * SD_FRAMES * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (frames) *frames = fr;
+    return SD_OK;
+}
+
 // ------------------------------------------------------------------ a4-a6
 extern "C" int sd_postseg(sd_ctx* c, const float* h_seg, int64_t chunks, uint8_t* h_bin, float* h_masks,
                           int32_t* h_count, int64_t cap_count, int64_t* n_count)
@@ -128,6 +149,28 @@ extern "C" int sd_cluster(sd_ctx* c, const double* h_X, int64_t N, int d, double
     int rc = run_cluster_labels(c, (const double*)dx.p, N, d, cutoff, lab);
     if (rc) return rc;
     for (int64_t i = 0; i < N; ++i) h_labels1[i] = lab[(size_t)i];
+    return SD_OK;
+}
+
+// Clustering::fcluster (cl.h:9-10, cl.cpp:442-457; criterion "distance"): Z [N-1][4] of N observations -> 1-based labels [N].  Host
+// arithmetic only (O(N) pointer chasing over a dendrogram the caller already holds): no GPU work, c may be NULL.
+extern "C" int sd_fcluster(sd_ctx* c, const double* h_Z, int64_t N, double cutoff, int32_t* h_labels1)
+{
+    if (c) c->err.clear();
+    auto fail = [&](const char* m) { if (c) c->err = m; return (int)SD_ERR_ARG; };
+    if (!h_labels1 || N < 1 || (N > 1 && !h_Z)) return fail("sd_fcluster: bad argument");
+    // a dendrogram of N leaves: merge k joins two DIFFERENT nodes < N + k, each node at most once (the reference indexes arrays with them unchecked)
+    std::vector<char> used((size_t)(2 * N - 1), 0);
+    for (int64_t k = 0; k + 1 < N; ++k)
+        for (int q = 0; q < 2; ++q) {
+            const double v = h_Z[k * 4 + q];
+            if (!(v >= 0.0) || v >= (double)(N + k) || v != std::floor(v) || used[(size_t)v]) return fail("sd_fcluster: Z is not a dendrogram of N observations");
+            used[(size_t)v] = 1;
+        }
+    std::vector<double> Z(h_Z, h_Z + (size_t)(N > 1 ? N - 1 : 0) * 4);
+    std::vector<int> T;
+    fcluster_host(Z, N, cutoff, T);
+    for (int64_t i = 0; i < N; ++i) h_labels1[i] = T[(size_t)i];
     return SD_OK;
 }
 
@@ -346,7 +389,7 @@ extern "C" int sd_diarize_dev(sd_ctx* c, const int16_t* d_pcm, int64_t n, sd_tur
     c->stage_ms[3] = now_ms() - t0;
     if (getenv("SD_TRACE_WS")) {
         fprintf(stderr, "[sdhip] job %.1f ms (segmentation %.1f, embedding %.1f, finalize %.1f); workspace allocations so far in this process: %zu hipMalloc, %.2f GB, %.1f ms (+ %.1f ms hipFree)\n",
-                c->stage_ms[3], c->stage_ms[0], c->stage_ms[1], c->stage_ms[2], g_ws_allocs, (double)g_ws_alloc_bytes / 1e9, g_ws_alloc_ms, g_ws_free_ms);
+                c->stage_ms[3], c->stage_ms[0], c->stage_ms[1], c->stage_ms[2], g_ws_allocs.load(), (double)g_ws_alloc_bytes.load() / 1e9, (double)g_ws_alloc_us.load() * 1e-3, (double)g_ws_free_us.load() * 1e-3);
         for (const auto& kv : c->ws) if (kv.second.cap >= ((size_t)256 << 20)) fprintf(stderr, "[sdhip]   %-16s %8.2f GB\n", kv.first.c_str(), (double)kv.second.cap / 1e9);
     }
     return turns_out(c, v, turns, n_turns);
@@ -391,13 +434,13 @@ int resample_dev(sd_ctx* c, const float* d_in, int64_t n, int32_t in_sr, int32_t
 extern "C" int sd_diarize_wav(sd_ctx* c, const char* path, int flags, sd_turn** turns, int64_t* n_turns)
 {
     ENTER(c);
-    if (!path || !turns || !n_turns || (flags & ~(SD_WAV_RESAMPLE | SD_WAV_DOWNMIX))) SD_FAIL(c, SD_ERR_ARG, "sd_diarize_wav: bad argument");
+    if (!path || !turns || !n_turns || (flags & ~(SD_WAV_RESAMPLE | SD_WAV_DOWNMIX | SD_WAV_ASSUME_16K))) SD_FAIL(c, SD_ERR_ARG, "sd_diarize_wav: bad argument");
     *turns = nullptr; *n_turns = 0;
     {   // the common case -- 16-bit, 16 kHz, nothing to mix -- stays int16 up to the GPU (k_pcm_to_f32 does the reference's / 32768 there)
         int16_t* pcm = nullptr; int64_t np = 0; int32_t sr16 = 0, ch16 = 0;
         if (sd_read_wav(path, &pcm, &np, &sr16, &ch16) == SD_OK) {
             struct FreePcm { int16_t* p; ~FreePcm() { sd_free_pcm(p); } } g{pcm};
-            if (sr16 == 16000 && !(ch16 > 1 && (flags & SD_WAV_DOWNMIX))) return sd_diarize(c, pcm, np, turns, n_turns);
+            if ((sr16 == 16000 || (flags & SD_WAV_ASSUME_16K)) && !(ch16 > 1 && (flags & SD_WAV_DOWNMIX))) return sd_diarize(c, pcm, np, turns, n_turns);
         }
     }
     float* wav = nullptr; int64_t n = 0; int32_t sr = 0, ch = 0, bits = 0;
@@ -411,10 +454,10 @@ extern "C" int sd_diarize_wav(sd_ctx* c, const char* path, int flags, sd_turn** 
             wav[i] = s / (float)ch;
         }
     }
-    if (sr == 16000) return sd_diarize_f32(c, wav, n, turns, n_turns);
+    if (sr == 16000 || (flags & SD_WAV_ASSUME_16K)) return sd_diarize_f32(c, wav, n, turns, n_turns);      // ASSUME_16K: the reference's behaviour (sd.cpp:2940-2942)
     if (!(flags & SD_WAV_RESAMPLE))
         SD_FAIL(c, SD_ERR_ARG, "%s: sample rate %d Hz; the pipeline needs 16000 (README.md:37 of the reference, which would process the file as if it "
-                               "were 16 kHz) -- pass SD_WAV_RESAMPLE / --resample", path, sr);
+                               "were 16 kHz: SD_WAV_ASSUME_16K / --assume-16k does the same) -- pass SD_WAV_RESAMPLE / --resample", path, sr);
     if (n <= 0) SD_FAIL(c, SD_ERR_SHORT, "%s holds no samples", path);
     const double t0 = now_ms();
     const int64_t no = sd_resample_len(n, sr, 16000);

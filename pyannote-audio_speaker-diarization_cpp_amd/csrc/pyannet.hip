@@ -20,12 +20,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------- k_chunk_norm
 // xn[chunk][j] = (x - mean) / sqrt(var + 1e-5) * w + b  for j < L, 0 beyond
-__global__ __launch_bounds__(256) void k_chunk_norm(const float* __restrict__ wav, int64_t origin, int64_t first_chunk, int L,
+__global__ __launch_bounds__(256) void k_chunk_norm(const float* __restrict__ wav, int64_t origin, int64_t first_chunk, int64_t hop, int L,
                                                     float w, float b, float* __restrict__ xn)
 {
     __shared__ float red[256];
     const int ck = blockIdx.x, tid = threadIdx.x;
-    const int64_t base = (first_chunk + ck) * (int64_t)SD_HOP - origin;          // wav[0] is sample `origin` of the recording
+    const int64_t base = (first_chunk + ck) * hop - origin;          // wav[0] is sample `origin` of the recording; hop = SD_HOP (slide) or the row length (sd_segment_chunks)
     const float* x = wav + base;
     float s = 0.0f;
     for (int j = tid; j < L; j += 256) s += x[j];
@@ -391,7 +391,8 @@ static ConvArgs gemm_args(const ConvLayer& L, const float* X, int x_ld, float* Y
 }
 
 // one batch of `cnt` chunks that all have L samples
-static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chunk, int64_t cnt, int L, float* d_seg)
+// hop = samples between the starts of consecutive chunks in d_wav: SD_HOP for the sliding window, the row length for separate rows
+static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chunk, int64_t cnt, int L, float* d_seg, int64_t hop = SD_HOP)
 {
     const SegWeights& S = c->sw;
     hipStream_t st = c->stream;
@@ -418,7 +419,7 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
     WS(c, float, y0, "sg_y0", CB * F * 128);
     WS(c, float, y1, "sg_y1", CB * F * 128);
     int rc;
-    if (c->seg_shared_conv0 && c->wav_padded && S.conv0.Cout == 80 && S.conv0_wsum) {
+    if (c->seg_shared_conv0 && c->wav_padded && hop == SD_HOP && S.conv0.Cout == 80 && S.conv0_wsum) {
         // conv0 once over the batch's stretch of the waveform: rows 0 .. 800 (CB - 1) + L0 (chunk ck's frames start at row 800 ck;
         // the last window ends 4 samples behind the last chunk, inside the waveform's padding), then the chunk's normalisation as an
         // affine map inside the pooling kernel.  10x fewer FLOPs and 10x less output than one conv per chunk.
@@ -439,7 +440,7 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
     } else {
         WS(c, float, xn, "sg_xn", CB * SD_CHUNK + 512);
         WS(c, float, c0, "sg_c0", CB * L0 * 80);
-        hipLaunchKernelGGL(k_chunk_norm, dim3((unsigned)CB), dim3(256), 0, st, d_wav, c->wav_origin, first_chunk, L, S.wn_w, S.wn_b, xn);
+        hipLaunchKernelGGL(k_chunk_norm, dim3((unsigned)CB), dim3(256), 0, st, d_wav, c->wav_origin, first_chunk, hop, L, S.wn_w, S.wn_b, xn);
         KCHECK(c);
         {   // conv0: rows = output positions, row r reads xn[10 r .. 10 r + 256)
             ConvArgs a; memset(&a, 0, sizeof(a));
@@ -534,4 +535,25 @@ int run_segment(sd_ctx* c, const float* d_wav, int64_t n, int64_t chunk_lo, int6
     if (has_short_tail && chunk_lo <= total - 1)
         if ((rc = seg_batch(c, d_wav, n, total - 1, 1, (int)last_len, d_seg + (size_t)(total - 1 - chunk_lo) * SD_FRAMES * 3))) return rc;
     return SD_OK;
+}
+
+// SegmentModel::infer as the reference declares it (sd.cpp:1352-1404): `rows` separate waveforms of T samples each, [rows][T] -> [rows][293][3]
+// (frames beyond the *frames the network yields for T samples are zero, as slide() pads them, sd.cpp:1473-1479).  Same kernels as run_segment
+// with the chunk stride T instead of SD_HOP (the shared-conv0 shortcut needs overlapping chunks and is off).
+int run_segment_rows(sd_ctx* c, const float* d_rows, int64_t rows, int T, float* d_seg, int* frames)
+{
+    if (!c->sw.loaded) SD_FAIL(c, SD_ERR_MODEL, "segmentation model not loaded");
+    if (T < 1 || T > SD_CHUNK) SD_FAIL(c, SD_ERR_ARG, "sd_segment_chunks: T = %d samples per row (1 .. %d)", T, SD_CHUNK);
+    const int L0 = (T >= 251) ? (T - 251) / 10 + 1 : 0;
+    const int P0 = L0 / 3, L1 = P0 - 4, P1 = L1 / 3, L2 = P1 - 4, P2 = L2 / 3;
+    if (frames) *frames = (L0 <= 0 || P0 <= 0 || L1 <= 0 || P1 <= 0 || L2 <= 0 || P2 <= 0) ? 0 : (P2 > SD_FRAMES ? SD_FRAMES : P2);
+    int64_t cb = c->seg_batch_chunks;
+    if (cb < 1) cb = 1;
+    const int64_t origin = c->wav_origin;
+    c->wav_origin = 0;
+    int rc = SD_OK;
+    for (int64_t k = 0; k < rows && rc == SD_OK; k += cb)
+        rc = seg_batch(c, d_rows, rows * (int64_t)T, k, rows - k < cb ? rows - k : cb, T, d_seg + (size_t)k * SD_FRAMES * 3, T);
+    c->wav_origin = origin;
+    return rc;
 }

@@ -98,7 +98,8 @@ int resample_dev(sd_ctx* c, const float* d_in, int64_t n, int32_t in_sr, int32_t
     // tap table, double on the host, float on the device; cached per rate pair
     char key[64];
     snprintf(key, sizeof(key), "rs_taps_%d_%d", in_sr, out_sr);
-    const bool have = c->ws.count(key) != 0;
+    // "filled" is recorded only after the upload has completed: a failed allocation or copy leaves no entry behind that a later call would trust
+    const bool have = c->rs_taps_filled.count(key) != 0;
     WS(c, float, d_taps, key, ntap * p.L);
     if (!have) {
         std::vector<float> h((size_t)(ntap * p.L));
@@ -116,6 +117,7 @@ int resample_dev(sd_ctx* c, const float* d_in, int64_t n, int32_t in_sr, int32_t
             }
         HIPCHK(c, hipMemcpyAsync(d_taps, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));                      // h goes out of scope
+        c->rs_taps_filled.insert(key);
     }
     const size_t lds = (size_t)p.span * sizeof(float);
     if (lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -38,6 +38,7 @@ EXPORTS = [
     "sd_write_rttm", "sd_set_planted", "sd_comm_unique_id", "sd_comm_init", "sd_comm_destroy", "sd_comm_info", "sd_shard_plan",
     "sd_diarize_sharded", "sd_diarize_sharded_dev", "sd_write_rttm_ex", "sd_relabel_turns", "sd_relabel_turns_ex", "sd_last_confidence",
     "sd_debug_read_ws", "sd_test_pack_split_weights", "sd_resample", "sd_resample_len", "sd_diarize_wav", "sd_set_dump_dir",
+    "sd_fcluster", "sd_segment_chunks", "sd_embed_signals",
 ]
 COMM_ID_BYTES = 128
 
@@ -74,6 +75,9 @@ def lib():
     L.sd_frontend.argtypes = [vp, vp, i64, vp, i64, vp, vp]
     L.sd_ecapa.argtypes = [vp, vp, vp, i64, vp]
     L.sd_linkage.argtypes = [vp, vp, i64, C.c_int, vp]
+    L.sd_fcluster.argtypes = [vp, vp, i64, dbl, vp]
+    L.sd_segment_chunks.argtypes = [vp, vp, i64, i64, vp, C.POINTER(i32)]
+    L.sd_embed_signals.argtypes = [vp, vp, vp, i64, vp]
     L.sd_cluster.argtypes = [vp, vp, i64, C.c_int, dbl, vp]
     L.sd_clustering.argtypes = [vp, vp, i64, C.c_int, vp, C.POINTER(i32)]
     L.sd_clustering_ex.argtypes = [vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(i32)]
@@ -120,6 +124,17 @@ def num_chunks(n):
     ll = C.c_int64(0)
     c = lib().sd_num_chunks(n, C.byref(ll))
     return int(c), int(ll.value)
+
+
+def fcluster(Z, cutoff):
+    """sd_fcluster = Clustering::fcluster (clustering.h:9-10): Z [N-1][4] -> 1-based labels [N].  Host arithmetic, no context, no GPU."""
+    Z = np.ascontiguousarray(Z, np.float64).reshape(-1, 4)
+    N = len(Z) + 1
+    T = np.zeros(N, np.int32)
+    rc = lib().sd_fcluster(None, _ptr(Z) if len(Z) else None, N, float(cutoff), _ptr(T))
+    if rc:
+        raise SdError(rc, "sd_fcluster: Z is not a dendrogram")
+    return T
 
 
 def shard_plan(n_total, world, rank0_permille=-1):
@@ -284,6 +299,25 @@ class Diarizer:
         nc = C.c_int64(0)
         self._chk(lib().sd_postseg(self._h, _ptr(seg), c, _ptr(nb), _ptr(masks), _ptr(count), cap, C.byref(nc)))
         return nb, masks, count[:nc.value]
+
+    def segment_chunks(self, chunks):
+        """sd_segment_chunks = SegmentModel::infer as declared (sd.cpp:1352): [rows][T] separate waveforms -> ([rows][293][3], frames)"""
+        chunks = np.ascontiguousarray(chunks, np.float32)
+        rows, T = chunks.shape
+        out = np.zeros((rows, FRAMES, SPEAKERS), np.float32)
+        fr = C.c_int32(0)
+        self._chk(lib().sd_segment_chunks(self._h, _ptr(chunks), rows, T, _ptr(out), C.byref(fr)))
+        return out, int(fr.value)
+
+    def embed_signals(self, signals, wav_lens):
+        """sd_embed_signals = EmbeddingModel1::infer as declared (sd.cpp:1977): [B][80000] compacted signals + relative lengths -> [B][192]"""
+        signals = np.ascontiguousarray(signals, np.float32)
+        wav_lens = np.ascontiguousarray(wav_lens, np.float32)
+        B, T = signals.shape
+        assert T == 80000 and wav_lens.shape == (B,)
+        out = np.zeros((B, EMB_DIM), np.float32)
+        self._chk(lib().sd_embed_signals(self._h, _ptr(signals), _ptr(wav_lens), B, _ptr(out)))
+        return out
 
     # ---- a6-a9
     def embed(self, wav, masks):

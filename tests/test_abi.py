@@ -114,7 +114,7 @@ int main(void) {
 
 
 def test_reference_side_binding_of_seam4_compiles_against_the_reference_header(tmp_path):
-    """INTEGRATION.md seam 4 as a compilable file: Clustering::cluster / ::linkage re-implemented on sd_cluster / sd_linkage must
+    """INTEGRATION.md seam 4 as a compilable file: Clustering::cluster / ::linkage / ::fcluster re-implemented on sd_cluster / sd_linkage / sd_fcluster must
     match the reference's own clustering.h (signatures, constness) and include/sdhip.h"""
     import subprocess
     ref = "/root/reference/pipeline/src/clustering"
@@ -122,6 +122,51 @@ def test_reference_side_binding_of_seam4_compiles_against_the_reference_header(t
         pytest.skip("reference tree absent (GPU box)")
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-include", "vector", "-include", "algorithm", "-include", "cstdint", "-I", ref,
                            "-I", os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "oracle", "ref_build", "seam4_binding.cpp"), "-o", str(tmp_path / "seam4.o")])
+
+
+def test_reference_side_bindings_of_the_two_literal_model_seams_compile(tmp_path):
+    """INTEGRATION.md seams 2 and 3 in their literal form -- SegmentModel::infer (sd.cpp:1352) on sd_segment_chunks and EmbeddingModel1::infer
+    (sd.cpp:1977) on sd_embed_signals, with the reference's own parameter and return types -- compile against include/sdhip.h, alone and
+    as the test shims the GPU tests run (tests/test_next_rows.py)"""
+    import subprocess
+    pkg = os.path.join(ROOT, "pyannote-audio_speaker-diarization_cpp_amd")
+    for seam in ("seam2", "seam3"):
+        src = os.path.join(ROOT, "oracle", "ref_build", seam + "_binding.cpp")
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-include", "algorithm", "-include", "cstdint", "-I", os.path.join(ROOT, "include"),
+                               "-c", src, "-o", str(tmp_path / (seam + ".o"))])
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-include", "algorithm", "-include", "cstdint", "-DSEAM_TEST_SHIM", "-fPIC", "-shared",
+                               "-I", os.path.join(ROOT, "include"), src, "-o", str(tmp_path / ("lib" + seam + ".so")), "-L", pkg, "-lsdhip"])
+
+
+def test_fcluster_entry_point_against_the_oracle_and_the_reference():
+    """sd_fcluster = Clustering::fcluster (clustering.h:9-10, clustering.cpp:442-457) is host arithmetic: labels equal to the C oracle's and to
+    the reference's own compiled fcluster on dendrograms with nested, flat and tied heights, at cutoffs below, between and above them; a Z
+    that is not a dendrogram is refused instead of indexed with"""
+    rng = np.random.default_rng(12)
+    cases = []
+    for N, d in ((2, 4), (3, 4), (40, 8), (700, 16)):
+        X = rng.standard_normal((N, d)); X[N // 2:] += 3.0
+        cases.append(orc.linkage_centroid(orc.pdist(X), N))
+    g = np.stack(np.meshgrid(np.arange(4.0), np.arange(4.0)), -1).reshape(-1, 2)                 # lattice: equal heights everywhere
+    cases.append(orc.linkage_centroid(orc.pdist(g), len(g)))
+    R = orc.ref()
+    for Z in cases:
+        N = len(Z) + 1
+        hs = np.sort(Z[:, 2])
+        for cut in (hs[0] * 0.5, hs[len(hs) // 2], float(np.nextafter(hs[len(hs) // 2], -np.inf)), hs[-1], hs[-1] * 2, orc.THRESH_F32):
+            T = sdhip.fcluster(Z, cut)
+            assert np.array_equal(T, orc.fcluster_distance(Z, cut)), (N, cut)
+            if R is not None:
+                Tr = np.zeros(N, np.int32)
+                R.ref_fcluster(np.ascontiguousarray(Z), N, float(cut), Tr)
+                assert np.array_equal(T, Tr), (N, cut)
+    assert np.array_equal(sdhip.fcluster(np.zeros((0, 4)), 1.0), [1])                             # one observation: one cluster
+    bad = cases[2].copy(); bad[5, 0] = 10 ** 6
+    with pytest.raises(sdhip.SdError):
+        sdhip.fcluster(bad, 1.0)
+    bad = cases[2].copy(); bad[7, 1] = bad[3, 1]                                                  # a node merged twice
+    with pytest.raises(sdhip.SdError):
+        sdhip.fcluster(bad, 1.0)
 
 
 def test_split_weight_packing_of_the_x3_mode_on_the_host():
