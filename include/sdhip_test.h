@@ -53,6 +53,9 @@ int sd_test_pack_split_weights(const float* w, int K, int Cout, int CinPad, int 
  * process's workspace hipMalloc / hipFree calls have cost so far (count, GB, ms) with every workspace of 256 MB or more. */
 /* tuning hooks (tools/): time one conv_gemm shape on scratch data (dbg selects an ablation); time a grid barrier */
 int sd_bench_barrier(sd_ctx*, int workgroups, int iters, int dirty_doubles, double* us_per_barrier);
+/* what a merge round of k_linkage_rg is made of (linkage_rg.hip: k_rg_parts): a synthetic round with its geometry and memory pattern, parts
+ * switched on by bits: 1 row loads, 2 Lance-Williams arithmetic, 4 row stores, 8 workgroup reductions, 16 slot exchange + digest */
+int sd_bench_linkage_parts(sd_ctx*, int64_t N, int workgroups, int rounds, int parts, int one_xcd, double* us_per_round);
 int sd_bench_conv(sd_ctx*, int64_t items, int Tp, int T, int Cin, int Cout, int KT, int dil, int has_x2, int dbg, int reps, double* ms_per_launch);
 
 #ifdef __cplusplus

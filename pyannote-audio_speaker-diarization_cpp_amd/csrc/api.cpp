@@ -107,6 +107,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "emb_batch_default") { c->emb_batch_items = 3072; c->emb_batch_explicit = false; c->embed_calls = v; }   // test hook: back to the implicit plan (v = calls already made)
     else if (k == "linkage_wgs") c->linkage_wgs = v;
     else if (k == "linkage_threads") c->linkage_threads = v;
+    else if (k == "linkage_kernel") c->linkage_kernel = v;
     else if (k == "linkage_one_xcd") c->linkage_one_xcd = v;
     else if (k == "linkage_square") c->linkage_square = v;
     else if (k == "skip_dead_rows") c->skip_dead_rows = v != 0;

@@ -16,15 +16,10 @@
 // that replays the reference's heap operation by operation, so Z is bit-identical to the
 // reference for every input, ties included.  fcluster is O(N) pointer chasing and runs on the host.
 #include "common.h"
+#include "linkage_dev.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
-
-__host__ __device__ __forceinline__ int64_t cidx(int64_t n, int64_t i, int64_t j)     // cl.cpp:236-242
-{
-    if (i < j) return n * i - (i * (i + 1) / 2) + (j - i - 1);
-    return n * j - (j * (j + 1) / 2) + (i - j - 1);
-}
 
 // ---------------------------------------------------------------- row gather + L2 normalise (a10/a11)
 // Xout[i] = X[tidx[i]] (un-normalised copy), Xn[i] = row / (double)(float)sqrt(sum x^2)
@@ -141,91 +136,6 @@ __global__ __launch_bounds__(256) void k_pdist_sq(const double* __restrict__ X, 
     }
 }
 
-// ---------------------------------------------------------------- nearest active neighbour above a row (cl.cpp:259-276)
-struct MinIdx { double v; int i; };
-__device__ __forceinline__ MinIdx better(MinIdx a, MinIdx b)
-{
-    // smaller value wins; equal values -> lower index (== "first strictly smaller" of a sequential scan); -1 = none
-    if (b.i < 0) return a;
-    if (a.i < 0) return b;
-    if (b.v < a.v) return b;
-    if (b.v == a.v && b.i < a.i) return b;
-    return a;
-}
-// Wave-wide reductions with DPP lane moves (quad swaps, half-mirror, mirror, row broadcasts) instead of
-// ds_bpermute shuffles: the dependent chain is ~10x shorter, and these reductions sit on the serial path of
-// every merge.  All 64 lanes must be active.  The result (in lane 63 after the last step) is returned to all lanes.
-template <int CTRL, int RM> __device__ __forceinline__ int dppi(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, RM, 0xF, false); }
-template <int CTRL, int RM> __device__ __forceinline__ double dppd(double v)
-{
-    const int lo = dppi<CTRL, RM>(__double2loint(v)), hi = dppi<CTRL, RM>(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_d(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-// Wave minimum in two moves instead of six (value, index) butterfly steps of ~12 dependent instructions each: the minimum VALUE
-// first (v_min_f64 over DPP moves), then a ballot of the lanes that hold it.  One lane in the ballot (the rule on data without
-// ties): its index is read with v_readlane.  Several: the lowest index among them, as `better` decides.  Same result as the
-// butterfly for every input without NaN (distances are never NaN here).
-__device__ __forceinline__ double wave_min_d(double v)
-{
-    v = fmin(v, dppd<0xB1, 0xF>(v)); v = fmin(v, dppd<0x4E, 0xF>(v)); v = fmin(v, dppd<0x141, 0xF>(v)); v = fmin(v, dppd<0x140, 0xF>(v));
-    v = fmin(v, dppd<0x142, 0xA>(v)); v = fmin(v, dppd<0x143, 0xC>(v));
-    return readlane_d(v, 63);
-}
-__device__ __forceinline__ int wave_min_i(int v)
-{
-    v = min(v, dppi<0xB1, 0xF>(v)); v = min(v, dppi<0x4E, 0xF>(v)); v = min(v, dppi<0x141, 0xF>(v)); v = min(v, dppi<0x140, 0xF>(v));
-    v = min(v, dppi<0x142, 0xA>(v)); v = min(v, dppi<0x143, 0xC>(v));
-    return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ MinIdx wave_min(MinIdx m)
-{
-    const bool has = m.i >= 0;
-    const double vmin = wave_min_d(has ? m.v : (double)INFINITY);
-    const bool at = has && m.v == vmin;
-    const unsigned long long mask = __ballot(at);
-    MinIdx r; r.v = INFINITY; r.i = -1;
-    if (mask == 0) return r;
-    r.v = vmin;
-    if (mask & (mask - 1)) r.i = wave_min_i(at ? m.i : 0x7fffffff);
-    else r.i = __builtin_amdgcn_readlane(m.i, __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1));
-    return r;
-}
-
-// Two smallest values of a set: the minimum with its index (same rules as MinIdx) and the smallest value among all OTHER elements
-// (equal to the minimum when it occurs twice).  The second value is what makes a row's bound robust: when the distance to its
-// neighbour grows but stays below every other entry of the row, the bound is still exact (see k_linkage_mw).
-struct Min2 { double v; int i; double v2; };
-__device__ __forceinline__ void min2_acc(Min2& m, double v, int j)       // sequential scan in ascending j
-{
-    if (v < m.v) { m.v2 = m.v; m.v = v; m.i = j; }
-    else if (v < m.v2) m.v2 = v;
-}
-__device__ __forceinline__ Min2 min2_merge(Min2 a, Min2 b)
-{
-    if (b.i < 0) return a;
-    if (a.i < 0) return b;
-    Min2 r;
-    const bool bw = b.v < a.v || (b.v == a.v && b.i < a.i);
-    r.v = bw ? b.v : a.v; r.i = bw ? b.i : a.i;
-    r.v2 = fmin(bw ? a.v : b.v, fmin(a.v2, b.v2));
-    return r;
-}
-__device__ __forceinline__ Min2 wave_min2(Min2 m)
-{
-    MinIdx q; q.v = m.v; q.i = m.i;
-    const MinIdx w = wave_min(q);
-    Min2 r; r.v = w.v; r.i = w.i; r.v2 = INFINITY;
-    if (w.i < 0) return r;
-    // every lane but the winner's contributes its own minimum, the winner's lane its second value
-    const bool win = m.i == w.i && m.i >= 0;
-    r.v2 = wave_min_d(win ? m.v2 : (m.i >= 0 ? m.v : (double)INFINITY));
-    return r;
-}
-
 __global__ __launch_bounds__(256) void k_row_nn(const double* __restrict__ D, int64_t n, int* __restrict__ nb, double* __restrict__ md, double* __restrict__ md2, int square)
 {
     const int lane = threadIdx.x & 63;
@@ -263,13 +173,6 @@ __device__ __forceinline__ MinIdx scan_row_nn(const double* __restrict__ D, cons
         }
     }
     return q;
-}
-
-// Lance-Williams centroid update with the reference's operation order, cl.cpp:250-256
-__device__ __forceinline__ double lw_centroid(double d_xi, double d_yi, double d_xy, int sx, int sy)
-{
-    return sqrt(((((double)sx * d_xi * d_xi) + ((double)sy * d_yi * d_yi)) -
-                 ((double)(sx * sy) * d_xy * d_xy) / (double)(sx + sy)) / (double)(sx + sy));
 }
 
 #define LT 1024
@@ -454,7 +357,6 @@ __global__ __launch_bounds__(LT) void k_linkage_heap(double* D, int n, int* size
 // arg-min candidate that carries its neighbour and its flags along through the reductions.
 // fresh bit 0: the bound is exact (== D[i, y]); bit 1 (CAND_TIE): some OTHER row holds exactly the same bound -- the case in
 // which the reference's heap, not the value, decides who comes first (see k_linkage_heap)
-#define CAND_TIE 2
 struct Cand { double v; int i; int y; int fresh; };
 
 __device__ __forceinline__ bool mw_barrier(unsigned* counter, unsigned target, unsigned* timeout_flag)
@@ -477,22 +379,6 @@ __device__ __forceinline__ bool mw_barrier(unsigned* counter, unsigned target, u
     return ok;
 }
 
-// Cross-workgroup data of the cooperative kernel (distance matrix, bounds, neighbours, slots) is moved with agent-scope
-// relaxed atomics only: on gfx950 these are `sc1` loads / stores (write-through past the per-XCD L2, loads that do not
-// trust a non-coherent line).  Every wave drains its stores (`s_waitcnt vmcnt(0)`) before the workgroup publishes its
-// slot, so no agent-scope release / acquire -- an L2 write-back and a full L2 invalidate per merge -- is needed, and
-// each workgroup's private state (cluster sizes, freshness flags) stays cached.
-template <class T> __device__ __forceinline__ T LDG(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <class T> __device__ __forceinline__ void STG(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// One-XCD form (k_linkage_mw<true>): every participating workgroup sits on the SAME XCD (checked in the kernel from
-// HW_REG_XCC_ID, not assumed), so that XCD's L2 is the point of coherence: stores stay plain -- they write through the CU's L1
-// and KEEP the line in the L2 (an sc1 store drops it, and even a same-XCD reader then pays the cross-XCD round trip) -- while
-// loads stay sc1 (bypass the reader's L1, served by the L2).  MI355X_MICROARCH.md, table of store / load flavours.
-template <bool ONEX, class T> __device__ __forceinline__ void STX(T* p, T v)
-{
-    if constexpr (ONEX) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ MinIdx block_min_t(MinIdx m, MinIdx* sh, int nwaves)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -590,7 +476,6 @@ __device__ __forceinline__ void block_min_qc(Min2& q, Cand& m, Min2* shq, Cand* 
 // 3 its neighbour, 4 freshness, 5-6 NN(y) partial (double), 7 its row; merge rounds: 8 "row x had a second pair at the merge height",
 // 9-10 second value of the NN(y) partial; retry rounds: 8+5r.. refreshed-row partial r (minimum double, its row, second value double).
 #define SLOT_WORDS 32
-typedef unsigned long long MwGran;
 
 // SQ form (k_linkage_mw<*, true>): the distance matrix is the full N x N square and a workgroup owns a contiguous range of COLUMNS.
 // Only rows are ever read or written in bulk: a merge (x, y) reads rows x and y and writes row y, every workgroup its own column range,
@@ -1188,6 +1073,12 @@ __global__ void k_fill_size_ty(int* p, int64_t n, int64_t total, int with_ty)
     if (i < total) p[i] = (with_ty && ((i / n) & 1)) ? -1 : 1;
 }
 
+// linkage_rg.hip
+bool linkage_rg_fits(int64_t N, int G, int TH);
+hipError_t linkage_rg_launch(sd_ctx* c, bool onex, int G, int TH, double* D, int n, int* cid, const int* nb, const double* md, const double* md2,
+                             double* Z, MwGran* gran, unsigned* sync, int cap);
+int linkage_rg_slot_granules();
+
 int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
 {
     if (N < 2) return SD_OK;
@@ -1233,14 +1124,29 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2, square))) return rc;
     // one-XCD form while two workgroups per CU of one XCD (32 CUs) can hold the job; above, all XCDs' memory pipelines are worth more
     bool onex = c->linkage_one_xcd != 0 && G <= 32 && c->num_cu >= 256;
-    WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * SLOT_WORDS);
-    HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * SLOT_WORDS * sizeof(MwGran), c->stream));
-    const int64_t priv = (int64_t)G * N * (square ? 2 : 1);
-    WS(c, int, size_all, "cl_size_all", priv);
-    hipLaunchKernelGGL(k_fill_size_ty, dim3((unsigned)((priv + 255) / 256)), dim3(256), 0, c->stream, size_all, N, priv, square ? 1 : 0);
-    KCHECK(c);
-    WS(c, unsigned, sync, "cl_sync", 32);
-    HIPCHK(c, hipMemsetAsync(sync, 0, 32 * sizeof(unsigned), c->stream));
+    // square form: k_linkage_rg (register state, sizes / ty in the slots) where its geometry fits -- at most 4 columns per thread -- else k_linkage_mw
+    bool use_rg = square && c->linkage_kernel != 0;
+    // measured (r05, planted embeddings): N = 12 602, one XCD, 32 workgroups: 256 threads 72.7 ms, 512 threads 81.2, 128 threads 76.6 (k_linkage_mw 76.7);
+    // N = 100 174, all XCDs, 128 workgroups: 256 threads 819 ms, 512 threads 829 (k_linkage_mw 996); 64 x 512: 875
+    if (use_rg && c->linkage_threads <= 0) TH = 256;
+    if (use_rg && !linkage_rg_fits(N, G, TH)) {
+        int t2 = TH;
+        while (t2 < 1024 && !linkage_rg_fits(N, G, t2)) t2 *= 2;
+        if (linkage_rg_fits(N, G, t2) && (c->linkage_threads <= 0 || c->linkage_kernel > 0)) TH = t2; else use_rg = false;
+    }
+    const int slot_gran = use_rg ? linkage_rg_slot_granules() : SLOT_WORDS;
+    WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * slot_gran);
+    HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * slot_gran * sizeof(MwGran), c->stream));
+    int* size_all = nullptr;
+    if (!use_rg) {
+        const int64_t priv = (int64_t)G * N * (square ? 2 : 1);
+        WS(c, int, sa, "cl_size_all", priv);
+        size_all = sa;
+        hipLaunchKernelGGL(k_fill_size_ty, dim3((unsigned)((priv + 255) / 256)), dim3(256), 0, c->stream, size_all, N, priv, square ? 1 : 0);
+        KCHECK(c);
+    }
+    WS(c, unsigned, sync, "cl_sync", 32 + 16 * 256);
+    HIPCHK(c, hipMemsetAsync(sync, 0, (32 + 16 * 256) * sizeof(unsigned), c->stream));
     const char* why = nullptr;
     {
         ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
@@ -1255,11 +1161,20 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
             (void)hipFuncSetAttribute(f_all, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 32);
             (void)hipGetLastError();
         }
+        if (use_rg) {
+            if (onex) {
+                le = linkage_rg_launch(c, true, G, TH, D, n_i, cid, nb, md, md2, d_Z, gran, sync, cap);
+                if (le != hipSuccess) { (void)hipGetLastError(); onex = false; }
+            }
+            if (!onex) le = linkage_rg_launch(c, false, G, TH, D, n_i, cid, nb, md, md2, d_Z, gran, sync, cap);
+            c->stats["linkage_rg_launches"].launches += 1;
+        } else {
         if (onex) {
             le = hipLaunchCooperativeKernel(f_one, dim3(8 * G), dim3(TH), args, (size_t)cap * 32, c->stream);
             if (le != hipSuccess) { (void)hipGetLastError(); onex = false; }
         }
         if (!onex) le = hipLaunchCooperativeKernel(f_all, dim3(G), dim3(TH), args, (size_t)cap * 32, c->stream);
+        }
         if (le != hipSuccess) { (void)hipGetLastError(); why = "cooperative launch refused"; }
     }
     unsigned h[32] = {0};
@@ -1270,6 +1185,15 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
 #ifdef SD_LINKAGE_STAMPS
         fprintf(stderr, "linkage stamps (us): retry-scan %u retry-argmin %u barrier %u digest %u pick %u bookkeeping %u lw-compute+stores %u publish-stores %u | lw-issue %u lw-fixup %u block-min %u tie+Z %u drain %u | fix-up lanes %u waves %u\n",
                 h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[16], h[17], h[18], h[19], h[20], h[24], h[25]);
+        if (use_rg) {          // every workgroup's view of the enabled intervals (min / mean / max over the workgroups, ms)
+            std::vector<unsigned> hw((size_t)16 * G);
+            HIPCHK(c, hipMemcpy(hw.data(), sync + 32, hw.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+            for (int i = 0; i < 16; ++i) {
+                double mn = 1e30, mx = 0, sm = 0;
+                for (int q = 0; q < G; ++q) { const double v = hw[(size_t)q * 16 + i] * 1e-2; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sm += v; }
+                if (mx > 0) fprintf(stderr, "  stamp %2d over %d workgroups: min %.2f mean %.2f max %.2f Mcycles (shader clock)\n", i, G, mn, sm / G, mx);
+            }
+        }
 #endif
         if (h[1] && onex) {
             // too few workgroups found themselves on XCC 0 (dispatch not round-robin?): never again in this context; the

@@ -453,7 +453,7 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
         // A batch plan whose activation arena cannot be allocated (a second context on the GPU, an 8-h job beside the 80 GB distance matrix: the
         // default plan asks for ~57 GB at the 1-h size) is repeated with a smaller one -- 768 items (16 GB), then 96: every row's bits are
         // batch-independent (tests/test_planted.py), so only time is lost.  Any other failure is returned as it is.
-        for (int attempt = 0;; ++attempt) {
+        for (;;) {
         const int64_t cap_rows = nb * SD_TP;
         auto batch_efficiency = [&](int64_t a0, int64_t a1) -> double {
             // {row space, weight = K x groups of 4 column tiles} of the 256 x 256 launches: block0, tdnn1 / tdnn2 of the three blocks, MFA,

@@ -38,7 +38,7 @@ EXPORTS = [
     "sd_write_rttm", "sd_set_planted", "sd_comm_unique_id", "sd_comm_init", "sd_comm_destroy", "sd_comm_info", "sd_shard_plan",
     "sd_diarize_sharded", "sd_diarize_sharded_dev", "sd_write_rttm_ex", "sd_relabel_turns", "sd_relabel_turns_ex", "sd_last_confidence",
     "sd_debug_read_ws", "sd_test_pack_split_weights", "sd_resample", "sd_resample_len", "sd_diarize_wav", "sd_set_dump_dir",
-    "sd_fcluster", "sd_segment_chunks", "sd_embed_signals",
+    "sd_fcluster", "sd_segment_chunks", "sd_embed_signals", "sd_bench_linkage_parts",
 ]
 COMM_ID_BYTES = 128
 
@@ -115,6 +115,7 @@ def lib():
     L.sd_debug_read_ws.argtypes = [vp, C.c_char_p, i64, vp, i64]
     L.sd_test_pack_split_weights.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.sd_bench_barrier.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(dbl)]
+    L.sd_bench_linkage_parts.argtypes = [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(dbl)]
     L.sd_bench_conv.argtypes = [vp, i64] + [C.c_int] * 9 + [C.POINTER(dbl)]
     _lib = L
     return L

