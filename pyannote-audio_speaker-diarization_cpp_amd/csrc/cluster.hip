@@ -1078,6 +1078,9 @@ bool linkage_rg_fits(int64_t N, int G, int TH);
 hipError_t linkage_rg_launch(sd_ctx* c, bool onex, int G, int TH, double* D, int n, int* cid, const int* nb, const double* md, const double* md2,
                              double* Z, MwGran* gran, unsigned* sync, int cap);
 int linkage_rg_slot_granules();
+// linkage_hx.hip
+bool linkage_hx_fits(int64_t N, int workers);
+int linkage_hx_run(sd_ctx* c, bool onex, int workers, double* D, int64_t N, int* cid, int* size, int* tyv, int* nb, double* md, double* d_Z, bool* stopped);
 
 int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
 {
@@ -1148,7 +1151,8 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     WS(c, unsigned, sync, "cl_sync", 32 + 16 * 256);
     HIPCHK(c, hipMemsetAsync(sync, 0, (32 + 16 * 256) * sizeof(unsigned), c->stream));
     const char* why = nullptr;
-    {
+    if (c->linkage_force_heap) why = "forced (option linkage_force_heap)";
+    else {
         ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
         int n_i = (int)N;
         void* args[] = {&D, &n_i, &size_all, &cid, &nb, &md, &md2, &d_Z, &gran, &sync, &cap, &G};
@@ -1207,7 +1211,30 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     }
     if (!why) return SD_OK;
     c->stats["linkage_fallbacks"].launches += 1;
-    if (c->profile_detail) fprintf(stderr, "linkage: %s at N = %lld -> k_linkage_heap\n", why, (long long)N);
+    if (c->profile_detail) fprintf(stderr, "linkage: %s at N = %lld -> heap replay\n", why, (long long)N);
+    // the reference's heap replayed with the row work spread over worker workgroups (k_linkage_hx) on the square matrix, where it fits
+    if (square && c->linkage_tie_kernel != 0) {
+        bool hx_onex = c->linkage_one_xcd != 0 && c->num_cu >= 256 && linkage_hx_fits(N, 31);
+        int workers = hx_onex ? 31 : (N >= 60000 ? 127 : 63);
+        if (c->linkage_tie_kernel > 1) { workers = (int)c->linkage_tie_kernel; hx_onex = hx_onex && workers <= 31; }
+        if (workers + 1 > c->num_cu) workers = c->num_cu - 1;
+        if (linkage_hx_fits(N, workers)) {
+            WS(c, int, tyv, "cl_ty", N);
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2, true))) return rc;
+                hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, tyv, -1, N, 0);
+                KCHECK(c);
+                bool stopped = false;
+                if ((rc = linkage_hx_run(c, hx_onex, workers, D, N, cid, size, tyv, nb, md, d_Z, &stopped))) return rc;
+                if (!stopped) { c->stats["linkage_hx_jobs"].launches += 1; return SD_OK; }
+                if (!hx_onex) break;
+                hx_onex = false;                 // one XCD refused or too few workgroups arrived there: all XCDs
+                workers = N >= 60000 ? 127 : 63;
+                if (!linkage_hx_fits(N, workers)) break;
+            }
+            c->stats["linkage_hx_failed"].launches += 1;
+        }
+    }
     // the heap kernel works on the condensed matrix; the square one (up to 170 GB) is given back first, so that the fallback -- exact
     // ties are its designed trigger -- also fits right below the auto-square limit (the stream is idle: it was synchronised above)
     { auto it = c->ws.find("cl_Dsq"); if (it != c->ws.end()) it->second.release(); }

@@ -11,6 +11,7 @@ import torch
 
 from oracle import nn_oracle as nn
 from oracle import orc, pipeline_oracle
+import sdhip
 
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-3, 1e-4
@@ -553,6 +554,62 @@ def test_linkage_with_exact_ties_is_bit_identical(diarizer, G):
         assert np.array_equal(T, T_ref), (name, G)
         used_mw = (G == 16 and len(X) > 16) or (G == -1 and len(X) >= 1500)
         assert (diarizer.kernel_stats("linkage_tie_fallbacks")["launches"] - fb0 == 2) == used_mw, (name, G)
+
+
+@pytest.mark.parametrize("workers", [5, 31, 63])
+def test_heap_replay_with_worker_workgroups_is_bit_identical(diarizer, workers):
+    """k_linkage_hx (linkage_hx.hip): the reference's loop, heap included, on one thread, the row work of every step on `workers` workgroups
+    (31 = one XCD, 63 = all XCDs).  Forced onto tie-free data (clustered: many bounds drop per merge, ordered change lists; uniform: stale heap
+    tops rescanned cooperatively) and run where it is meant to run -- duplicated rows, the cooperative kernel stops at the first tie --
+    the dendrogram is the oracle's bit for bit"""
+    rng = np.random.default_rng(400 + workers)
+    Y = _blobs(rng, 2600); Y[rng.integers(0, 2600, 400)] = Y[rng.integers(0, 2600, 400)]
+    cases = [("blobs", _blobs(rng, 2500), 1), ("uniform", rng.random((3000, 3)), 1), ("duplicates", Y, 0)]
+    for name, X, force in cases:
+        _, Z_ref = orc.ahc(X, orc.THRESH_F32)
+        j0 = diarizer.kernel_stats("linkage_hx_jobs")["launches"]
+        diarizer.set_option("linkage_tie_kernel", workers)
+        diarizer.set_option("linkage_force_heap", force)
+        try:
+            Z = diarizer.linkage(X)
+        finally:
+            diarizer.set_option("linkage_tie_kernel", 1)
+            diarizer.set_option("linkage_force_heap", 0)
+        assert np.array_equal(Z, Z_ref), (name, workers)
+        assert diarizer.kernel_stats("linkage_hx_jobs")["launches"] == j0 + 1, (name, workers)      # it was this kernel, not the one-workgroup fallback
+    assert diarizer.kernel_stats("linkage_hx_stale_scans")["flops"] > 0
+
+
+def test_one_hour_sized_set_with_duplicated_rows_against_the_reference_clustering(diarizer):
+    """12 989 rows (the live items of the planted hour), 5 % of them exact copies of other rows (looped audio, digital
+    silence): the cooperative kernel stops at the first tie, k_linkage_hx finishes the job, and Z / the labels are those of the
+    REFERENCE's own compiled clustering.cpp (oracle/_ref/libref_clustering.so; the C oracle where that is absent) bit for bit"""
+    rng = np.random.default_rng(12989)
+    N = 12989
+    X = _blobs(rng, N, k=5)
+    dup = rng.choice(N, N // 20, replace=False)
+    X[dup] = X[rng.integers(0, N, len(dup))]
+    R = orc.ref()
+    if R is not None:
+        Z_ref = np.zeros((N - 1, 4)); T_ref = np.zeros(N, np.int32)
+        R.ref_linkage(np.ascontiguousarray(X), N, X.shape[1], Z_ref)
+        R.ref_fcluster(Z_ref, N, orc.THRESH_F32, T_ref)
+    else:
+        T_ref, Z_ref = orc.ahc(X, orc.THRESH_F32)
+    f0 = diarizer.kernel_stats("linkage_tie_fallbacks")["launches"]
+    j0 = diarizer.kernel_stats("linkage_hx_jobs")["launches"]
+    diarizer.reset_stats()
+    diarizer.set_option("profile", 1)
+    try:
+        Z = diarizer.linkage(X)
+        ms = diarizer.kernel_stats("linkage_hx")["ms"]
+    finally:
+        diarizer.set_option("profile", 0)
+    assert np.array_equal(Z, Z_ref)
+    assert np.array_equal(sdhip.fcluster(Z, orc.THRESH_F32), T_ref)
+    assert diarizer.kernel_stats("linkage_hx_jobs")["launches"] >= 1
+    print("k_linkage_hx on 12 989 rows with 5 %% duplicates: %.1f ms" % ms)
+    assert ms < 400.0           # (k_linkage_heap, one workgroup: ~700 ms at this size)
 
 
 def test_heap_linkage_with_global_heap_is_bit_identical(diarizer):
