@@ -1076,7 +1076,7 @@ __global__ void k_fill_size_ty(int* p, int64_t n, int64_t total, int with_ty)
 // linkage_rg.hip
 bool linkage_rg_fits(int64_t N, int G, int TH);
 hipError_t linkage_rg_launch(sd_ctx* c, bool onex, int G, int TH, double* D, int n, int* cid, const int* nb, const double* md, const double* md2,
-                             double* Z, MwGran* gran, unsigned* sync, int cap);
+                             double* Z, MwGran* gran, unsigned* sync, int cap, int helper);
 int linkage_rg_slot_granules();
 // linkage_hx.hip
 bool linkage_hx_fits(int64_t N, int workers);
@@ -1167,10 +1167,10 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         }
         if (use_rg) {
             if (onex) {
-                le = linkage_rg_launch(c, true, G, TH, D, n_i, cid, nb, md, md2, d_Z, gran, sync, cap);
+                le = linkage_rg_launch(c, true, G, TH, D, n_i, cid, nb, md, md2, d_Z, gran, sync, cap, (int)c->linkage_prefetch);
                 if (le != hipSuccess) { (void)hipGetLastError(); onex = false; }
             }
-            if (!onex) le = linkage_rg_launch(c, false, G, TH, D, n_i, cid, nb, md, md2, d_Z, gran, sync, cap);
+            if (!onex) le = linkage_rg_launch(c, false, G, TH, D, n_i, cid, nb, md, md2, d_Z, gran, sync, cap, (int)c->linkage_prefetch);
             c->stats["linkage_rg_launches"].launches += 1;
         } else {
         if (onex) {

@@ -168,7 +168,7 @@ __device__ __forceinline__ unsigned rq_word(const RQ& q, int k)      // word k o
 // TB = launch bound (256 / 512 / 1024 threads): the register budget follows it -- 128 VGPRs at 1024 threads spill part of the column state
 template <bool ONEX, int TB>
 __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, const int* nb0, const double* md0, const double* md20, double* Z,
-                                                         MwGran* gran /*[2][G][RG_SLOT], zeroed*/, unsigned* sync, int cap /*columns per workgroup + 1*/, int G)
+                                                         MwGran* gran /*[2][G][RG_SLOT], zeroed*/, unsigned* sync, int cap /*columns per workgroup + 1*/, int G, int helper)
 {
     extern __shared__ __attribute__((aligned(16))) int dyn_lds[];
     // what the cooperative row scans of a retry round need of a column they do not own in registers: last rewrite, cluster size, "gone"
@@ -185,7 +185,12 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
     __shared__ int s_L[2][RG_KR], s_Lty[2][RG_KR], s_Lsz[2][RG_KR];
     __shared__ int s_nL[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int T = blockDim.x, NW = T >> 6;
+    // helper = 1: the last wave owns no columns and takes no part in the hand-offs; after every merge it requests the rows of the runner-up
+    // neighbours of the new cluster for this workgroup's columns, so that they sit in the XCD's L2 when one of them becomes the next merge's
+    // partner (on clustered data the new cluster is in 97 % of the next merges, and its partner was the 2nd or 3rd nearest one or two merges
+    // before in 85 % of them: profiles/r05_linkage_*.txt).  Results do not depend on it.
+    const int T = (int)blockDim.x - (helper ? 64 : 0), NW = (int)blockDim.x >> 6;
+    const bool is_helper = helper && wv == NW - 1;
     int g = blockIdx.x;
     if constexpr (ONEX) {
         // 8 G workgroups were launched; the first G that find themselves on XCC 0 take part (rank = ticket), the others leave (k_linkage_mw)
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
 #pragma unroll
     for (int u = 0; u < RG_U; ++u) {
         const int p = tid + u * T;
-        const int z = p < nown ? z0 + p : -1;
+        const int z = (!is_helper && p < nown) ? z0 + p : -1;
         zc[u] = z;
         const bool row = z >= 0 && z < n - 1;
         c_md[u] = row ? md0[z] : (double)INFINITY; c_md2[u] = row ? md20[z] : (double)INFINITY; c_nb[u] = row ? nb0[z] : -1;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
         const int total = G * nw;
         // a thread's granules are requested together and re-requested together until all of them carry this round's tag (one after the other each
         // would cost its own round trip to the L2: 3 in a row for some threads at 32 workgroups x 16 words and 256 threads)
-        for (int i0 = tid; i0 < total; i0 += 4 * T) {
+        for (int i0 = is_helper ? total : tid; i0 < total; i0 += 4 * T) {
             const MwGran* p[4]; MwGran v[4]; int sl[4], wd[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
 #pragma unroll
         for (int u = 0; u < RG_U; ++u) {
             act[u] = false;
-            if (u < nu) {
+            if (u < nu && !is_helper) {
                 const int z = zc[u];
                 act[u] = z >= 0 && !(c_fl[u] & 2) && z != x && z != y;
                 const int zl = act[u] ? z : zsafe;
@@ -597,10 +602,32 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
                 }
             best = rc_better(best, cy);
         }
+        if (is_helper) {
+            // the two best local NN(y) candidates other than the winner (whose row the pass requests right now)
+            double qv = INFINITY; int qi = -1;
+            if (lane < G) { const RQ t = slot_q(lane, RG_CW); qv = t.v; qi = t.i; }
+            if (qi == nn.i || qi < 0) qv = INFINITY;
+            for (int e = 0; e < 2; ++e) {
+                unsigned long long mm;
+                const double v = wave_argmin_d(qv, mm);
+                const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
+                const int r = v < (double)INFINITY ? __builtin_amdgcn_readlane(qi, l) : -1;
+                if (lane == l) qv = INFINITY;
+                if (r >= 0) {
+                    // requests whose data nobody waits for: the loads pull the lines into the L2, the register they land in is never read
+                    const double* row = D + (int64_t)r * N + z0;
+                    for (int j = lane; j < nown; j += 64) {
+                        double dump;
+                        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(dump) : "v"(row + j) : "memory");
+                    }
+                }
+            }
+        }
         lp ^= 1;
         if (!((best.fl & 1) && best.y >= 0)) pick_stale(cy, lp);
         RSTAMP(4);
     }
+
 #ifdef SD_LINKAGE_STAMPS
     if (g == 0 && tid == 0) for (int i = 0; i < 16; ++i) sync[8 + i] = (unsigned)(acc[i] / 10000);   // 10 kilo-cycles
     if (tid == 0) for (int i = 0; i < 16; ++i) sync[32 + g * 16 + i] = (unsigned)(acc[i] / 10000);   // every workgroup's own view
@@ -616,17 +643,19 @@ bool linkage_rg_fits(int64_t N, int G, int TH)
     return colsB <= (int64_t)RG_U * TH && TH <= RG_T_MAX;
 }
 hipError_t linkage_rg_launch(sd_ctx* c, bool onex, int G, int TH, double* D, int n, int* cid, const int* nb, const double* md, const double* md2,
-                             double* Z, MwGran* gran, unsigned* sync, int cap)
+                             double* Z, MwGran* gran, unsigned* sync, int cap, int helper)
 {
+    if (helper && (TH > 448 || G > 64)) helper = 0;         // (one slot per lane in the helper's fold; 16 waves at most)
+    const int TT = TH + (helper ? 64 : 0);
     const size_t dyn = (((size_t)cap * 9) + 15) & ~(size_t)15;
-    const void* f = TH <= 256 ? (onex ? (const void*)k_linkage_rg<true, 256> : (const void*)k_linkage_rg<false, 256>)
-                  : TH <= 512 ? (onex ? (const void*)k_linkage_rg<true, 512> : (const void*)k_linkage_rg<false, 512>)
+    const void* f = TT <= 256 ? (onex ? (const void*)k_linkage_rg<true, 256> : (const void*)k_linkage_rg<false, 256>)
+                  : TT <= 512 ? (onex ? (const void*)k_linkage_rg<true, 512> : (const void*)k_linkage_rg<false, 512>)
                               : (onex ? (const void*)k_linkage_rg<true, 1024> : (const void*)k_linkage_rg<false, 1024>);
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     (void)hipGetLastError();
-    void* args[] = {&D, &n, &cid, &nb, &md, &md2, &Z, &gran, &sync, &cap, &G};
+    void* args[] = {&D, &n, &cid, &nb, &md, &md2, &Z, &gran, &sync, &cap, &G, &helper};
     // cooperative launch: all workgroups are resident together, or the launch is refused (they poll each other's slots)
-    return hipLaunchCooperativeKernel(f, dim3(onex ? 8 * G : G), dim3(TH), args, dyn, c->stream);
+    return hipLaunchCooperativeKernel(f, dim3(onex ? 8 * G : G), dim3(TT), args, dyn, c->stream);
 }
 int linkage_rg_slot_granules() { return RG_SLOT; }
 

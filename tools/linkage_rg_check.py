@@ -15,7 +15,8 @@ def blobs(rng, N, dd=192, k=4, s=0.6):
     return X / np.linalg.norm(X, axis=1, keepdims=True)
 ok_all = True
 def run(X, G, T, kern, sq=1):
-    d.set_option("linkage_wgs", G); d.set_option("linkage_threads", T); d.set_option("linkage_kernel", kern); d.set_option("linkage_square", sq)
+    d.set_option("linkage_wgs", G); d.set_option("linkage_threads", T); d.set_option("linkage_kernel", min(kern, 1)); d.set_option("linkage_square", sq)
+    d.set_option("linkage_prefetch", 1 if kern == 2 else 0)          # kernel code 2 = rg with the helper (prefetch) wave
     d.reset_stats()
     Z = d.linkage(X)
     return Z, d.kernel_stats("linkage")["ms"], d.kernel_stats("linkage_retry_rounds")["flops"], d.kernel_stats("linkage_fallbacks")["launches"], d.kernel_stats("linkage_rg_launches")["launches"]
@@ -53,5 +54,5 @@ if hours > 0:
         Z, ms, rr, fb, rg = run(X, G, T, kern, -1)
         if Zref is None: Zref = Z
         same = np.array_equal(Z, Zref); ok_all &= same
-        print("planted %gh N=%d kernel %s G=%3d T=%4d: %.1f ms (%.2f us/merge) retry %d fallbacks %d same %s" % (hours, len(X), "rg" if rg else "mw", G, T, ms, ms * 1e3 / (len(X) - 1), rr, fb, same), flush=True)
+        print("planted %gh N=%d kernel %s G=%3d T=%4d: %.1f ms (%.2f us/merge) retry %d fallbacks %d same %s" % (hours, len(X), ("rg+pf" if kern == 2 else "rg") if rg else "mw", G, T, ms, ms * 1e3 / (len(X) - 1), rr, fb, same), flush=True)
 print("ALL OK" if ok_all else "MISMATCH")
