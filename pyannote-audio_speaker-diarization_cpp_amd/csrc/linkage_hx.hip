@@ -34,44 +34,73 @@
 #define HX_OP_QUIT 3
 
 // the reference's heap (cl.cpp:28-119) over two tiers of storage; every operation below is the reference's, swap by swap
+// Storage: the values of the first `lc` entries (the top levels) in LDS, the rest in global memory; keys and positions in LDS as 16-bit
+// numbers when n <= 65 535 (S16), else in global memory.  A sift moves ONE element along a path: it is held in registers and written once
+// at its final place, the elements it passes are shifted by one level -- the array the reference's swap-by-swap loops leave behind
+// (cl.cpp:44-78: every swap exchanges the moving element with the next one on the path), with a third of the memory traffic.
+template <bool S16>
 struct HxHeap {
-    double* lv; int* lk; double* gv; int* gk; int* pos; int lc; int size;
+    double* lv; double* gv; unsigned short* lk16; unsigned short* lp16; int* gk; int* gp; int lc; int size;
     __device__ __forceinline__ double V(int i) const { return i < lc ? lv[i] : gv[i]; }
-    __device__ __forceinline__ int K(int i) const { return i < lc ? lk[i] : gk[i]; }
     __device__ __forceinline__ void setV(int i, double v) { if (i < lc) lv[i] = v; else gv[i] = v; }
-    __device__ __forceinline__ void setK(int i, int k) { if (i < lc) lk[i] = k; else gk[i] = k; }
+    __device__ __forceinline__ int K(int i) const { if constexpr (S16) return (int)lk16[i]; else return gk[i]; }
+    __device__ __forceinline__ void setK(int i, int k) { if constexpr (S16) lk16[i] = (unsigned short)k; else gk[i] = k; }
+    __device__ __forceinline__ int P(int key) const { if constexpr (S16) return (int)lp16[key]; else return gp[key]; }
+    __device__ __forceinline__ void setP(int key, int i) { if constexpr (S16) lp16[key] = (unsigned short)i; else gp[key] = i; }
 };
-__device__ __forceinline__ void hx_swap(HxHeap& h, int a, int b)                          // cl.cpp:70-78
+template <bool S16> __device__ __forceinline__ void hx_swap(HxHeap<S16>& h, int a, int b)                          // cl.cpp:70-78
 {
     const double va = h.V(a), vb = h.V(b);
     h.setV(a, vb); h.setV(b, va);
     const int ka = h.K(a), kb = h.K(b);
     h.setK(a, kb); h.setK(b, ka);
-    h.pos[ka] = b; h.pos[kb] = a;
+    h.setP(ka, b); h.setP(kb, a);
 }
-__device__ __forceinline__ void hx_down(HxHeap& h, int idx)                                // cl.cpp:53-68
+template <bool S16> __device__ __forceinline__ void hx_down(HxHeap<S16>& h, int idx)                                // cl.cpp:53-68
 {
+    const double v = h.V(idx);
+    const int k = h.K(idx);
+    const int start = idx;
     int ch = 2 * idx + 1;
     while (ch < h.size) {
-        if (ch + 1 < h.size && h.V(ch + 1) < h.V(ch)) ch += 1;
-        if (h.V(idx) > h.V(ch)) { hx_swap(h, idx, ch); idx = ch; ch = 2 * idx + 1; }
+        double vc = h.V(ch);
+        if (ch + 1 < h.size) { const double v1 = h.V(ch + 1); if (v1 < vc) { vc = v1; ch += 1; } }
+        if (v > vc) { const int kc = h.K(ch); h.setV(idx, vc); h.setK(idx, kc); h.setP(kc, idx); idx = ch; ch = 2 * idx + 1; }
         else break;
     }
+    if (idx != start) { h.setV(idx, v); h.setK(idx, k); h.setP(k, idx); }
 }
-__device__ __forceinline__ void hx_up(HxHeap& h, int idx)                                  // cl.cpp:44-51
+template <bool S16> __device__ __forceinline__ void hx_up(HxHeap<S16>& h, int idx)                                  // cl.cpp:44-51
 {
-    int par = (idx - 1) >> 1;
-    while (idx > 0 && h.V(par) > h.V(idx)) { hx_swap(h, idx, par); idx = par; par = (idx - 1) >> 1; }
+    const double v = h.V(idx);
+    const int k = h.K(idx);
+    const int start = idx;
+    while (idx > 0) {
+        const int par = (idx - 1) >> 1;
+        const double vp = h.V(par);
+        if (!(vp > v)) break;
+        const int kp = h.K(par);
+        h.setV(idx, vp); h.setK(idx, kp); h.setP(kp, idx);
+        idx = par;
+    }
+    if (idx != start) { h.setV(idx, v); h.setK(idx, k); h.setP(k, idx); }
 }
-__device__ __forceinline__ void hx_change(HxHeap& h, int key, double v)                    // cl.cpp:108-117
+template <bool S16> __device__ __forceinline__ void hx_change(HxHeap<S16>& h, int key, double v)                    // cl.cpp:108-117
 {
-    const int idx = h.pos[key];
+    const int idx = h.P(key);
     const double old = h.V(idx);
     h.setV(idx, v);
     if (v < old) hx_up(h, idx); else hx_down(h, idx);
 }
+// change_value for a value known to have DROPPED (the rows of cl.cpp:381-392: dist < min_dist[z]): the same as hx_change without reading the old value
+template <bool S16> __device__ __forceinline__ void hx_decrease(HxHeap<S16>& h, int key, double v)
+{
+    const int idx = h.P(key);
+    h.setV(idx, v);
+    hx_up(h, idx);
+}
 
-template <bool ONEX>
+template <bool ONEX, bool S16>
 __global__ __launch_bounds__(HX_T) void k_linkage_hx(double* D, int n, int* cid, int* size, int* tyv, int* nb, double* md, double* Z,
                                                      double* g_hval, int* g_hkey, int* g_hpos, MwGran* cmd /*[16]*/, MwGran* rep /*[G][8]*/,
                                                      int* chg_z /*[G][cap]*/, double* chg_v /*[G][cap]*/, unsigned* sync, int cap, int G /*workers*/, int lc)
@@ -115,9 +144,9 @@ __global__ __launch_bounds__(HX_T) void k_linkage_hx(double* D, int n, int* cid,
 
     if (g == 0) {
         // =============================================================== master: the reference's loop, heap included
-        HxHeap h;
-        h.lv = (double*)dyn_lds; h.lk = (int*)(h.lv + lc); h.gv = g_hval; h.gk = g_hkey; h.pos = g_hpos; h.lc = lc; h.size = n - 1;
-        for (int i = tid; i < n - 1; i += HX_T) { h.setV(i, md[i]); h.setK(i, i); h.pos[i] = i; }          // cl.cpp:80-91
+        HxHeap<S16> h;
+        h.lv = (double*)dyn_lds; h.gv = g_hval; h.lk16 = (unsigned short*)(h.lv + lc); h.lp16 = h.lk16 + n; h.gk = g_hkey; h.gp = g_hpos; h.lc = lc; h.size = n - 1;
+        for (int i = tid; i < n - 1; i += HX_T) { h.setV(i, md[i]); h.setK(i, i); h.setP(i, i); }          // cl.cpp:80-91
         __syncthreads();
         if (tid == 0) for (int i = h.size / 2; i >= 0; --i) hx_down(h, i);                                  // cl.cpp:94
         __syncthreads();
@@ -212,7 +241,7 @@ __global__ __launch_bounds__(HX_T) void k_linkage_hx(double* D, int n, int* cid,
                     st_z[e] = LDG(&chg_z[src]); st_v[e] = LDG(&chg_v[src]);
                 }
                 __syncthreads();
-                if (tid == 0) for (int e = 0; e < cnt; ++e) hx_change(h, st_z[e], st_v[e]);
+                if (tid == 0) for (int e = 0; e < cnt; ++e) hx_decrease(h, st_z[e], st_v[e]);
                 __syncthreads();
             }
             if (y < n - 1) {                                                                             // cl.cpp:395-404
@@ -356,7 +385,14 @@ int linkage_hx_run(sd_ctx* c, bool onex, int workers, double* D, int64_t N, int*
     *stopped = false;
     const int G = workers;
     const int cap = (int)((N + G - 1) / G);
-    const int lc = (int)(N - 1 < HX_LDS_HEAP ? N - 1 : HX_LDS_HEAP);
+    // dynamic LDS: 16-bit keys and positions of all entries (n <= 65 535) + as many heap values as fit beside them, at most levels 0-12
+    const bool s16 = N <= 65535;
+    const size_t budget = 130 * 1024;
+    const size_t kp_bytes = s16 ? (size_t)4 * N : 0;
+    int64_t lc64 = kp_bytes < budget ? (int64_t)((budget - kp_bytes) / 8) : 0;
+    if (lc64 > HX_LDS_HEAP) lc64 = HX_LDS_HEAP;
+    if (lc64 > N - 1) lc64 = N - 1;
+    const int lc = (int)lc64;
     WS(c, double, hv, "cl_hval", N);
     WS(c, int, hk, "cl_hkey", N);
     WS(c, int, hp, "cl_hpos", N);
@@ -367,8 +403,9 @@ int linkage_hx_run(sd_ctx* c, bool onex, int workers, double* D, int64_t N, int*
     HIPCHK(c, hipMemsetAsync(cmd, 0, (size_t)(16 + 8 * G) * sizeof(MwGran), c->stream));
     HIPCHK(c, hipMemsetAsync(sync, 0, (32 + 16 * 256) * sizeof(unsigned), c->stream));
     MwGran* rep = cmd + 16;
-    const size_t dyn = (((size_t)lc * 12) + 15) & ~(size_t)15;
-    const void* f = onex ? (const void*)k_linkage_hx<true> : (const void*)k_linkage_hx<false>;
+    const size_t dyn = (((size_t)lc * 8 + kp_bytes) + 15) & ~(size_t)15;
+    const void* f = onex ? (s16 ? (const void*)k_linkage_hx<true, true> : (const void*)k_linkage_hx<true, false>)
+                         : (s16 ? (const void*)k_linkage_hx<false, true> : (const void*)k_linkage_hx<false, false>);
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     (void)hipGetLastError();
     int n_i = (int)N, cap_i = cap, G_i = G, lc_i = lc;

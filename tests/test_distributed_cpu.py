@@ -171,7 +171,39 @@ def test_bench_multi_rank_control_flow_dry_run():
         j = json.loads(lines[0])
         assert j["n_gpus"] == n and j["rccl_ranks"] == n and j["metric"].startswith("DRY-RUN") and "dry-run" in j["data"]
         assert j["config"]["single_job_ms"] > 0 and j["value"] > 0 and j["scaling"] == "weak"
+        sr = j["strong_scaling_reading"]
+        assert sr["scaling"] == "strong" and sr["value"] > 0 and sr["single_job_ms"] > 0 and "no N > 1 number has been measured" in j["multi_gpu_note"]
         if not extra:
             assert "measured on a warm job" in j["config"]["rank0_share"]
         else:
             assert j["config"]["rank0_share"] is None and "[(0, 192), (192, 711)]" in j["config"]["sharding"]     # 25 % of 711 chunks, rounded to 32
+
+
+def test_bench_eight_rank_control_flow_at_the_eight_hour_size():
+    """VERDICT r04 #7, first-contact insurance: the REAL `bench.py --gpus 8` at the size the driver will ask for -- 8 ranks, one hour each,
+    every rank synthesising the hull of its chunk ranges (with the 72 000-sample halo), the measured rank-0 share and the re-plan, the
+    timed region, the single-job pass and the strong-scaling leg (one hour in total over the 8 ranks) -- end to end against the stand-in
+    for the library, well inside the driver's 1 800 s limit (synthesis time included: it is most of the wall here).  Checked: one JSON line,
+    n_gpus / rccl_ranks = 8, weak scaling for `value`, a single-job latency, both readings of BASELINE's metric, the plan's geometry."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run-control-plane", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    wall = time.time() - t0
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and out.stdout.rstrip().endswith(lines[0])          # the JSON line is the last thing on stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["higher_is_better"] is True
+    assert j["metric"].startswith("DRY-RUN") and "dry-run" in j["data"] and j["vs_baseline"] is None
+    assert j["config"]["chunks"] == 57591 and j["config"]["audio_seconds"] == 8 * 3600.0 and j["config"]["single_job_ms"] > 0
+    assert "measured on a warm job" in j["config"]["rank0_share"] and "ncclAllGather" in j["config"]["sharding"]
+    sr = j["strong_scaling_reading"]
+    assert sr["scaling"] == "strong" and sr["chunks"] == 7191 and sr["value"] > 0 and sr["steps"] == 3 and sr["single_job_ms"] > 0
+    assert "no N > 1 number has been measured" in j["multi_gpu_note"]
+    assert wall < 900.0, wall
