@@ -92,6 +92,12 @@ __global__ void k_wav_lens(const int* __restrict__ counts, int items, float* __r
 // The dB values of the item in flight go to a per-workgroup scratch (160 KB, re-used item after item: it stays in L2 / the
 // Infinity Cache and is never re-read by another kernel).
 #include "dft25_gen.h"
+// A/B builds (tools/frontend_ablate.sh; wrong results, timing only): SD_FE_ABLATE = 1: no dB scratch -- phase 1 does not store the tile's dB values and
+// phase 2 reads none (what removing the per-workgroup scratch round trip could gain AT MOST); 2: no FFT arithmetic (stages A and B skipped: the
+// memory traffic alone)
+#ifndef SD_FE_ABLATE
+#define SD_FE_ABLATE 0
+#endif
 #define SIGP 3072                          // padded LDS signal: sample s of the tile sits at s + 16 (s / 160)
 #define MEL_LDS_NNZ 512
 #define YK 17                              // stage A -> B exchange: Y[frame][k1][r], k1 stride padded to 17 complex (bank spread)
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_fbank(
             __syncthreads();
             // ---- stage A
             const int flA = 4 * w + fA;
-            if (t0 + 4 * w < SD_T) {
+            if (SD_FE_ABLATE != 2 && t0 + 4 * w < SD_T) {
                 double x[25], yr[13], yi[13];
                 const float* sp = sig + 176 * flA + r;
 #pragma unroll
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_fbank(
             }
             __syncthreads();
             // ---- stage B (pw aliases sig: every wave is past its stage A reads)
-            if (lane < 52 && t0 + 4 * w < SD_T) {
+            if (SD_FE_ABLATE != 2 && lane < 52 && t0 + 4 * w < SD_T) {
                 const int flB = 4 * w + fB;
                 double vr[16], vi[16];
                 const double2* yi_ = Y + ((size_t)flB * 13 + k1) * YK;
@@ -209,7 +215,9 @@ __global__ __launch_bounds__(256, 2) void k_stft_fbank(
                 if (mel_lds) { const float* qq = &mw[moff[m]]; for (int b = 0; b < c; ++b) acc = fmaf(pp[b], qq[b], acc); }
                 else { const float* qq = &mel_w[moff[m]]; for (int b = 0; b < c; ++b) acc = fmaf(pp[b], qq[b], acc); }
                 const float v = 10.0f * log10f(fmaxf(acc, 1e-10f));
+#if SD_FE_ABLATE != 1
                 db[(size_t)t * SD_NMELS + m] = v;
+#endif
                 vmax = fmaxf(vmax, v);
             }
         }
@@ -223,6 +231,9 @@ __global__ __launch_bounds__(256, 2) void k_stft_fbank(
             const int c = tid % SD_NMELS, g = tid / SD_NMELS;
             float sum = 0.0f;
             int t = g;
+#if SD_FE_ABLATE == 1
+            t = nn; sum = floor_db * (float)nn;
+#endif
             for (; t + 9 < nn; t += 12) {                       // 4 loads in flight; the sum keeps its order
                 const float v0 = db[(size_t)t * SD_NMELS + c], v1 = db[(size_t)(t + 3) * SD_NMELS + c], v2 = db[(size_t)(t + 6) * SD_NMELS + c], v3 = db[(size_t)(t + 9) * SD_NMELS + c];
                 sum += fmaxf(v0, floor_db); sum += fmaxf(v1, floor_db); sum += fmaxf(v2, floor_db); sum += fmaxf(v3, floor_db);
@@ -237,7 +248,11 @@ __global__ __launch_bounds__(256, 2) void k_stft_fbank(
         for (int idx = tid; idx < need * SD_FEAT_LD; idx += 256) {
             const int t = idx / SD_FEAT_LD, c = idx - t * SD_FEAT_LD;
             float v = 0.0f;
+#if SD_FE_ABLATE == 1
+            if (c < SD_NMELS) v = floor_db - mean[c];
+#else
             if (c < SD_NMELS) v = fmaxf(db[(size_t)t * SD_NMELS + c], floor_db) - mean[c];
+#endif
             dst[idx] = v;
         }
     }

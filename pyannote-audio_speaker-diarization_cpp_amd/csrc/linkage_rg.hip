@@ -166,7 +166,7 @@ __device__ __forceinline__ unsigned rq_word(const RQ& q, int k)      // word k o
 #endif
 
 // TB = launch bound (256 / 512 / 1024 threads): the register budget follows it -- 128 VGPRs at 1024 threads spill part of the column state
-template <bool ONEX, int TB>
+template <bool ONEX, int TB, int UU>
 __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, const int* nb0, const double* md0, const double* md20, double* Z,
                                                          MwGran* gran /*[2][G][RG_SLOT], zeroed*/, unsigned* sync, int cap /*columns per workgroup + 1*/, int G, int helper)
 {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
     const int colsB = cap - 1;
     const int z0 = g * colsB;
     const int nown = n - z0 < colsB ? (n - z0 > 0 ? n - z0 : 0) : colsB;
-    const int nu = (nown + T - 1) / T;                       // register slots in use (uniform over the workgroup), <= RG_U
+    const int nu = (nown + T - 1) / T;                       // register slots in use (uniform over the workgroup), <= UU
     const int zsafe = z0 < n ? z0 : 0;                       // a valid column for the loads of idle register slots
     unsigned bar = 0;
     int par = 0, lp = 0;
@@ -217,10 +217,10 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
 #endif
 
     // ---- per-column state, registers
-    int zc[RG_U], c_nb[RG_U], c_fl[RG_U], c_ty[RG_U], c_sz[RG_U], c_nbsz[RG_U], c_nbty[RG_U];
-    double c_md[RG_U], c_md2[RG_U];
+    int zc[UU], c_nb[UU], c_fl[UU], c_ty[UU], c_sz[UU], c_nbsz[UU], c_nbty[UU];
+    double c_md[UU], c_md2[UU];
 #pragma unroll
-    for (int u = 0; u < RG_U; ++u) {
+    for (int u = 0; u < UU; ++u) {
         const int p = tid + u * T;
         const int z = (!is_helper && p < nown) ? z0 + p : -1;
         zc[u] = z;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
                 const int xr = Lprev[r];
                 const RQ q = s_row[r];
 #pragma unroll
-                for (int u = 0; u < RG_U; ++u)
+                for (int u = 0; u < UU; ++u)
                     if (zc[u] == xr) {
                         c_nb[u] = q.i; c_md[u] = (q.i < 0) ? (double)INFINITY : q.v; c_md2[u] = (q.i < 0) ? (double)INFINITY : q.v2;
                         c_fl[u] = (c_fl[u] & 2) | 1; c_nbsz[u] = q.sz; c_nbty[u] = q.ty;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
         for (int r = 0; r < RG_KR; ++r) ex[r] = r < nL ? L[r] : -1;
         RCand m = rc_none();
 #pragma unroll
-        for (int u = 0; u < RG_U; ++u) {
+        for (int u = 0; u < UU; ++u) {
             const int z = zc[u];
             bool skip = z < 0 || (c_fl[u] & 2) || z >= n - 1;
 #pragma unroll
@@ -504,9 +504,9 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
         RQ q = rq_none();
         RCand m = rc_none();
         int row_tie = 0;
-        double dzx[RG_U], dzy[RG_U]; bool act[RG_U];
+        double dzx[UU], dzy[UU]; bool act[UU];
 #pragma unroll
-        for (int u = 0; u < RG_U; ++u) {
+        for (int u = 0; u < UU; ++u) {
             act[u] = false;
             if (u < nu && !is_helper) {
                 const int z = zc[u];
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
         }
         RSTAMP(8);
 #pragma unroll
-        for (int u = 0; u < RG_U; ++u) {
+        for (int u = 0; u < UU; ++u) {
             if (u < nu && act[u]) {
 #ifdef SD_LINKAGE_STAMPS
                 { const bool fx = (txm < c_ty[u]) || (tym < c_ty[u]); fix_lanes += fx ? 1u : 0u; }
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
         }
         RSTAMP(9);
 #pragma unroll
-        for (int u = 0; u < RG_U; ++u) {
+        for (int u = 0; u < UU; ++u) {
             if (!(u < nu && act[u])) continue;
             const int z = zc[u];
             const double nd = lw_centroid(dzx[u], dzy[u], dist, nx, ny);
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
         RSTAMP(10);
         // ---- the pair's own columns: x is gone, y is the merged cluster, rewritten in this merge
 #pragma unroll
-        for (int u = 0; u < RG_U; ++u) {
+        for (int u = 0; u < UU; ++u) {
             if (zc[u] == x) { c_fl[u] |= 2; l_dead[tid + u * T] = 1; }
             if (zc[u] == y) { c_sz[u] = nx + ny; c_ty[u] = k; l_sz[tid + u * T] = nx + ny; l_ty[tid + u * T] = k; }
         }
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
         if (y < n - 1) {
             if (nn.i >= 0) { cy.v = nn.v; cy.i = y; cy.y = nn.i; cy.fl = 1; cy.szi = nx + ny; cy.szy = nn.sz; cy.tyi = k; cy.tyy = nn.ty; }
 #pragma unroll
-            for (int u = 0; u < RG_U; ++u)
+            for (int u = 0; u < UU; ++u)
                 if (zc[u] == y) {
                     c_nb[u] = nn.i; c_md[u] = nn.i >= 0 ? nn.v : (double)INFINITY; c_md2[u] = nn.i >= 0 ? nn.v2 : (double)INFINITY;
                     c_fl[u] = (c_fl[u] & 2) | 1; c_nbsz[u] = nn.sz; c_nbty[u] = nn.ty;
@@ -640,7 +640,7 @@ bool linkage_rg_fits(int64_t N, int G, int TH)
 {
     if (G < 2 || G > RG_GMAX) return false;
     const int64_t colsB = (N + G - 1) / G;
-    return colsB <= (int64_t)RG_U * TH && TH <= RG_T_MAX;
+    return colsB <= (int64_t)(TH <= 512 ? 8 : RG_U) * TH && TH <= RG_T_MAX;         // (8 columns per thread: the <= 512-thread forms only -- register budget)
 }
 hipError_t linkage_rg_launch(sd_ctx* c, bool onex, int G, int TH, double* D, int n, int* cid, const int* nb, const double* md, const double* md2,
                              double* Z, MwGran* gran, unsigned* sync, int cap, int helper)
@@ -648,9 +648,12 @@ hipError_t linkage_rg_launch(sd_ctx* c, bool onex, int G, int TH, double* D, int
     if (helper && (TH > 448 || G > 64)) helper = 0;         // (one slot per lane in the helper's fold; 16 waves at most)
     const int TT = TH + (helper ? 64 : 0);
     const size_t dyn = (((size_t)cap * 9) + 15) & ~(size_t)15;
-    const void* f = TT <= 256 ? (onex ? (const void*)k_linkage_rg<true, 256> : (const void*)k_linkage_rg<false, 256>)
-                  : TT <= 512 ? (onex ? (const void*)k_linkage_rg<true, 512> : (const void*)k_linkage_rg<false, 512>)
-                              : (onex ? (const void*)k_linkage_rg<true, 1024> : (const void*)k_linkage_rg<false, 1024>);
+    const bool wide = (int64_t)(cap - 1) > (int64_t)RG_U * TH;         // more than 4 columns per thread: the 8-column form
+    const void* f = wide ? (TT <= 256 ? (onex ? (const void*)k_linkage_rg<true, 256, 8> : (const void*)k_linkage_rg<false, 256, 8>)
+                                      : (onex ? (const void*)k_linkage_rg<true, 512, 8> : (const void*)k_linkage_rg<false, 512, 8>))
+                  : TT <= 256 ? (onex ? (const void*)k_linkage_rg<true, 256, RG_U> : (const void*)k_linkage_rg<false, 256, RG_U>)
+                  : TT <= 512 ? (onex ? (const void*)k_linkage_rg<true, 512, RG_U> : (const void*)k_linkage_rg<false, 512, RG_U>)
+                              : (onex ? (const void*)k_linkage_rg<true, 1024, RG_U> : (const void*)k_linkage_rg<false, 1024, RG_U>);
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     (void)hipGetLastError();
     void* args[] = {&D, &n, &cid, &nb, &md, &md2, &Z, &gran, &sync, &cap, &G, &helper};

@@ -507,10 +507,11 @@ def test_linkage_bit_exact(diarizer, N, d):
     assert np.array_equal(diarizer.cluster(X, cutoff), T_ref)
 
 
-@pytest.mark.parametrize("N,G,T", [(3, 2, 256), (65, 7, 512), (300, 64, 256), (300, 200, 1024), (2000, 16, 256), (2000, 32, 256), (5000, 64, 512)])
+@pytest.mark.parametrize("N,G,T", [(3, 2, 256), (65, 7, 512), (300, 64, 256), (300, 200, 1024), (2000, 16, 256), (2000, 32, 256), (5000, 64, 512), (5000, 2, 256), (3000, 3, 128)])
 def test_cooperative_linkage_bit_exact(diarizer, N, G, T):
-    """k_linkage_mw (G co-resident workgroups, LDS active-row lists, cooperative refresh of stale rows) gives the
-    oracle's dendrogram bit for bit for any workgroup count / size"""
+    """the cooperative kernels (k_linkage_rg: per-column state in registers, 4 or -- (5000, 2, 256), (3000, 3, 128) -- 8 columns per thread;
+    k_linkage_mw where the geometry does not fit it, e.g. 200 workgroups) give the oracle's dendrogram bit for bit for any workgroup
+    count / size"""
     rng = np.random.default_rng(1000 + N + G)
     X = _blobs(rng, N)
     _, Z_ref = orc.ahc(X, orc.THRESH_F32)
@@ -627,7 +628,7 @@ def test_heap_linkage_with_global_heap_is_bit_identical(diarizer):
     assert np.array_equal(Z, Z_ref)
 
 
-@pytest.mark.parametrize("square", [1, 0])
+@pytest.mark.parametrize("square", [1, 0, 2])
 @pytest.mark.parametrize("N,d,G,T", [(2500, 3, 32, 256), (4000, 2, 16, 512), (3000, 8, 64, 256), (6000, 3, -1, 0)])
 def test_cooperative_linkage_on_unclustered_low_dimensional_data(diarizer, N, d, G, T, square):
     """uniform points in 2 / 3 / 8 dimensions: the opposite regime of the speaker embeddings.  Merges are balanced (many small clusters grow
@@ -640,16 +641,20 @@ def test_cooperative_linkage_on_unclustered_low_dimensional_data(diarizer, N, d,
     _, Z_ref = orc.ahc(X, orc.THRESH_F32)
     fb0 = diarizer.kernel_stats("linkage_fallbacks")["launches"]
     rr0 = diarizer.kernel_stats("linkage_retry_rounds")["flops"]
+    rg0 = diarizer.kernel_stats("linkage_rg_launches")["launches"]
     diarizer.set_option("linkage_wgs", G)
     diarizer.set_option("linkage_threads", T)
-    diarizer.set_option("linkage_square", square)
+    diarizer.set_option("linkage_square", 1 if square else 0)          # 1: square matrix, k_linkage_rg; 2: square matrix, k_linkage_mw; 0: condensed, k_linkage_mw
+    diarizer.set_option("linkage_kernel", 0 if square == 2 else -1)
     try:
         Z = diarizer.linkage(X)
     finally:
         diarizer.set_option("linkage_wgs", -1)
         diarizer.set_option("linkage_threads", 0)
         diarizer.set_option("linkage_square", -1)
+        diarizer.set_option("linkage_kernel", -1)
     assert np.array_equal(Z, Z_ref)
+    assert (diarizer.kernel_stats("linkage_rg_launches")["launches"] - rg0 == 1) == (square == 1)
     assert diarizer.kernel_stats("linkage_fallbacks")["launches"] == fb0
     assert diarizer.kernel_stats("linkage_retry_rounds")["flops"] > rr0          # stale candidates did reach the top here
 
