@@ -143,35 +143,44 @@ __global__ __launch_bounds__(256, 2) void k_stft_fbank(
         for (int k = tid; k < 296; k += 256) pre[k] = prefix[(size_t)item * 296 + k];
         float vmax = -INFINITY;
         const int t_end = sig_mode ? SD_T : need;
-        for (int t0 = 0; t0 < t_end; t0 += 16) {
-            __syncthreads();                                   // pre is loaded; the previous tile's mel pass is done with pw
-            // ---- gather the compacted samples [160 t0 - 200, +2800): each thread a run of 11 consecutive ones
-            {
-                const int mstart = 160 * t0 - 200;
-                const int s0 = tid * 11;
-                int f = -1, fend = 0, fbeg = 0, fsrc = 0;     // current mask frame: compacted range [fbeg, fend), first source sample
-                int src[11];                                  // source sample relative to the chunk start, -1 = zero
-                const int64_t room = n - chunk_start;
+        const int64_t room = n - chunk_start;
+        // the compacted samples [160 t0 - 200, +2800) of a tile: each thread a run of 11 consecutive ones.  The requests of tile t0 + 16 are
+        // issued BEFORE tile t0 is computed and land in registers meanwhile (r05: a tile's gather -- a binary search in the prefix table, then
+        // loads that miss the L2 for every chunk's newest tenth -- used to be waited for at the head of every tile; the kernel without any FFT
+        // arithmetic still took 5.7 of its 7.4 ms, profiles/r05_frontend_ablation_a.txt)
+        float vn[11];
+        auto gather_issue = [&](int t0) {
+            const int mstart = 160 * t0 - 200;
+            const int s0 = tid * 11;
+            int f = -1, fend = 0, fbeg = 0, fsrc = 0;     // current mask frame: compacted range [fbeg, fend), first source sample
+            int src[11];                                  // source sample relative to the chunk start, -1 = zero
 #pragma unroll
-                for (int q = 0; q < 11; ++q) {                // addresses first ...
-                    const int m = mstart + s0 + q;
-                    src[q] = -1;
-                    if (s0 + q < 2800 && m >= 0 && m < cnt) {
-                        if (f < 0 || m >= fend) {             // smallest f with pre[f+1] > m (binary search once per run, then walk)
-                            int lo = 0, hi = SD_FRAMES - 1;
-                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pre[mid + 1] > m) hi = mid; else lo = mid + 1; }
-                            f = lo; fbeg = pre[f]; fend = pre[f + 1]; fsrc = frame_start(f);
-                        }
-                        const int sp = fsrc + (m - fbeg);
-                        if ((int64_t)sp < room) src[q] = sp;
+            for (int q = 0; q < 11; ++q) {                // addresses first ...
+                const int m = mstart + s0 + q;
+                src[q] = -1;
+                if (s0 + q < 2800 && m >= 0 && m < cnt) {
+                    if (f < 0 || m >= fend) {             // smallest f with pre[f+1] > m (binary search once per run, then walk)
+                        int lo = 0, hi = SD_FRAMES - 1;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (pre[mid + 1] > m) hi = mid; else lo = mid + 1; }
+                        f = lo; fbeg = pre[f]; fend = pre[f + 1]; fsrc = frame_start(f);
                     }
+                    const int sp = fsrc + (m - fbeg);
+                    if ((int64_t)sp < room) src[q] = sp;
                 }
-                float v[11];
-#pragma unroll
-                for (int q = 0; q < 11; ++q) v[q] = src[q] >= 0 ? wav[chunk_start - origin + src[q]] : 0.0f;      // ... then all loads in flight together
-#pragma unroll
-                for (int q = 0; q < 11; ++q) { const int sidx = s0 + q; if (sidx < 2800) sig[sidx + 16 * (sidx / 160)] = v[q]; }
             }
+#pragma unroll
+            for (int q = 0; q < 11; ++q) vn[q] = src[q] >= 0 ? wav[chunk_start - origin + src[q]] : 0.0f;      // ... then all loads in flight together
+        };
+        __syncthreads();                                   // pre is loaded
+        gather_issue(0);
+        for (int t0 = 0; t0 < t_end; t0 += 16) {
+            __syncthreads();                               // the previous tile's mel pass is done with pw
+            {
+                const int s0 = tid * 11;
+#pragma unroll
+                for (int q = 0; q < 11; ++q) { const int sidx = s0 + q; if (sidx < 2800) sig[sidx + 16 * (sidx / 160)] = vn[q]; }
+            }
+            if (t0 + 16 < t_end) gather_issue(t0 + 16);
             __syncthreads();
             // ---- stage A
             const int flA = 4 * w + fA;
