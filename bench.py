@@ -528,7 +528,7 @@ def main():
     cg_e, cg_s = d.kernel_stats("conv_w256_ecapa"), d.kernel_stats("conv_w256_seg")
     stages = d.stage_ms()
     extra = {}
-    for k in ("stft_mel", "lstm_rec", "pdist", "linkage", "linkage_heap", "row_nn", "se_apply", "asp_pool", "rccl_all_gather"):
+    for k in ("stft_mel", "lstm_rec", "pdist", "linkage", "linkage_hx", "linkage_heap", "row_nn", "se_apply", "asp_pool", "rccl_all_gather"):
         s = d.kernel_stats(k)
         if s["launches"] == 0:
             continue
