@@ -1107,7 +1107,7 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     // boxes disagree, 256 wins on two of three; all XCDs 128 x 512 0.99 s at N = 100 174 (128 x 256: 1.10 s)
     // one XCD, larger N: 512 threads (N = 18 867: 121 ms against 126; N = 25 274: 170 against 179; N = 50 158: 384 against 465)
     if (TH <= 0) TH = auto_onex ? (N >= 16000 ? 512 : 256) : N >= 8000 ? 512 : 256;
-    TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : TH >= 256 ? 256 : 128;
+    TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : TH >= 256 ? 256 : TH >= 128 ? 128 : 64;
     if (G <= 1) {
         WS(c, double, D, "cl_D", m);
         if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2))) return rc;
