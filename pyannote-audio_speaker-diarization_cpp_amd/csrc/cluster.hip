@@ -1137,6 +1137,10 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         while (t2 < 1024 && !linkage_rg_fits(N, G, t2)) t2 *= 2;
         if (linkage_rg_fits(N, G, t2) && (c->linkage_threads <= 0 || c->linkage_kernel > 0)) TH = t2; else use_rg = false;
     }
+    // k_linkage_mw runs with at most 512 threads: with 1024 (16 waves; never the automatic choice) the CONDENSED form gave a wrong late merge in ~4 % of
+    // the runs of a 2 200-row job (round 5, tools/linkage_fuzz.py + tools/linkage_stress.py: blobs in 1-D, 31 workgroups; 0 of 150 runs at 512 / 256 threads,
+    // 0 of 150 for both square-form kernels at 1024) -- a timing-dependent defect of that form that was not found; profiles/r05_linkage_fuzz.txt
+    if (!use_rg && TH > 512) TH = 512;
     const int slot_gran = use_rg ? linkage_rg_slot_granules() : SLOT_WORDS;
     WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * slot_gran);
     HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * slot_gran * sizeof(MwGran), c->stream));

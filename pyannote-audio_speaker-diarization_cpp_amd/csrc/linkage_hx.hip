@@ -241,7 +241,33 @@ __global__ __launch_bounds__(HX_T) void k_linkage_hx(double* D, int n, int* cid,
                     st_z[e] = LDG(&chg_z[src]); st_v[e] = LDG(&chg_v[src]);
                 }
                 __syncthreads();
-                if (tid == 0) for (int e = 0; e < cnt; ++e) hx_decrease(h, st_z[e], st_v[e]);
+                // change_value for every staged row, in list order.  A decrease whose new value is still >= its parent's moves nothing (cl.cpp:44-51:
+                // the sift-up loop ends at once); a parent's value only ever DROPS while the list is worked off, so an entry that passes that test against
+                // the heap as it stands passes it whenever its turn comes, and a run of such entries can be written at once.  Wave 0 takes 64 entries at a
+                // time: the lanes in front of the first entry that WOULD move write their values together, that entry is sifted by its lane alone,
+                // and the rest of the chunk is looked at again (on clustered data most bounds drop by a little and stay where they are).
+                if (wv == 0) {
+                    int e0 = 0;
+                    while (e0 < cnt) {
+                        const int e = e0 + lane;
+                        const bool valid = e < cnt;
+                        int idx = 0; double v = 0.0; bool stay = false;
+                        if (valid) {
+                            idx = h.P(st_z[e]); v = st_v[e];
+                            stay = idx == 0 || !(h.V((idx - 1) >> 1) > v);
+                        }
+                        const unsigned long long mv = __ballot(valid && !stay);
+                        const int f = mv ? __builtin_ctzll(mv) : 64;               // first lane whose entry moves
+                        if (valid && lane < f) h.setV(idx, v);
+                        __builtin_amdgcn_wave_barrier();
+                        if (f < 64) {
+                            if (lane == f) hx_decrease(h, st_z[e], st_v[e]);
+                            e0 += f + 1;
+                        } else e0 += 64;
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this pass's heap writes are done before the next pass reads the heap
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
                 __syncthreads();
             }
             if (y < n - 1) {                                                                             // cl.cpp:395-404

@@ -49,8 +49,10 @@ while time.time() - t0 < budget:
     d.set_option("linkage_wgs", G); d.set_option("linkage_threads", T)
     d.set_option("linkage_kernel", 0 if mode == 2 else -1)
     d.set_option("linkage_force_heap", 1 if mode == 3 else 0)
-    d.set_option("linkage_tie_kernel", int(rng.choice([1, 3, 31, 63])) if mode == 3 or rng.random() < 0.5 else 1)
-    d.set_option("linkage_square", int(rng.choice([-1, 1, 0])))
+    tk = int(rng.choice([1, 3, 31, 63])) if mode == 3 or rng.random() < 0.5 else 1
+    sq = int(rng.choice([-1, 1, 0]))
+    d.set_option("linkage_tie_kernel", tk)
+    d.set_option("linkage_square", sq)
     if mode == 3: d.set_option("linkage_wgs", 16)     # (a cooperative geometry, so that the forced replay is k_linkage_hx also below N = 1500)
     try:
         Z = d.linkage(X)
@@ -61,7 +63,14 @@ while time.time() - t0 < budget:
     runs += 1; by[kind] = by.get(kind, 0) + 1
     if not ok:
         fails += 1
-        print("MISMATCH kind=%s N=%d d=%d mode=%d G=%d T=%d" % (kind, N, dd, mode, G, T), flush=True)
+        rows = np.where((Z != Zr).any(1))[0] if Z.shape == Zr.shape else []
+        again = 0
+        for _ in range(20):
+            again += 0 if np.array_equal(d.linkage(X), Zr, equal_nan=True) else 1
+        print("MISMATCH kind=%s N=%d d=%d mode=%d G=%d T=%d square=%d tie_kernel=%d run %d: %d rows differ, first %s got %s want %s; the same job again: %d of 20 differ; stats rg %d hx %d tie-fallbacks %d fallbacks %d timeouts %d" % (
+              kind, N, dd, mode, G, T, sq, tk, runs, len(rows), rows[:1], Z[rows[0]] if len(rows) else None, Zr[rows[0]] if len(rows) else None, again,
+              d.kernel_stats("linkage_rg_launches")["launches"], d.kernel_stats("linkage_hx_jobs")["launches"], d.kernel_stats("linkage_tie_fallbacks")["launches"],
+              d.kernel_stats("linkage_fallbacks")["launches"], d.kernel_stats("linkage_one_xcd_timeouts")["launches"]), flush=True)
 for k in ("linkage_rg_launches", "linkage_hx_jobs", "linkage_tie_fallbacks", "linkage_fallbacks", "linkage_hx_failed", "linkage_one_xcd_timeouts"):
     print(k, d.kernel_stats(k)["launches"])
 print("runs %d failures %d by family %s (%.0f s)" % (runs, fails, by, time.time() - t0))
