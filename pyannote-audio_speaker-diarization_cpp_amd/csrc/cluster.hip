@@ -969,11 +969,18 @@ __global__ __launch_bounds__(MWT_MAX) void k_linkage_mw(double* D, int n, int* s
         if (y < n - 1) {
             if (nn.i >= 0) {
                 cy.v = nn.v; cy.i = y; cy.y = nn.i; cy.fresh = 1;
-                // (lane 0 of EVERY wave writes the same values: the next pass starts without a workgroup barrier, and a wave reads LDS behind its own writes)
-                if (lane == 0 && own(y)) { const int py = slot(y); l_nb[py] = nn.i; l_md[py] = nn.v; l_md2[py] = nn.v2; l_fr[py] = 1; if (tid == 0) { STX<ONEX>(&nb[y], nn.i); STX<ONEX>(&md[y], nn.v); } }
+                // The next pass starts without a workgroup barrier, and a wave reads LDS behind its own writes: the values are written by the ONE wave whose
+                // thread reads slot py in the pass (slot p belongs to thread p % T).  (Until round 5 lane 0 of EVERY wave wrote them: a wave that fell a
+                // whole pass behind then overwrote the update the next merge had already made to the slot -- a wrong late merge in ~4 % of the runs of a
+                // 2 200-row job with 16 waves per workgroup, none seen with 8 or 4; found by tools/linkage_fuzz.py, profiles/r05_linkage_fuzz.txt.)
+                if (own(y)) {
+                    const int py = slot(y);
+                    if (lane == 0 && wv == ((py % T) >> 6)) { l_nb[py] = nn.i; l_md[py] = nn.v; l_md2[py] = nn.v2; l_fr[py] = 1; }
+                    if (tid == 0) { STX<ONEX>(&nb[y], nn.i); STX<ONEX>(&md[y], nn.v); }
+                }
             } else {
                 cy.v = LDG(&md[y]); cy.i = y; cy.y = LDG(&nb[y]); cy.fresh = 0;
-                if (lane == 0 && own(y)) l_fr[slot(y)] = 0;
+                if (own(y)) { const int py = slot(y); if (lane == 0 && wv == ((py % T) >> 6)) l_fr[py] = 0; }
             }
             best = cbetter(best, cy);
             __builtin_amdgcn_wave_barrier();       // keep the LDS stores above in front of the next pass's LDS loads in the instruction stream
@@ -1137,10 +1144,6 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         while (t2 < 1024 && !linkage_rg_fits(N, G, t2)) t2 *= 2;
         if (linkage_rg_fits(N, G, t2) && (c->linkage_threads <= 0 || c->linkage_kernel > 0)) TH = t2; else use_rg = false;
     }
-    // k_linkage_mw runs with at most 512 threads: with 1024 (16 waves; never the automatic choice) the CONDENSED form gave a wrong late merge in ~4 % of
-    // the runs of a 2 200-row job (round 5, tools/linkage_fuzz.py + tools/linkage_stress.py: blobs in 1-D, 31 workgroups; 0 of 150 runs at 512 / 256 threads,
-    // 0 of 150 for both square-form kernels at 1024) -- a timing-dependent defect of that form that was not found; profiles/r05_linkage_fuzz.txt
-    if (!use_rg && TH > 512) TH = 512;
     const int slot_gran = use_rg ? linkage_rg_slot_granules() : SLOT_WORDS;
     WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * slot_gran);
     HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * slot_gran * sizeof(MwGran), c->stream));
