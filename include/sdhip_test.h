@@ -46,7 +46,10 @@ int sd_test_pack_split_weights(const float* w, int K, int Cout, int CinPad, int 
  * takes), "conv_pn" / "conv_pn128" (column tiles per super-block), "ecapa_ld_pad" (elements added to the activation rows, multiple of 8),
  * "seg_shared_conv0" (1 = SincNet's first convolution once over the waveform instead of once per overlapping chunk), "seg_wide_ih" (1 = LSTM input
  * projections of layers 1-3 on the 256 x 256 tile), "linkage_square" (-1 auto, 0 condensed, 1 full N x N distance matrix), "ecapa_f16_hp" /
- * "ecapa_keep_cat" (precision diagnostics of tools/diag_fp16_layers.py), "ws_limit_mb" (test: PROCESS-WIDE, a workspace request above this many
+ * "ecapa_keep_cat" (precision diagnostics of tools/diag_fp16_layers.py), "linkage_kernel" (-1 auto / 1: k_linkage_rg for the square matrix where its geometry fits,
+ * 0: k_linkage_mw), "linkage_tie_kernel" (what finishes a job with exact ties: 1 = k_linkage_hx, n > 1 = with n worker workgroups, 0 = k_linkage_heap),
+ * "linkage_force_heap" (1 = skip the cooperative kernel: the heap replay on tie-free data), "linkage_hx_wide" (1 = k_linkage_hx's 32-bit key / position form, which
+ * jobs above 65 535 rows take, on any size), "linkage_prefetch" (1 = k_linkage_rg's helper wave; measured: no gain), "ws_limit_mb" (test: PROCESS-WIDE, a workspace request above this many
  * MB fails as on an exhausted GPU; 0 = off) and "emb_batch_default" (test: forget an explicit "emb_batch_items"; value = embedding calls the
  * context pretends to have made, 0 = the next one plans the small first-job arena). */
 /* environment (diagnostic): SD_TRACE_CREATE=1 prints where sd_create's time goes; SD_TRACE_WS=1 makes sd_diarize_dev print the job's stage times and what the

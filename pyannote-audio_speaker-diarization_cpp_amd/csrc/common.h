@@ -185,6 +185,7 @@ struct sd_ctx {
     int64_t linkage_one_xcd = 1;               // 1 = k_linkage_mw<true> (all workgroups on one XCD) when G <= 64
     int64_t linkage_tie_kernel = 1;            // what finishes a job with exact ties: 1 = k_linkage_hx (heap replay, row work on worker workgroups; > 1 = that many workers), 0 = k_linkage_heap (one workgroup)
     int64_t linkage_prefetch = 0;              // k_linkage_rg: 1 = a helper wave per workgroup requests the rows of the runner-up neighbours ahead of time
+    bool linkage_hx_wide = false;              // test: k_linkage_hx with 32-bit heap keys / positions in global memory (the form of N > 65 535) on any size
     bool linkage_force_heap = false;           // test / measurement: skip the cooperative kernel, go straight to the heap replay
     int64_t linkage_kernel = -1;               // -1 auto / 1: k_linkage_rg (linkage_rg.hip) for the square form where its geometry fits; 0: k_linkage_mw
     int64_t linkage_threads = 0;               // 0 auto (256, or 1024 for N >= 60000), else 256 / 512 / 1024 threads per cooperative workgroup

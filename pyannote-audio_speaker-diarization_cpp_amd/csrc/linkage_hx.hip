@@ -412,7 +412,7 @@ int linkage_hx_run(sd_ctx* c, bool onex, int workers, double* D, int64_t N, int*
     const int G = workers;
     const int cap = (int)((N + G - 1) / G);
     // dynamic LDS: 16-bit keys and positions of all entries (n <= 65 535) + as many heap values as fit beside them, at most levels 0-12
-    const bool s16 = N <= 65535;
+    const bool s16 = N <= 65535 && !c->linkage_hx_wide;          // (option linkage_hx_wide: the 32-bit key / position form, which jobs above 65 535 rows take, on any size -- tests)
     const size_t budget = 130 * 1024;
     const size_t kp_bytes = s16 ? (size_t)4 * N : 0;
     int64_t lc64 = kp_bytes < budget ? (int64_t)((budget - kp_bytes) / 8) : 0;

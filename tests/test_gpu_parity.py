@@ -571,11 +571,13 @@ def test_heap_replay_with_worker_workgroups_is_bit_identical(diarizer, workers):
         j0 = diarizer.kernel_stats("linkage_hx_jobs")["launches"]
         diarizer.set_option("linkage_tie_kernel", workers)
         diarizer.set_option("linkage_force_heap", force)
+        diarizer.set_option("linkage_hx_wide", 1 if workers == 5 else 0)          # (5 workers: also the 32-bit key / position form of jobs above 65 535 rows)
         try:
             Z = diarizer.linkage(X)
         finally:
             diarizer.set_option("linkage_tie_kernel", 1)
             diarizer.set_option("linkage_force_heap", 0)
+            diarizer.set_option("linkage_hx_wide", 0)
         assert np.array_equal(Z, Z_ref), (name, workers)
         assert diarizer.kernel_stats("linkage_hx_jobs")["launches"] == j0 + 1, (name, workers)      # it was this kernel, not the one-workgroup fallback
     assert diarizer.kernel_stats("linkage_hx_stale_scans")["flops"] > 0

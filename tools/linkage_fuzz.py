@@ -52,6 +52,7 @@ while time.time() - t0 < budget:
     tk = int(rng.choice([1, 3, 31, 63])) if mode == 3 or rng.random() < 0.5 else 1
     sq = int(rng.choice([-1, 1, 0]))
     d.set_option("linkage_tie_kernel", tk)
+    d.set_option("linkage_hx_wide", int(rng.random() < 0.3))
     d.set_option("linkage_square", sq)
     if mode == 3: d.set_option("linkage_wgs", 16)     # (a cooperative geometry, so that the forced replay is k_linkage_hx also below N = 1500)
     try:
