@@ -407,11 +407,11 @@ class Diarizer:
         """sd_set_dump_dir: the reference's WRITE_DATA items as <path>/cpp_<item>.txt from the next whole-path call on (None = off)"""
         self._chk(lib().sd_set_dump_dir(self._h, str(path).encode() if path else None, level if path else 0))
 
-    def diarize_wav(self, path, resample=False, downmix=False):
-        """sd_diarize_wav: reader + sample-rate / channel handling + the whole path (SD_WAV_RESAMPLE = 1, SD_WAV_DOWNMIX = 2)"""
+    def diarize_wav(self, path, resample=False, downmix=False, assume_16k=False):
+        """sd_diarize_wav: reader + sample-rate / channel handling + the whole path (SD_WAV_RESAMPLE = 1, SD_WAV_DOWNMIX = 2, SD_WAV_ASSUME_16K = 4)"""
         p = C.POINTER(Turn)()
         n = C.c_int64(0)
-        self._chk(lib().sd_diarize_wav(self._h, str(path).encode(), (1 if resample else 0) | (2 if downmix else 0), C.byref(p), C.byref(n)))
+        self._chk(lib().sd_diarize_wav(self._h, str(path).encode(), (1 if resample else 0) | (2 if downmix else 0) | (4 if assume_16k else 0), C.byref(p), C.byref(n)))
         return self._turns(p, n)
 
     def resample(self, wav, in_sr, out_sr=16000):

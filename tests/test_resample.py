@@ -109,3 +109,9 @@ def test_wav_entry_point_checks_rate_and_channels(diarizer, weights, tmp_path):
     assert out.returncode == 1 and "44100" in out.stderr
     out = subprocess.run([exe, weights[0], weights[1], str(tmp_path / "m44.wav"), "--resample"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.count("--> Speaker_") == len(got)
+    # SD_WAV_ASSUME_16K / --assume-16k: the reference's own behaviour on such a file (sample_rate read and ignored, sd.cpp:2940-2942): the 44.1 kHz samples
+    # are diarized as if they were 16 kHz -- exactly sd_diarize of those samples
+    as16 = diarizer.diarize_wav(tmp_path / "m44.wav", assume_16k=True)
+    assert as16 == diarizer.diarize(pcm44) and as16 != got
+    out = subprocess.run([exe, weights[0], weights[1], str(tmp_path / "m44.wav"), "--assume-16k"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.count("--> Speaker_") == len(as16)
