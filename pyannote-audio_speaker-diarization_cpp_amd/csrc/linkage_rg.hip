@@ -733,18 +733,20 @@ __global__ __launch_bounds__(256) void k_rg_parts(double* D, int n, MwGran* gran
             q = sh_q[0]; m = sh_c[0];
             for (int w2 = 1; w2 < NW; ++w2) { q = rq_merge(q, sh_q[w2]); m = rc_better(m, sh_c[w2]); }
         }
+        const int PW = (parts & 128) ? NW : 1;            // parts & 128: every WAVE publishes its own record (no LDS fold in front of the publish): G * NW slots
         if (parts & 16) {
             ++bar;
-            if (wv == 0) {
-                MwGran* sl = gran + ((size_t)par * G + g) * RG_SLOT;
+            if (parts & 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (wv == 0 || (parts & 128)) {
+                MwGran* sl = gran + ((size_t)par * G * PW + (size_t)g * PW + ((parts & 128) ? wv : 0)) * RG_SLOT;
                 const MwGran tag = (MwGran)bar << 32;
                 unsigned w = 0; bool on = false;
                 if (lane < RG_CW) { on = true; w = lane == 0 ? lo32(m.v) : lane == 1 ? hi32(m.v) : lane == 2 ? (unsigned)m.i : lane == 3 ? (unsigned)m.y : 1u; }
                 else if (lane < RG_CW + RG_QW) { on = true; w = rq_word(q, lane - RG_CW); }
                 if (on) STX<ONEX>(&sl[lane], tag | (MwGran)w);
             }
-            const MwGran* base = gran + (size_t)par * G * RG_SLOT;
-            const int total = G * RG_MW;
+            const MwGran* base = gran + (size_t)par * G * PW * RG_SLOT;
+            const int total = G * PW * RG_MW;
             bool ok = true;
             for (int i0 = tid; i0 < total; i0 += 4 * T) {
                 const MwGran* p[4]; MwGran v[4]; int sl[4], wd[4];
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(256) void k_rg_parts(double* D, int n, MwGran* gran
             if (!__syncthreads_and(ok ? 1 : 0)) return;
             if (parts & 64) { par ^= 1; keep += (double)s_words[lane % G][2]; continue; }       // the hand-off alone, without the digest
             RCand b = rc_none(); RQ a = rq_none();
-            for (int u = lane; u < G; u += 64) {
+            for (int u = lane; u < G * PW; u += 64) {
                 RCand c; c.v = __longlong_as_double((long long)(((unsigned long long)s_words[u][1] << 32) | s_words[u][0])); c.i = (int)s_words[u][2]; c.y = (int)s_words[u][3]; c.fl = 1;
                 c.szi = c.szy = 1; c.tyi = c.tyy = -1;
                 b = rc_better(b, c);
@@ -793,10 +795,11 @@ extern "C" int sd_bench_linkage_parts(sd_ctx* c, int64_t N, int G, int rounds, i
     const int cap = (int)((N + G - 1) / G) + 1;
     if (cap - 1 > RG_U * 256) SD_FAIL(c, SD_ERR_ARG, "sd_bench_linkage_parts: %d columns per workgroup (limit %d)", cap - 1, RG_U * 256);
     WS(c, double, D, "cl_Dsq", (size_t)N * N);
-    WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * RG_SLOT);
+    if ((parts & 128) && G * 4 > RG_GMAX) SD_FAIL(c, SD_ERR_ARG, "sd_bench_linkage_parts: per-wave slots need workgroups * 4 <= %d", RG_GMAX);
+    WS(c, MwGran, gran, "cl_gran", (int64_t)2 * G * 4 * RG_SLOT);
     WS(c, unsigned, sync, "cl_sync", 32 + 16 * 256);
     WS(c, double, sink, "bb_scratch", 1 << 22);
-    HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * RG_SLOT * sizeof(MwGran), c->stream));
+    HIPCHK(c, hipMemsetAsync(gran, 0, (size_t)2 * G * 4 * RG_SLOT * sizeof(MwGran), c->stream));
     HIPCHK(c, hipMemsetAsync(sync, 0, (32 + 16 * 256) * sizeof(unsigned), c->stream));
     HIPCHK(c, hipMemsetAsync(D, 0x3f, (size_t)N * N * sizeof(double), c->stream));          // finite doubles
     hipEvent_t e0, e1;
