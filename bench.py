@@ -540,7 +540,7 @@ def main():
             # wave-instructions per launch = more than 43 % of the chip's VALU issue slots for its whole duration).
             extra[k].update({"hbm_GBps_algorithmic": round(s["bytes"] / s["ms"] / 1e6, 1), "hbm_frac_of_8TBps": round(s["bytes"] / s["ms"] / 1e6 / 8000.0, 4),
                              "algorithmic_MB_per_launch": round(s["bytes"] / max(s["launches"], 1) / 1e6, 1), "GFLOPs_fft_fp64_plus_mel_f32": round(s["flops"] / s["ms"] / 1e6, 1),
-                             "bound": "fp64 VALU issue, not HBM"})
+                             "bound": "per-tile latency chain (gather, three LDS exchanges, mel pass): neither HBM nor the fp64 FFT alone -- the kernel without its FFT arithmetic takes 5.5 of 7.2 ms"})
             # the bound it really has: vector-ALU time.  Of the billed FLOPs 15 000 per frame are the fp64 FFT (fp64 vector peak 78.6 TFLOP/s), 2 x 201 x 80 the f32
             # mel contraction (f32 vector peak 157.3 TFLOP/s): the fraction of the launch's duration those FLOPs would need at the two peaks
             f64_share = 15000.0 / (15000.0 + 201.0 * 80 * 2)
@@ -549,7 +549,7 @@ def main():
                              "ms_at_60pct_hbm": round(s["bytes"] / max(s["launches"], 1) / (0.6 * 8e12) * 1e3, 3),
                              "ms_at_vector_alu_peaks": round((s["flops"] * f64_share / 78.6e12 + s["flops"] * (1.0 - f64_share) / 157.3e12) / max(s["launches"], 1) * 1e3, 3),
                              "roofline_note": "the north star's '>= 60 % of the HBM roofline on the STFT' is out of reach with the reference's fp64 STFT (sd.cpp:1980-2013): the launch's arithmetic "
-                                              "alone needs `ms_at_vector_alu_peaks` at 100 % of the fp64 / f32 vector peaks, more than twice `ms_at_60pct_hbm`; ablations in profiles/r05_frontend_ablation.txt"})
+                                              "alone needs `ms_at_vector_alu_peaks` at 100 % of the fp64 / f32 vector peaks, more than twice `ms_at_60pct_hbm`; ablations in profiles/r05_frontend_ablation_a.txt / _b.txt"})
     kst = d.kernel_stats("clusters_K")
 
     # ---- one job at a time (no overlap between consecutive jobs): the latency a single recording sees on N GPUs
