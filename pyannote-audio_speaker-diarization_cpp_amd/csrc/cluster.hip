@@ -1120,9 +1120,6 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2))) return rc;
         return linkage_heap(c, N, D, size, cid, nb, md, d_Z);
     }
-    if ((N + G - 1) / G > 3400) G = (int)((N + 3399) / 3400);      // active-row lists and bounds live in LDS: 32 B per owned row (109 KB + 43 KB static)
-    if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
-    int cap = (int)((N + G - 1) / G) + 1;
     // square form (full N x N matrix, row-only bulk accesses) while the square fits beside everything else; the condensed form above that
     bool square = c->linkage_square < 0 ? (double)N * (double)N * 8.0 <= 170e9 : c->linkage_square != 0;
     double* D = nullptr;
@@ -1131,6 +1128,16 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         if (!D) { (void)hipGetLastError(); square = false; c->stats["linkage_square_alloc_failed"].launches += 1; }      // no room for the square: the condensed form needs half
     }
     if (!square) { WS(c, double, Dc, "cl_D", m); D = Dc; }
+    // k_linkage_rg's own automatic geometry (r05, planted embeddings, 256 threads; profiles/r05_linkage_rg.txt): one XCD with 32 workgroups only while a thread
+    // has one or two columns -- N = 12 602: 72.7 ms with 32 (one XCD), 72.6 with 64 (all XCDs); N = 18 867: 127.7 / 120.0; N = 25 274: 179.1 / 165.2 (128: 169.1;
+    // k_linkage_mw 170.2); N = 50 158: 462.8 / 372.8 (128: 366.3; k_linkage_mw 381.8); N = 100 174: 128 workgroups 819 ms (64: 875; k_linkage_mw 996)
+    if (c->linkage_wgs < 0 && square && c->linkage_kernel != 0 && N >= 1500) {
+        G = N < 16000 ? 32 : N < 45000 ? 64 : 128;
+        if (G > c->num_cu) G = c->num_cu;
+    }
+    if ((N + G - 1) / G > 3400) G = (int)((N + 3399) / 3400);      // active-row lists and bounds live in LDS: 32 B per owned row (109 KB + 43 KB static)
+    if (G > c->num_cu || G > MWT) SD_FAIL(c, SD_ERR_ARG, "linkage: N=%lld needs %d cooperative workgroups", (long long)N, G);
+    int cap = (int)((N + G - 1) / G) + 1;
     if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2, square))) return rc;
     // one-XCD form while two workgroups per CU of one XCD (32 CUs) can hold the job; above, all XCDs' memory pipelines are worth more
     bool onex = c->linkage_one_xcd != 0 && G <= 32 && c->num_cu >= 256;
