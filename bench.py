@@ -576,7 +576,7 @@ def main():
     # (`value` above is the weak reading: N hours on N GPUs).  Same communicator, same library calls; every rank synthesises its slice of that hour
     # (the hull of its ranges under any rank-0 share), the share is balanced from a measured warm job as above, then `steps` jobs are timed.
     strong = None
-    if world > 1 and a.strong_steps > 0:
+    if use_dist and a.strong_steps > 0:          # (also under --force-dist on one GPU: the same library calls with a second recording length in one context)
         n_s = per_samples if a.hours_per_gpu <= 1.0 else int(round(HOUR * SR))
         C_s, _ = sdhip.num_chunks(n_s)
         pm_s = int(round(1000.0 / world))
@@ -608,11 +608,15 @@ def main():
         st = d.stage_ms()
         mine = torch.tensor([st[0] + st[1], st[2] if rank == 0 else 0.0, float(ranges_s[rank][1] - ranges_s[rank][0])], dtype=torch.float64)
         allv = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        pm_b, _ = balanced_rank0_permille([float(v[0]) for v in allv], [float(v[2]) for v in allv], float(allv[0][1]), C_s, world)
+        if world > 1:
+            dist.all_gather(allv, mine)
+        else:
+            allv = [mine]
+        pm_b, _ = balanced_rank0_permille([float(v[0]) for v in allv], [float(v[2]) for v in allv], float(allv[0][1]), C_s, world) if world > 1 else (pm_s, 0.0)
         _, rg_b = sdhip.shard_plan(n_s, world, pm_b)
         fits = torch.tensor([1.0 if (rg_b[rank][1] <= rg_b[rank][0] or (lo_s <= rg_b[rank][0] and rg_b[rank][1] <= hi_s)) else 0.0], dtype=torch.float64)
-        dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+        if world > 1:
+            dist.all_reduce(fits, op=dist.ReduceOp.MIN)
         if float(fits.item()) > 0.5:
             pm_s, ranges_s = pm_b, rg_b
             d.set_option("rank0_permille", pm_s)
@@ -623,7 +627,8 @@ def main():
             turns_s = step_s()
         fence()
         ts_ = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
-        dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+        if world > 1:
+            dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
         ms_s = float(ts_.item()) / a.strong_steps * 1e3
         lat_s = []
         for _ in range(2):
@@ -632,7 +637,8 @@ def main():
             step_s()
             fence()
             tl = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
-            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            if world > 1:
+                dist.all_reduce(tl, op=dist.ReduceOp.MAX)
             lat_s.append(float(tl.item()) * 1e3)
         strong = {"what": "the strong reading of the metric: ONE recording of %g h sharded over the %d GPUs (`value` is the weak reading: %g h per GPU)" % (sec_s / HOUR, world, a.hours_per_gpu),
                   "value": round(sec_s / (ms_s / 1e3), 2), "unit": "x real-time", "ms_per_step": round(ms_s, 2), "steps": a.strong_steps, "scaling": "strong",
@@ -871,8 +877,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["config"]["rank0_share"] = share_note
-        if world > 1:
+        if use_dist:
             out["strong_scaling_reading"] = strong
+        if world > 1:
             out["multi_gpu_note"] = ("no N > 1 number has been measured by the builder: the container has no GPU and gpurun boxes have one; the RCCL path has run as a "
                                      "world of one and as `virtual_world` on one GPU, the control flow of this script at N = 8 / 8 h against a stand-in on CPUs "
                                      "(tests/test_distributed_cpu.py).  `value` = N x %g h on N GPUs (weak); `strong_scaling_reading.value` = one hour on N GPUs." % a.hours_per_gpu)
