@@ -279,17 +279,20 @@ extern "C" int sd_embed_signals(sd_ctx* c, const float* h_signals, const float* 
         if (nn[(size_t)i] < 1) SD_FAIL(c, SD_ERR_ARG, "sd_embed_signals: wav_lens[%lld] = %g leaves no frame to normalise over", (long long)i, (double)h_wav_lens[i]);
     }
     const int64_t ns = B * (int64_t)SD_CHUNK;
-    DTMP(c, dw, (ns + 512) * sizeof(float)); DTMP(c, dv, B * sizeof(int)); DTMP(c, dn, B * sizeof(int));
-    DTMP(c, dr, EC_SPACES * (B + 1) * sizeof(int)); DTMP(c, de, B * SD_EMB_DIM * sizeof(float));
-    HIPCHK(c, hipMemcpy(dw.p, h_signals, ns * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemset((float*)dw.p + ns, 0, 512 * sizeof(float)));
-    HIPCHK(c, hipMemcpy(dv.p, nv.data(), B * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dn.p, nn.data(), B * sizeof(int), hipMemcpyHostToDevice));
+    // persistent workspaces, not per-call allocations: the reference calls infer once per batch of 32 items (677 times per hour of audio)
+    WS(c, float, dw_p, "sig_wav", ns + 512); WS(c, int, dv_p, "sig_nvalid", B); WS(c, int, dn_p, "sig_nnorm", B);
+    WS(c, int, dr_p, "sig_rowoff", EC_SPACES * (B + 1)); WS(c, float, de_p, "sig_emb", B * SD_EMB_DIM);
+    struct { void* p; } dw{dw_p}, dv{dv_p}, dn{dn_p}, dr{dr_p}, de{de_p};
+    HIPCHK(c, hipMemcpyAsync(dw.p, h_signals, ns * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync((float*)dw.p + ns, 0, 512 * sizeof(float), c->stream));
+    HIPCHK(c, hipMemcpyAsync(dv.p, nv.data(), B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dn.p, nn.data(), B * sizeof(int), hipMemcpyHostToDevice, c->stream));
     EcapaRowPlan plan;
-    int rc = ecapa_row_plan(c, nv.data(), B, plan, (int*)dr.p);
+    int rc = ecapa_row_plan(c, nv.data(), B, plan, (int*)dr.p);          // (synchronises the stream: the host vectors above may go)
     if (rc) return rc;
     const std::vector<int>& rowoff = plan.off[0];
-    DTMP(c, df, (size_t)rowoff[(size_t)B] * SD_FEAT_LD * sizeof(float));
+    WS(c, float, df_p, "sig_feats", (size_t)rowoff[(size_t)B] * SD_FEAT_LD);
+    struct { void* p; } df{df_p};
     if ((rc = frontend_prepare_signals(c, B))) return rc;
     const int64_t origin = c->wav_origin;
     c->wav_origin = 0; c->fe_bill_samples = -1;

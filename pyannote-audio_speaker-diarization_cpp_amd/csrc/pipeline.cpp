@@ -88,9 +88,11 @@ extern "C" int sd_segment_chunks(sd_ctx* c, const float* h_chunks, int64_t rows,
 {
     ENTER(c);
     if (!h_chunks || !h_out || rows <= 0 || T < 1 || T > SD_CHUNK) SD_FAIL(c, SD_ERR_ARG, "sd_segment_chunks: bad argument (rows >= 1, 1 <= T <= %d)", SD_CHUNK);
-    DTMP(c, dw, (rows * T + 512) * sizeof(float)); DTMP(c, ds, rows * SD_FRAMES * 3 * sizeof(float));
-    HIPCHK(c, hipMemcpy(dw.p, h_chunks, rows * T * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemset((float*)dw.p + rows * T, 0, 512 * sizeof(float)));
+    // persistent workspaces, not per-call allocations: slide() calls infer once per batch of 32 chunks (225 times per hour of audio)
+    WS(c, float, dw_p, "rows_wav", rows * T + 512); WS(c, float, ds_p, "rows_seg", rows * SD_FRAMES * 3);
+    struct { void* p; } dw{dw_p}, ds{ds_p};
+    HIPCHK(c, hipMemcpyAsync(dw.p, h_chunks, rows * T * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync((float*)dw.p + rows * T, 0, 512 * sizeof(float), c->stream));
     const bool padded = c->wav_padded;
     c->wav_padded = true;
     int fr = 0;

@@ -567,6 +567,22 @@ def test_bench_line_contract_on_a_short_job():
 
 
 @pytest.mark.gpu
+def test_bench_strong_scaling_leg_through_rccl_world_of_one():
+    """`bench.py --gpus N` (N > 1) also times ONE hour sharded over the N ranks (`strong_scaling_reading`).  No multi-GPU box exists here, so the leg
+    is run the only way it can be with the real library: `--force-dist` on one GPU -- RCCL communicator of one rank, a SECOND recording length (the
+    leg's shorter job) through the same context and communicator, planted outputs re-pointed and restored.  Both jobs must give their known turns."""
+    import json
+    out, _ = _run_bench(["--force-dist", "--hours-per-gpu", "0.1", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--fp16-steps", "0", "--x3-steps", "0",
+                         "--strong-steps", "2"], 900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    sr = j["strong_scaling_reading"]
+    assert j["rccl_ranks"] == 1 and sr["scaling"] == "strong" and sr["steps"] == 2 and sr["value"] > 0
+    assert sr["chunks"] == j["config"]["chunks"] and sr["turns"] == j["config"]["turns"] > 0          # (at <= 1 h per GPU the leg's recording is the job's own)
+    assert "multi_gpu_note" not in j
+
+
+@pytest.mark.gpu
 def test_cli_cold_start_on_a_one_hour_wav_by_process_wall(weights, tmp_path):
     """what a one-shot user of `speakerDiarizer` sees (the reference's surface is a one-shot CLI, sd.cpp:3415-3442): process wall of the CLI
     on a 1-h 16-bit wav against the job time the CLI itself reports ("Time cost", the reference's own timer line, sd.cpp:3434).  Everything
