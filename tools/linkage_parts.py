@@ -10,7 +10,7 @@ Gs = [int(v) for v in sys.argv[2:]] or [32]
 d = sdhip.Diarizer(None, None)
 L = sdhip.lib()
 names = {1: "loads", 2: "math", 4: "stores", 8: "wave-reduce", 32: "lds-fold", 16: "exchange", 64: "no-digest", 128: "per-wave-slots"}
-for onex in (1,):
+for onex in ((1,) if os.environ.get('ONEX', '1') == '1' else (0,)):
     for G in Gs:
         for parts in (0, 2, 8, 32, 8 | 32, 1, 1 | 2 | 4, 1 | 2 | 4 | 8, 1 | 2 | 4 | 8 | 32, 1 | 2 | 4 | 8 | 32 | 16 | 64, 1 | 2 | 4 | 8 | 32 | 16, 1 | 2 | 4 | 8 | 16 | 128, 1 | 2 | 4 | 8 | 16 | 128 | 64, 1 | 2 | 4 | 8 | 32 | 16):
             us = C.c_double(0)
