@@ -330,6 +330,7 @@ def main():
                     "MFMA) and put them into the `x3` object of the result line (0 = skip)")
     ap.add_argument("--strong-steps", type=int, default=3, help="N > 1: also time this many jobs of ONE hour in total sharded over the N GPUs (the strong reading of the "
                     "metric; 0 = skip); reported as `strong_scaling_reading`")
+    ap.add_argument("--strong-timeout", type=int, default=600, help="seconds the strong-scaling leg may take before the line is printed without it")
     ap.add_argument("--dry-run-control-plane", action="store_true", help="no GPU work: a stand-in for the library (ControlPlaneStandIn) lets the multi-rank control "
                     "flow of this script run on a box without GPUs; the line says dry-run and is not a measurement")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL communicator inside the library, "
@@ -575,8 +576,8 @@ def main():
     # ---- the STRONG reading of BASELINE's metric ("1 h 16 kHz mono on 1 / 2 / 4 / 8 MI355X"): ONE hour in total, sharded over the N ranks
     # (`value` above is the weak reading: N hours on N GPUs).  Same communicator, same library calls; every rank synthesises its slice of that hour
     # (the hull of its ranges under any rank-0 share), the share is balanced from a measured warm job as above, then `steps` jobs are timed.
-    strong = None
-    if use_dist and a.strong_steps > 0:          # (also under --force-dist on one GPU: the same library calls with a second recording length in one context)
+    def strong_leg():
+        """runs on EVERY rank (collectives inside); returns the `strong_scaling_reading` object"""
         n_s = per_samples if a.hours_per_gpu <= 1.0 else int(round(HOUR * SR))
         C_s, _ = sdhip.num_chunks(n_s)
         pm_s = int(round(1000.0 / world))
@@ -648,6 +649,7 @@ def main():
         d.set_option("rank0_permille", permille)
         if planted and hi > lo:
             d.set_planted(d_ps.data_ptr(), d_pe.data_ptr(), lo, hi - lo)
+        return strong
 
     # ---- N = 1 extras: the same job handed over as HOST PCM (sd_diarize: H2D copy inside the call), the cold first job, and the fp16 mode
     extra_lines = {}
@@ -877,13 +879,35 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["config"]["rank0_share"] = share_note
+        out.update(extra_lines)
+    # ---- the strong-scaling leg runs LAST, behind the complete headline numbers and under a watchdog: it is the one part of an N > 1 run that no box
+    # available to the builder could exercise with more than one real rank.  If it raises on a rank or does not finish in time, rank 0 still prints the
+    # line (with the reason in place of the reading) and every rank leaves at once instead of waiting in a collective.
+    strong = None
+    if use_dist and a.strong_steps > 0:
+        import threading
+
+        def bail(reason):
+            if rank == 0:
+                out["strong_scaling_reading"] = {"error": reason}
+                print(json.dumps(out), flush=True)
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
+        wd = threading.Timer(float(a.strong_timeout), bail, args=("the strong-scaling leg did not finish within %d s; every other number of the line is complete" % a.strong_timeout,))
+        wd.daemon = True
+        wd.start()
+        try:
+            strong = strong_leg()
+        except Exception as e:             # (the other ranks are inside a collective by now: their watchdogs end them)
+            bail("the strong-scaling leg raised on rank %d: %s" % (rank, repr(e)[:300]))
+        wd.cancel()
+    if rank == 0:
         if use_dist:
             out["strong_scaling_reading"] = strong
         if world > 1:
             out["multi_gpu_note"] = ("no N > 1 number has been measured by the builder: the container has no GPU and gpurun boxes have one; the RCCL path has run as a "
                                      "world of one and as `virtual_world` on one GPU, the control flow of this script at N = 8 / 8 h against a stand-in on CPUs "
                                      "(tests/test_distributed_cpu.py).  `value` = N x %g h on N GPUs (weak); `strong_scaling_reading.value` = one hour on N GPUs." % a.hours_per_gpu)
-        out.update(extra_lines)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)          # the JSON line stays the last thing on stdout: whatever a library printf()s at teardown goes to stderr
     d.close()

@@ -207,3 +207,21 @@ def test_bench_eight_rank_control_flow_at_the_eight_hour_size():
     assert sr["scaling"] == "strong" and sr["chunks"] == 7191 and sr["value"] > 0 and sr["steps"] == 3 and sr["single_job_ms"] > 0
     assert "no N > 1 number has been measured" in j["multi_gpu_note"]
     assert wall < 900.0, wall
+
+
+def test_bench_prints_its_line_even_if_the_strong_scaling_leg_cannot_finish():
+    """the strong-scaling leg is the one part of an N > 1 run no box here could exercise with more than one real rank, so it runs LAST and under a
+    watchdog: if it does not finish (here: a budget of 0 s) rank 0 still prints the complete line, with the reason in place of the reading, and every
+    rank exits at once (exit code 0) instead of waiting in a collective"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-control-plane", "--hours-per-gpu", "0.05", "--steps", "1", "--warmup", "0",
+                          "--strong-timeout", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["single_job_ms"] > 0 and "did not finish" in j["strong_scaling_reading"]["error"]
