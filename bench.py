@@ -880,6 +880,10 @@ def main():
             out["cpu_baseline"] = None
         out["config"]["rank0_share"] = share_note
         out.update(extra_lines)
+        if world > 1:
+            out["multi_gpu_note"] = ("no N > 1 number has been measured by the builder: the container has no GPU and gpurun boxes have one; the RCCL path has run as a "
+                                     "world of one and as `virtual_world` on one GPU, the control flow of this script at N = 8 / 8 h against a stand-in on CPUs "
+                                     "(tests/test_distributed_cpu.py).  `value` = N x %g h on N GPUs (weak); `strong_scaling_reading.value` = one hour on N GPUs." % a.hours_per_gpu)
     # ---- the strong-scaling leg runs LAST, behind the complete headline numbers and under a watchdog: it is the one part of an N > 1 run that no box
     # available to the builder could exercise with more than one real rank.  If it raises on a rank or does not finish in time, rank 0 still prints the
     # line (with the reason in place of the reading) and every rank leaves at once instead of waiting in a collective.
@@ -904,10 +908,6 @@ def main():
     if rank == 0:
         if use_dist:
             out["strong_scaling_reading"] = strong
-        if world > 1:
-            out["multi_gpu_note"] = ("no N > 1 number has been measured by the builder: the container has no GPU and gpurun boxes have one; the RCCL path has run as a "
-                                     "world of one and as `virtual_world` on one GPU, the control flow of this script at N = 8 / 8 h against a stand-in on CPUs "
-                                     "(tests/test_distributed_cpu.py).  `value` = N x %g h on N GPUs (weak); `strong_scaling_reading.value` = one hour on N GPUs." % a.hours_per_gpu)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)          # the JSON line stays the last thing on stdout: whatever a library printf()s at teardown goes to stderr
     d.close()
