@@ -719,6 +719,7 @@ __global__ __launch_bounds__(256) void k_rg_parts(double* D, int n, MwGran* gran
             double nd = dzx[u] + dzy[u];
             if (parts & 2) nd = lw_centroid(dzx[u], dzy[u], 0.5 + 1e-3 * (r & 7), 3 + (r & 3), 5);
             if (parts & 4) STX<ONEX>(&D[(int64_t)y * N + z], dzy[u]);     // (the loaded value goes back: the matrix stays what it was)
+            if (parts & 256) STX<ONEX>(&D[(int64_t)z * N + y], dzy[u]);   // the mirror of row y into column y: one scattered 8-byte store per column
             rq_acc(q, nd, z, 1, -1);
             rc_acc(m, nd + 1.0, z, z + 1, 1, 1, 1, -1, -1);
         }
