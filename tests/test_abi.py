@@ -82,6 +82,28 @@ def test_synth_is_deterministic_and_prefix_consistent():
     assert a.dtype == np.int16 and len(a) == 480000 and np.abs(a).max() > 5000
 
 
+def test_product_path_never_touches_the_oracle():
+    """oracle/ is the checker, never the thing shipped: no source of the package -- library, CLI, ctypes mirror, synthetic-data and weight-pack helpers --
+    imports, opens or names anything under oracle/ (bench.py may, in its cpu_baseline leg only: checked there by its structure, not here), the shared
+    library has no dependency on liboracle / libref objects, and nothing in the package reads /root/reference"""
+    import subprocess
+    pkg = os.path.join(ROOT, "pyannote-audio_speaker-diarization_cpp_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        if "__pycache__" in dirpath:
+            continue
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                continue
+            text = open(os.path.join(dirpath, f), errors="replace").read()
+            for needle in ("from oracle", "import oracle", "libsd_oracle", "libref_", "oracle/_ref", "/root/reference"):
+                if needle in text:
+                    offenders.append((f, needle))
+    assert not offenders, offenders
+    needed = subprocess.run(["readelf", "-d", os.path.join(pkg, "libsdhip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in needed and "libref" not in needed and "libtorch" not in needed and "onnxruntime" not in needed
+
+
 def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
     """include/sdhip.h is the drop-in boundary: it must compile as C99 (no C++-isms), and a C program linked against
     libsdhip.so must be able to call the host-only entry points"""
