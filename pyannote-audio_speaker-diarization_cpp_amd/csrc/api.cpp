@@ -109,6 +109,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "linkage_threads") c->linkage_threads = v;
     else if (k == "linkage_kernel") c->linkage_kernel = v;
     else if (k == "linkage_tie_kernel") c->linkage_tie_kernel = v;
+    else if (k == "linkage_zero_phase") c->linkage_zero_phase = v;
     else if (k == "linkage_force_heap") c->linkage_force_heap = v != 0;
     else if (k == "linkage_hx_wide") c->linkage_hx_wide = v != 0;
     else if (k == "linkage_prefetch") c->linkage_prefetch = v != 0;

@@ -183,6 +183,7 @@ struct sd_ctx {
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
     int64_t linkage_square = -1;               // -1 auto (full N x N distance matrix while it fits), 0 condensed, 1 square
     int64_t linkage_one_xcd = 1;               // 1 = k_linkage_mw<true> (all workgroups on one XCD) when G <= 64
+    int64_t linkage_zero_phase = 1;            // a tie at height 0 (duplicate rows): the heap replay takes the merges at height 0, k_linkage_rg the rest (0 = whole replay)
     int64_t linkage_tie_kernel = 1;            // what finishes a job with exact ties: 1 = k_linkage_hx (heap replay, row work on worker workgroups; > 1 = that many workers), 0 = k_linkage_heap (one workgroup)
     int64_t linkage_prefetch = 0;              // k_linkage_rg: 1 = a helper wave per workgroup requests the rows of the runner-up neighbours ahead of time
     bool linkage_hx_wide = false;              // test: k_linkage_hx with 32-bit heap keys / positions in global memory (the form of N > 65 535) on any size

@@ -103,7 +103,8 @@ template <bool S16> __device__ __forceinline__ void hx_decrease(HxHeap<S16>& h, 
 template <bool ONEX, bool S16>
 __global__ __launch_bounds__(HX_T) void k_linkage_hx(double* D, int n, int* cid, int* size, int* tyv, int* nb, double* md, double* Z,
                                                      double* g_hval, int* g_hkey, int* g_hpos, MwGran* cmd /*[16]*/, MwGran* rep /*[G][8]*/,
-                                                     int* chg_z /*[G][cap]*/, double* chg_v /*[G][cap]*/, unsigned* sync, int cap, int G /*workers*/, int lc)
+                                                     int* chg_z /*[G][cap]*/, double* chg_v /*[G][cap]*/, unsigned* sync, int cap, int G /*workers*/, int lc,
+                                                     double stop_above /*stop in front of the first merge higher than this (inf = never); sync[3] = merges done*/)
 {
     extern __shared__ __attribute__((aligned(16))) int dyn_lds[];     // master: heap tier [lc] doubles + [lc] ints
     __shared__ MinIdx sh[HX_T / 64];
@@ -212,6 +213,11 @@ __global__ __launch_bounds__(HX_T) void k_linkage_hx(double* D, int n, int* cid,
                 __syncthreads();
             }
             if (y < 0) { if (tid == 0) { Z[(size_t)k * 4 + 3] = NAN; sync[1] = 1; } send(HX_OP_QUIT, 0, 0, 0.0, 0, 0, 0, 0, 0); return; }   // cannot happen while two clusters are active
+            if (dist > stop_above) {                 // the caller continues from here with the cooperative kernel (run_linkage: duplicates merged, the rest is tie-free)
+                if (tid == 0) sync[3] = (unsigned)k;
+                send(HX_OP_QUIT, 0, 0, 0.0, 0, 0, 0, 0, 0);
+                return;
+            }
             if (tid == 0) { s_nx = size[x]; s_ny = size[y]; s_tx = tyv[x]; s_ty = tyv[y]; }
             __syncthreads();
             const int nx = s_nx, ny = s_ny, txm = s_tx, tym = s_ty;
@@ -277,6 +283,7 @@ __global__ __launch_bounds__(HX_T) void k_linkage_hx(double* D, int n, int* cid,
             if (tid == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nb / md of row y have landed before the next command is visible
             __syncthreads();
         }
+        if (tid == 0) sync[3] = (unsigned)(n - 1);
         send(HX_OP_QUIT, 0, 0, 0.0, 0, 0, 0, 0, 0);
         return;
     }
@@ -406,9 +413,11 @@ bool linkage_hx_fits(int64_t N, int workers)
     return (N + workers - 1) / workers <= (int64_t)HX_U * HX_T;
 }
 // D: full N x N matrix, nb / md: exact nearest neighbours above each row (k_pdist_sq + k_row_nn); size = 1, cid = iota, tyv = -1
-int linkage_hx_run(sd_ctx* c, bool onex, int workers, double* D, int64_t N, int* cid, int* size, int* tyv, int* nb, double* md, double* d_Z, bool* stopped)
+int linkage_hx_run(sd_ctx* c, bool onex, int workers, double* D, int64_t N, int* cid, int* size, int* tyv, int* nb, double* md, double* d_Z, bool* stopped,
+                   double stop_above, int64_t* merges_done)
 {
     *stopped = false;
+    if (merges_done) *merges_done = 0;
     const int G = workers;
     const int cap = (int)((N + G - 1) / G);
     // dynamic LDS: 16-bit keys and positions of all entries (n <= 65 535) + as many heap values as fit beside them, at most levels 0-12
@@ -435,7 +444,7 @@ int linkage_hx_run(sd_ctx* c, bool onex, int workers, double* D, int64_t N, int*
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     (void)hipGetLastError();
     int n_i = (int)N, cap_i = cap, G_i = G, lc_i = lc;
-    void* args[] = {&D, &n_i, &cid, &size, &tyv, &nb, &md, &d_Z, &hv, &hk, &hp, &cmd, &rep, &chz, &chv, &sync, &cap_i, &G_i, &lc_i};
+    void* args[] = {&D, &n_i, &cid, &size, &tyv, &nb, &md, &d_Z, &hv, &hk, &hp, &cmd, &rep, &chz, &chv, &sync, &cap_i, &G_i, &lc_i, &stop_above};
     hipError_t le;
     {
         ProfScope ps(c, "linkage_hx", 0, 24.0 * (double)N * (double)N);
@@ -447,5 +456,6 @@ int linkage_hx_run(sd_ctx* c, bool onex, int workers, double* D, int64_t N, int*
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stats["linkage_hx_stale_scans"].flops += (double)h[2];
     if (h[1]) *stopped = true;                  // a hand-off timed out (or, one XCD: too few workgroups found themselves on XCC 0)
+    if (merges_done) *merges_done = (int64_t)h[3];
     return SD_OK;
 }

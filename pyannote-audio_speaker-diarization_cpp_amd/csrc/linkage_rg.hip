@@ -168,7 +168,8 @@ __device__ __forceinline__ unsigned rq_word(const RQ& q, int k)      // word k o
 // TB = launch bound (256 / 512 / 1024 threads): the register budget follows it -- 128 VGPRs at 1024 threads spill part of the column state
 template <bool ONEX, int TB, int UU>
 __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, const int* nb0, const double* md0, const double* md20, double* Z,
-                                                         MwGran* gran /*[2][G][RG_SLOT], zeroed*/, unsigned* sync, int cap /*columns per workgroup + 1*/, int G, int helper)
+                                                         MwGran* gran /*[2][G][RG_SLOT], zeroed*/, unsigned* sync, int cap /*columns per workgroup + 1*/, int G, int helper,
+                                                         int k0 /*merges already done*/, const int* sz0, const int* ty0 /*cluster size (0 = gone) / last rewrite of every column after k0 merges; null: a fresh start*/)
 {
     extern __shared__ __attribute__((aligned(16))) int dyn_lds[];
     // what the cooperative row scans of a retry round need of a column they do not own in registers: last rewrite, cluster size, "gone"
@@ -228,7 +229,12 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
         c_md[u] = row ? md0[z] : (double)INFINITY; c_md2[u] = row ? md20[z] : (double)INFINITY; c_nb[u] = row ? nb0[z] : -1;
         c_fl[u] = z >= 0 ? 1 : 2;                               // bit 0 fresh, bit 1 gone (or no column)
         c_ty[u] = -1; c_sz[u] = 1; c_nbsz[u] = 1; c_nbty[u] = -1;
-        if (z >= 0) { l_ty[p] = -1; l_sz[p] = 1; l_dead[p] = 0; }
+        if (sz0 && z >= 0) {                                    // continuing behind k0 merges another kernel made (run_linkage: the heap replay took the duplicates)
+            c_sz[u] = sz0[z]; c_ty[u] = ty0[z];
+            if (c_sz[u] == 0) { c_fl[u] = 2; c_nb[u] = -1; c_md[u] = (double)INFINITY; c_md2[u] = (double)INFINITY; }
+            if (c_nb[u] >= 0) { c_nbsz[u] = sz0[c_nb[u]]; c_nbty[u] = ty0[c_nb[u]]; }
+        }
+        if (z >= 0) { l_ty[p] = c_ty[u]; l_sz[p] = c_sz[u]; l_dead[p] = (c_fl[u] & 2) ? 1 : 0; }
     }
     if (tid == 0) { s_nL[0] = 0; s_nL[1] = 0; }
     __syncthreads();
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
     RCand best = d_best;
     if (!((best.fl & 1) && best.y >= 0)) pick_stale(nocand, lp);
 
-    for (int k = 0; k < n - 1; ++k) {
+    for (int k = k0; k < n - 1; ++k) {
         // ---- lazy validation (cl.cpp:323-339): cooperative refresh of the best stale candidates
         for (int guard = 0; guard <= n - k; ++guard) {
             if ((best.fl & 1) && best.y >= 0) break;
@@ -481,7 +487,10 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
             if (!((best.fl & 1) && best.y >= 0)) pick_stale(nocand, lp);
             RSTAMP(4);
         }
-        if (best.fl & CAND_TIE) { if (g == 0 && tid == 0) sync[5] = 1; return; }      // the closest pair is not unique: the heap decides (run_linkage)
+        if (best.fl & CAND_TIE) {      // the closest pair is not unique: the heap decides (run_linkage); the height of the tie goes along
+            if (g == 0 && tid == 0) { sync[5] = 1; sync[26] = lo32(best.v); sync[27] = hi32(best.v); }
+            return;
+        }
         // ---- merge (x, y) at height dist; everything about the pair came with the candidate
         const int x = best.i, y = best.y;
         const double dist = best.v;
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
         digest(0, s_L[lp], s_Lty[lp], s_Lsz[lp], true);
         RSTAMP(3);
         par ^= 1;
-        if (d_rowtie) { if (g == 0 && tid == 0) sync[5] = 1; return; }
+        if (d_rowtie) { if (g == 0 && tid == 0) { sync[5] = 1; sync[26] = lo32(dist); sync[27] = hi32(dist); } return; }
         best = d_best;
         const RQ nn = d_nn;
         // row y: exact by construction (cl.cpp:395-404).  Without an active column above it the row has no pair left, now or later
@@ -643,7 +652,7 @@ bool linkage_rg_fits(int64_t N, int G, int TH)
     return colsB <= (int64_t)(TH <= 512 ? 8 : RG_U) * TH && TH <= RG_T_MAX;         // (8 columns per thread: the <= 512-thread forms only -- register budget)
 }
 hipError_t linkage_rg_launch(sd_ctx* c, bool onex, int G, int TH, double* D, int n, int* cid, const int* nb, const double* md, const double* md2,
-                             double* Z, MwGran* gran, unsigned* sync, int cap, int helper)
+                             double* Z, MwGran* gran, unsigned* sync, int cap, int helper, int k0, const int* sz0, const int* ty0)
 {
     if (helper && (TH > 448 || G > 64)) helper = 0;         // (one slot per lane in the helper's fold; 16 waves at most)
     const int TT = TH + (helper ? 64 : 0);
@@ -656,7 +665,7 @@ hipError_t linkage_rg_launch(sd_ctx* c, bool onex, int G, int TH, double* D, int
                               : (onex ? (const void*)k_linkage_rg<true, 1024, RG_U> : (const void*)k_linkage_rg<false, 1024, RG_U>);
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     (void)hipGetLastError();
-    void* args[] = {&D, &n, &cid, &nb, &md, &md2, &Z, &gran, &sync, &cap, &G, &helper};
+    void* args[] = {&D, &n, &cid, &nb, &md, &md2, &Z, &gran, &sync, &cap, &G, &helper, &k0, &sz0, &ty0};
     // cooperative launch: all workgroups are resident together, or the launch is refused (they poll each other's slots)
     return hipLaunchCooperativeKernel(f, dim3(onex ? 8 * G : G), dim3(TT), args, dyn, c->stream);
 }

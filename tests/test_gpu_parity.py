@@ -572,21 +572,26 @@ def test_heap_replay_with_worker_workgroups_is_bit_identical(diarizer, workers):
         diarizer.set_option("linkage_tie_kernel", workers)
         diarizer.set_option("linkage_force_heap", force)
         diarizer.set_option("linkage_hx_wide", 1 if workers == 5 else 0)          # (5 workers: also the 32-bit key / position form of jobs above 65 535 rows)
+        diarizer.set_option("linkage_zero_phase", 0)                              # (the whole job in the replay, not only its merges at height 0)
         try:
             Z = diarizer.linkage(X)
         finally:
             diarizer.set_option("linkage_tie_kernel", 1)
             diarizer.set_option("linkage_force_heap", 0)
             diarizer.set_option("linkage_hx_wide", 0)
+            diarizer.set_option("linkage_zero_phase", 1)
         assert np.array_equal(Z, Z_ref), (name, workers)
         assert diarizer.kernel_stats("linkage_hx_jobs")["launches"] == j0 + 1, (name, workers)      # it was this kernel, not the one-workgroup fallback
     assert diarizer.kernel_stats("linkage_hx_stale_scans")["flops"] > 0
 
 
-def test_one_hour_sized_set_with_duplicated_rows_against_the_reference_clustering(diarizer):
+@pytest.mark.parametrize("zero_phase", [1, 0])
+def test_one_hour_sized_set_with_duplicated_rows_against_the_reference_clustering(diarizer, zero_phase):
     """12 989 rows (the live items of the planted hour), 5 % of them exact copies of other rows (looped audio, digital
-    silence): the cooperative kernel stops at the first tie, k_linkage_hx finishes the job, and Z / the labels are those of the
-    REFERENCE's own compiled clustering.cpp (oracle/_ref/libref_clustering.so; the C oracle where that is absent) bit for bit"""
+    silence): the cooperative kernel stops at the first tie -- at height 0 -- and k_linkage_hx replays the reference's heap for the merges at
+    height 0 (about 600), after which no two rows coincide and k_linkage_rg takes the other 12 000 merges (zero_phase = 0: the replay does
+    the whole job); Z / the labels are those of the REFERENCE's own compiled clustering.cpp (oracle/_ref/libref_clustering.so; the C oracle
+    where that is absent) bit for bit"""
     rng = np.random.default_rng(12989)
     N = 12989
     X = _blobs(rng, N, k=5)
@@ -603,19 +608,39 @@ def test_one_hour_sized_set_with_duplicated_rows_against_the_reference_clusterin
     j0 = diarizer.kernel_stats("linkage_hx_jobs")["launches"]
     diarizer.reset_stats()
     diarizer.set_option("profile", 1)
+    diarizer.set_option("linkage_zero_phase", zero_phase)
     try:
         Z = diarizer.linkage(X)
-        ms = diarizer.kernel_stats("linkage_hx")["ms"]
+        ms = diarizer.kernel_stats("linkage_hx")["ms"] + diarizer.kernel_stats("linkage")["ms"]
     finally:
         diarizer.set_option("profile", 0)
+        diarizer.set_option("linkage_zero_phase", 1)
     assert np.array_equal(Z, Z_ref)
     assert np.array_equal(sdhip.fcluster(Z, orc.THRESH_F32), T_ref)
-    assert diarizer.kernel_stats("linkage_hx_jobs")["launches"] >= 1
-    print("k_linkage_hx on 12 989 rows with 5 %% duplicates: %.1f ms" % ms)
-    # (clustered rows PLUS duplicates is the slow regime of the replay: in the reference's semantics ~1.5 stale heap tops are rescanned per merge
-    # and many bounds drop per merge, each a hand-off round or a heap operation of the one master thread: ~550 ms measured; the raw 1-h
-    # workload -- 14 382 rows, nearly all in duplicate pairs -- takes 135 ms, k_linkage_heap with its one workgroup 775 ms)
-    assert ms < 1200.0
+    assert diarizer.kernel_stats("linkage_zero_phase_jobs" if zero_phase else "linkage_hx_jobs")["launches"] >= 1
+    print("12 989 rows with 5 %% duplicates, zero phase %d: replay + cooperative kernel %.1f ms" % (zero_phase, ms))
+    # measured: 84 ms with the zero phase (replay 8.7 ms for ~600 merges, k_linkage_rg 75 ms for the rest -- the tie-free job takes 73 ms);
+    # 290 ms for the whole replay (clustered rows are its slow regime: in the reference's semantics ~1.5 stale heap tops are rescanned per
+    # merge and many bounds drop per merge, each a hand-off round or a heap operation of the one master thread); k_linkage_heap: ~700 ms
+    assert ms < (250.0 if zero_phase else 1200.0)
+
+
+def test_duplicates_and_a_later_tie_end_in_the_whole_replay(diarizer):
+    """run_linkage's zero phase: duplicated rows on a lattice -- the merges at height 0 go through the replay, k_linkage_rg continues and meets the
+    lattice's ties at height 1, and the whole job is replayed: still the oracle's dendrogram bit for bit"""
+    rng = np.random.default_rng(1728)
+    g = np.stack(np.meshgrid(np.arange(12.0), np.arange(12.0), np.arange(12.0)), -1).reshape(-1, 3)
+    X = g[rng.permutation(len(g))]
+    X[rng.choice(len(X), 100, replace=False)] = X[rng.integers(0, len(X), 100)]
+    _, Z_ref = orc.ahc(X, orc.THRESH_F32)
+    z0 = diarizer.kernel_stats("linkage_zero_phase_jobs")["launches"]
+    m0 = diarizer.kernel_stats("linkage_zero_phase_merges")["flops"]
+    j0 = diarizer.kernel_stats("linkage_hx_jobs")["launches"]
+    Z = diarizer.linkage(X)
+    assert np.array_equal(Z, Z_ref)
+    assert diarizer.kernel_stats("linkage_zero_phase_merges")["flops"] > m0          # the zero phase ran ...
+    assert diarizer.kernel_stats("linkage_zero_phase_jobs")["launches"] == z0        # ... did not finish the job ...
+    assert diarizer.kernel_stats("linkage_hx_jobs")["launches"] == j0 + 1            # ... and the whole replay did
 
 
 def test_heap_linkage_with_global_heap_is_bit_identical(diarizer):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential fuzz of the linkage kernels against the C oracle: tools/linkage_fuzz.py [seconds] [seed].
-Random sizes (3 .. 3500), dimensions, data families (clustered, uniform, lattice = ties everywhere, duplicated rows, collinear, one far outlier,
+Random sizes (3 .. 3500), dimensions, data families (clustered, uniform, lattice = ties everywhere, duplicated rows, duplicates on a lattice / in clusters, collinear, one far outlier,
 tiny scale, huge scale), workgroup counts / thread counts, kernel choice (auto, k_linkage_mw, forced heap replay with 1 .. 63 workers); Z must be
 array_equal to the oracle's every time.  Prints one line per failure and a summary."""
 import os, sys, time
@@ -26,6 +26,15 @@ def make(kind, N, dd):
     elif kind == "dups":
         X = rng.standard_normal((N, dd)); m = max(1, N // int(rng.integers(2, 20)))
         X[rng.integers(0, N, m)] = X[rng.integers(0, N, m)]
+    elif kind == "dups+lattice":                      # merges at height 0, then ties at height 1: the zero phase, then the whole replay
+        side = int(np.ceil(N ** (1.0 / min(dd, 3))))
+        g = np.stack(np.meshgrid(*[np.arange(float(side))] * min(dd, 3)), -1).reshape(-1, min(dd, 3))
+        X = np.zeros((N, dd)); X[:, :min(dd, 3)] = g[rng.permutation(len(g))[:N]]
+        m = max(1, N // int(rng.integers(5, 40))); X[rng.integers(0, N, m)] = X[rng.integers(0, N, m)]
+    elif kind == "dups+blobs":                        # clustered rows with copies: the zero phase, then the cooperative kernel
+        k = int(rng.integers(1, 7)); cen = rng.standard_normal((k, dd))
+        X = cen[rng.integers(0, k, N)] + 0.6 * rng.standard_normal((N, dd)); m = max(1, N // int(rng.integers(2, 40)))
+        X[rng.integers(0, N, m)] = X[rng.integers(0, N, m)]
     elif kind == "collinear":
         X = np.outer(rng.random(N), rng.standard_normal(dd))
     elif kind == "outlier":
@@ -35,7 +44,7 @@ def make(kind, N, dd):
     else:
         X = 1e120 * rng.standard_normal((N, dd))
     return np.ascontiguousarray(X, np.float64)
-kinds = ["blobs", "uniform", "lattice", "dups", "collinear", "outlier", "tiny", "huge"]
+kinds = ["blobs", "uniform", "lattice", "dups", "dups+lattice", "dups+blobs", "collinear", "outlier", "tiny", "huge"]
 t0 = time.time(); runs = 0; fails = 0; by = {}
 while time.time() - t0 < budget:
     kind = kinds[int(rng.integers(0, len(kinds)))]
@@ -54,6 +63,7 @@ while time.time() - t0 < budget:
     d.set_option("linkage_tie_kernel", tk)
     d.set_option("linkage_hx_wide", int(rng.random() < 0.3))
     d.set_option("linkage_square", sq)
+    d.set_option("linkage_zero_phase", int(rng.random() < 0.8))
     if mode == 3: d.set_option("linkage_wgs", 16)     # (a cooperative geometry, so that the forced replay is k_linkage_hx also below N = 1500)
     try:
         Z = d.linkage(X)
@@ -72,7 +82,7 @@ while time.time() - t0 < budget:
               kind, N, dd, mode, G, T, sq, tk, runs, len(rows), rows[:1], Z[rows[0]] if len(rows) else None, Zr[rows[0]] if len(rows) else None, again,
               d.kernel_stats("linkage_rg_launches")["launches"], d.kernel_stats("linkage_hx_jobs")["launches"], d.kernel_stats("linkage_tie_fallbacks")["launches"],
               d.kernel_stats("linkage_fallbacks")["launches"], d.kernel_stats("linkage_one_xcd_timeouts")["launches"]), flush=True)
-for k in ("linkage_rg_launches", "linkage_hx_jobs", "linkage_tie_fallbacks", "linkage_fallbacks", "linkage_hx_failed", "linkage_one_xcd_timeouts"):
+for k in ("linkage_rg_launches", "linkage_zero_phase_jobs", "linkage_hx_jobs", "linkage_tie_fallbacks", "linkage_fallbacks", "linkage_hx_failed", "linkage_one_xcd_timeouts"):
     print(k, d.kernel_stats(k)["launches"])
 print("runs %d failures %d by family %s (%.0f s)" % (runs, fails, by, time.time() - t0))
 sys.exit(1 if fails else 0)
