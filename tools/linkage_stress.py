@@ -14,6 +14,9 @@ if kind == "uniform":
     X = rng.random((N, dd))
 elif kind == "blobs":
     k = 4; cen = rng.standard_normal((k, dd)); X = cen[rng.integers(0, k, N)] + 0.6 * rng.standard_normal((N, dd))
+elif kind == "dups":          # clustered rows, 5 % of them copies of other rows: the zero phase (replay for the merges at height 0, then k_linkage_rg)
+    k = 4; cen = rng.standard_normal((k, dd)); X = cen[rng.integers(0, k, N)] + 0.6 * rng.standard_normal((N, dd))
+    X[rng.integers(0, N, N // 20)] = X[rng.integers(0, N, N // 20)]
 else:
     X = rng.standard_normal((N, dd))
 _, Zr = orc.ahc(X, orc.THRESH_F32)

@@ -45,4 +45,15 @@ for name, X in cases:
         print("%-12s N=%5d zero phase %d: equal %s  replay %.1f ms + cooperative %.1f ms (%d launches; zero-phase jobs %d, merges at height 0: %d), pdist %.1f ms, row_nn %.2f ms, wall %.1f ms  (oracle %.1f s)" % (
               name, len(X), zp, ok, st["linkage_hx"]["ms"], st["linkage"]["ms"], st["linkage_rg_launches"]["launches"], st["linkage_zero_phase_jobs"]["launches"],
               st["linkage_zero_phase_merges"]["flops"], st["pdist"]["ms"], st["row_nn"]["ms"], wall * 1e3, t_or), flush=True)
+if os.environ.get("BIG", "0") == "1":        # the 8-h size: no oracle on the host (80 GB matrix); the two routes -- replay + cooperative kernel, whole replay -- against each other
+    N = 100174
+    X = blobs(rng, N, k=6); m = N // 100
+    X[rng.integers(0, N, m)] = X[rng.integers(0, N, m)]
+    out = []
+    for zp in (1, 0):
+        Z, wall, st = run(X, zp); out.append(Z)
+        print("8 h, 1 %% duplicates N=%d zero phase %d: replay %.1f ms + cooperative %.1f ms (zero-phase jobs %d, merges at height 0: %d), pdist %.1f ms, wall %.1f ms" % (
+              N, zp, st["linkage_hx"]["ms"], st["linkage"]["ms"], st["linkage_zero_phase_jobs"]["launches"], st["linkage_zero_phase_merges"]["flops"], st["pdist"]["ms"], wall * 1e3), flush=True)
+    ok = np.array_equal(out[0], out[1]); ok_all &= ok
+    print("8 h: both routes give the same Z: %s" % ok)
 print("ALL OK" if ok_all else "MISMATCH")
