@@ -48,6 +48,8 @@ int sd_test_pack_split_weights(const float* w, int K, int Cout, int CinPad, int 
  * projections of layers 1-3 on the 256 x 256 tile), "linkage_square" (-1 auto, 0 condensed, 1 full N x N distance matrix), "ecapa_f16_hp" /
  * "ecapa_keep_cat" (precision diagnostics of tools/diag_fp16_layers.py), "linkage_kernel" (-1 auto / 1: k_linkage_rg for the square matrix where its geometry fits,
  * 0: k_linkage_mw), "linkage_tie_kernel" (what finishes a job with exact ties: 1 = k_linkage_hx, n > 1 = with n worker workgroups, 0 = k_linkage_heap),
+ * "diag_res2_single" (TIMING ONLY, results are garbage: the Res2Net convolutions read one input stream instead of two -- the upper bound of what a pre-added
+ * input could save, profiles/r05_res2net_single_stream.txt),
  * "linkage_zero_phase" (1, default: after a tie at height 0 the replay takes the merges at height 0 only and k_linkage_rg the rest; 0: whole replay),
  * "linkage_force_heap" (1 = skip the cooperative kernel: the heap replay on tie-free data), "linkage_hx_wide" (1 = k_linkage_hx's 32-bit key / position form, which
  * jobs above 65 535 rows take, on any size), "linkage_prefetch" (1 = k_linkage_rg's helper wave; measured: no gain), "ws_limit_mb" (test: PROCESS-WIDE, a workspace request above this many

@@ -136,6 +136,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
                                         c->ecapa_precision = (int)v; }
     else if (k == "ecapa_f16_hp") { if (v != 0 && v != 1 && v != 3) SD_FAIL(c, SD_ERR_ARG, "ecapa_f16_hp must be 0, 1 (MFA output in f32) or 3 (+ the attention branch)"); c->ecapa_f16_hp = (int)v; }
     else if (k == "ecapa_keep_cat") c->ecapa_keep_cat = v != 0;
+    else if (k == "diag_res2_single") c->diag_res2_single = v != 0;
     else if (k == "rank0_permille") c->rank0_permille = (int)v;
     else if (k == "virtual_world") c->virtual_world = (int)v;
     else if (k == "comm_timeout_ms") c->comm_timeout_ms = v;

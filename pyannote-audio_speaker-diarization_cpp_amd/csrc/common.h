@@ -163,6 +163,7 @@ struct sd_ctx {
     int num_clusters = -1, min_clusters = -1, max_clusters = -1;   // optional constraints for the whole-path entry points
     int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation, 2 = the same with hi + lo fp16 weight planes, 3 = f32 tensors, hi + lo split of BOTH operands on the fp16 MFMA (wide layers; the others stay f32)
     int seg_precision = 0;                      // 0 = f32 MFMA; 3 = PyanNet's LSTM (input projections of layers 1-3 and the recurrence) with both MFMA operands split into hi + lo fp16 halves
+    bool diag_res2_single = false;              // TIMING diagnostics only (results are garbage): the Res2Net convolutions read t1_i alone, without r_(i-1) -- what a pre-added input would save at most
     bool ecapa_keep_cat = false;                // diagnostics: f32 mode keeps the block outputs (the logits get their own buffer)
     int ecapa_f16_hp = 0;                       // fp16 mode: bit 0 = MFA output / pooling inputs in f32, bit 1 = attention branch on the f32 MFMA
     bool conv_w256_f32 = true;                  // f32: the same 256 x 256 kernel for the wide, long-K ECAPA layers (TDNN, MFA)

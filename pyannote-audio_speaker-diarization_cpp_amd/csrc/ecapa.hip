@@ -276,7 +276,7 @@ static int run_ecapa_t(sd_ctx* c, const float* d_feats_all, const int* d_nvalid_
         for (int i = 1; i < 8; ++i) {
             ConvArgs a = conv_args(B.res[i - 1], tr + (i - 1) * S, LDT, tr + C + (i - 1) * S, LDT, Mc, true, P);
             a.act1 = 1;
-            if (i >= 2) { a.X2 = (const float*)(tr + C + (i - 2) * S); a.x2_ld = LDT; }
+            if (i >= 2 && !c->diag_res2_single) { a.X2 = (const float*)(tr + C + (i - 2) * S); a.x2_ld = LDT; }
             a.rowtab = t_cc;
             if ((rc = launch_conv_gemm(c, a, "res2net"))) return rc;
         }
