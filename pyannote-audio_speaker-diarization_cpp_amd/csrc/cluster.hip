@@ -1184,6 +1184,7 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     WS(c, unsigned, sync, "cl_sync", 32 + 16 * 256);
     HIPCHK(c, hipMemsetAsync(sync, 0, (32 + 16 * 256) * sizeof(unsigned), c->stream));
     const char* why = nullptr;
+    bool launch_refused = false;
     if (c->linkage_force_heap) why = "forced (option linkage_force_heap)";
     else {
         ProfScope ps(c, "linkage", 0, 24.0 * (double)N * (double)N);
@@ -1212,7 +1213,7 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
         }
         if (!onex) le = hipLaunchCooperativeKernel(f_all, dim3(G), dim3(TH), args, (size_t)cap * 32, c->stream);
         }
-        if (le != hipSuccess) { (void)hipGetLastError(); why = "cooperative launch refused"; }
+        if (le != hipSuccess) { (void)hipGetLastError(); why = "cooperative launch refused"; launch_refused = true; }
     }
     unsigned h[32] = {0};
     if (!why) {
@@ -1246,6 +1247,9 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     c->stats["linkage_fallbacks"].launches += 1;
     if (c->profile_detail) fprintf(stderr, "linkage: %s at N = %lld -> heap replay\n", why, (long long)N);
     // the reference's heap replayed with the row work spread over worker workgroups (k_linkage_hx) on the square matrix, where it fits
+    // matrix, bounds and ids are still as linkage_prepare left them when nothing ran (forced replay, refused launch) or k_linkage_rg stopped in front of its
+    // first merge (sync[28] = merges made; with two pairs of duplicates: always): the replay starts from them, no second pdist
+    bool untouched = c->linkage_force_heap != 0 || launch_refused || (use_rg && h[5] && !h[1] && h[28] == 0);
     if (square && c->linkage_tie_kernel != 0) {
         bool hx_onex = c->linkage_one_xcd != 0 && c->num_cu >= 256 && linkage_hx_fits(N, 31);
         int workers = hx_onex ? 31 : (N >= 60000 ? 127 : 63);
@@ -1261,7 +1265,8 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
             if (use_rg && h[5] && !h[1] && tie_h == 0.0 && c->linkage_zero_phase != 0) {
                 bool z_onex = hx_onex; int z_workers = workers;
                 for (int attempt = 0; attempt < 2; ++attempt) {
-                    if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2, true))) return rc;
+                    if (!untouched && (rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2, true))) return rc;
+                    untouched = false;
                     hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, tyv, -1, N, 0);
                     KCHECK(c);
                     bool stopped = false; int64_t k_done = 0;
@@ -1298,7 +1303,8 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
                 }
             }
             for (int attempt = 0; attempt < 2; ++attempt) {
-                if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2, true))) return rc;
+                if (!untouched && (rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2, true))) return rc;
+                untouched = false;
                 hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, tyv, -1, N, 0);
                 KCHECK(c);
                 bool stopped = false;

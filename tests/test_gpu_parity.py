@@ -643,6 +643,27 @@ def test_duplicates_and_a_later_tie_end_in_the_whole_replay(diarizer):
     assert diarizer.kernel_stats("linkage_hx_jobs")["launches"] == j0 + 1            # ... and the whole replay did
 
 
+def test_row_tie_at_the_first_merge_rebuilds_the_matrix(diarizer):
+    """rows 1 and 2 lie at the same distance on either side of row 0, closer than anything else: the first merge's row has two neighbours at the merge
+    height, which k_linkage_rg notices only after that merge's stores went out -- so the replay must not start from the matrix as it stands (run_linkage
+    keeps linkage_prepare's matrix only when the cooperative kernel stopped in FRONT of its first merge; found by tools/linkage_fuzz.py)"""
+    rng = np.random.default_rng(31)
+    X = _blobs(rng, 1800)
+    X[1] = X[0]; X[2] = X[0]
+    X[1, 0] += 2.0 ** -12; X[2, 0] -= 2.0 ** -12
+    assert np.linalg.norm(X[1] - X[0]) == np.linalg.norm(X[2] - X[0])
+    _, Z_ref = orc.ahc(X, orc.THRESH_F32)
+    f0 = diarizer.kernel_stats("linkage_tie_fallbacks")["launches"]
+    for G in (-1, 16):
+        diarizer.set_option("linkage_wgs", G)
+        try:
+            Z = diarizer.linkage(X)
+        finally:
+            diarizer.set_option("linkage_wgs", -1)
+        assert np.array_equal(Z, Z_ref), G
+    assert diarizer.kernel_stats("linkage_tie_fallbacks")["launches"] == f0 + 2
+
+
 def test_heap_linkage_with_global_heap_is_bit_identical(diarizer):
     """k_linkage_heap with its heap in global memory (N - 1 > 2048 entries), tie-free data"""
     X = _blobs(np.random.default_rng(77), 3000)
