@@ -118,6 +118,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "skip_dead_rows") c->skip_dead_rows = v != 0;
     else if (k == "conv_h256") c->conv_h256 = v != 0;
     else if (k == "conv_glds") c->conv_glds = v != 0;
+    else if (k == "conv_pp") c->conv_pp = v != 0;
     else if (k == "conv_glds_f32") c->conv_glds_f32 = v != 0;
     else if (k == "conv_mfma16") { if (v < 0 || v > 1) return SD_ERR_ARG; c->conv_mfma16 = (int)v; }
     else if (k == "conv_rot") { if (v < 0 || v > 3) return SD_ERR_ARG; c->conv_rot = (int)v; }

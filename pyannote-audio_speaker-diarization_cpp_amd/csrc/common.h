@@ -27,7 +27,7 @@ inline std::atomic<long long> g_ws_alloc_us{0}, g_ws_free_us{0};
 inline std::atomic<size_t> g_ws_alloc_bytes{0}, g_ws_allocs{0};
 inline std::atomic<size_t> g_ws_limit{0};          // test hook (option ws_limit_mb): a workspace request above this many bytes fails like an exhausted GPU; 0 = off
 // per-device "dynamic-LDS attribute set" masks of the wide conv kernels (the attribute belongs to the device's code object, the launch to a context)
-inline std::atomic<unsigned> g_attr_w256{0}, g_attr_g256{0};
+inline std::atomic<unsigned> g_attr_w256{0}, g_attr_g256{0}, g_attr_pp{0};
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int reserve(size_t bytes) {
@@ -179,6 +179,7 @@ struct sd_ctx {
     int conv_rot = 3;                           // LDS-DMA wide kernel: the workgroups that share a row panel request its quarters in rotated order (conv_gemm_g.hip); tuning
     int conv_stagger = 0;                       // 128 x 128 f32 kernel: start half of the workgroups half a tile late (0 off, 1 odd, 2 upper half); tuning
     bool conv_glds_f32 = false;                 // f32: the LDS-DMA staged form of the wide tile (conv_gemm_g.hip, P = 0): bit-identical, measured slower; A-B only
+    bool conv_pp = true;                        // fp16 mode: the two-group ping-pong kernel for the wide layers (conv_gemm_p.hip, round 6); 0 = conv_gemm_g.hip; A-B
     bool conv_glds = true;                      // fp16 mode: ... staged by LDS-DMA (conv_gemm_g.hip) instead of through registers; tuning / A-B
     bool skip_dead_rows = true;                 // ECAPA: skip row panels beyond nvalid + receptive field
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
@@ -242,6 +243,7 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& a, const char* tag);
 int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- conv_gemm_g.hip (fp16 mode, Cout >= 256: the same tile with LDS-DMA staging; returns 1 = not applicable)
 int launch_conv_gemm_g256(sd_ctx* c, const ConvArgs& a, const char* tag);
+int launch_conv_gemm_pp(sd_ctx* c, const ConvArgs& a, const char* tag);      // conv_gemm_p.hip
 // ---- conv_narrow.hip (f32, Cout <= 96, "valid" convs of SincNet: tile as wide as the layer; returns 1 = not applicable)
 int launch_conv_narrow(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- weights.cpp

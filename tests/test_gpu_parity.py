@@ -408,6 +408,31 @@ def test_ecapa_fp16_lds_dma_staged_kernel_gives_the_same_bits(diarizer):
     assert cosd.max() < 1e-5 and np.abs(e16 - e_reg).max() < 2e-3 * np.abs(e_reg).max()
 
 
+def test_ecapa_fp16_ping_pong_kernel_gives_the_same_bits(diarizer):
+    """fp16 mode: the two-group ping-pong kernel of the wide layers (conv_gemm_p.hip, round 6: half-tiles staged and released phase by phase,
+    weights as the MFMA's first operand, 16-byte stores straight from the accumulators, the epilogue in chunks behind the MFMAs of the next
+    K-tiles) against the kernel it replaces (conv_gemm_g.hip, 16x16x32 form): the same products in the same order, so the embeddings must be
+    bit-identical -- on ragged items (row tables with cross-space layers, clamped frames, a partly filled last tile, several tiles per
+    workgroup), run three times (a half-tile read before its DMA has landed, or overwritten before its last read, shows as a difference)."""
+    rng = np.random.default_rng(37)
+    lens = np.array([1.0, 0.5, 0.25, 0.9, 0.7, 0.33, 1.0, 0.6, 0.8, 0.45, 0.12, 1.0, 0.77, 0.05, 0.95, 0.5, 0.61, 1.0, 0.29, 0.83] * 3, np.float32)
+    feats = (3.0 * rng.standard_normal((len(lens), 501, 80))).astype(np.float32)
+    diarizer.set_option("ecapa_precision", 1)
+    try:
+        diarizer.set_option("conv_pp", 1)
+        e_pp = [diarizer.ecapa(feats, lens) for _ in range(3)]
+        diarizer.set_option("conv_pp", 0)
+        e_g = diarizer.ecapa(feats, lens)
+    finally:
+        diarizer.set_option("conv_pp", 1)
+        diarizer.set_option("ecapa_precision", 0)
+    assert np.isfinite(e_g).all()
+    for e in e_pp:
+        assert np.isfinite(e).all()
+        bad = np.flatnonzero((e != e_g).any(axis=1))
+        assert bad.size == 0, ("items that differ", bad[:10], np.abs(e - e_g).max())
+
+
 def test_ecapa_bits_do_not_depend_on_how_many_items_share_a_batch(diarizer):
     """2 100 short items: one batch under the default row budget (more than 2 048 items: the per-utterance layers -- SE, ASP bias, fc -- must
     still take the kernel they take in small batches) against batches of 96: bit-identical embeddings in f32, x3 and fp16 mode.  (Round 4:
