@@ -326,6 +326,7 @@ def main():
                     "shares and its stage times give the balance point; 1/N = equal shares, 0 = rank 0 only finalizes")
     ap.add_argument("--fp16-steps", type=int, default=3, help="N = 1, f32 run: also time this many steps in fp16 mode (BASELINE configs[4]) and put them, with the "
                     "cosine distances of the fp16 embeddings to the f32 ones, into the `fp16` object of the result line (0 = skip)")
+    ap.add_argument("--raw-steps", type=int, default=3, help="N = 1, planted run: also time this many jobs on the RAW network outputs (every item live and full length) -> workload_dependence.value_raw_workload")
     ap.add_argument("--x3-steps", type=int, default=3, help="N = 1, f32 run: also time this many steps with ecapa_precision = 3 (f32 tensors, split fp16 operands on the "
                     "MFMA) and put them into the `x3` object of the result line (0 = skip)")
     ap.add_argument("--strong-steps", type=int, default=3, help="N > 1: also time this many jobs of ONE hour in total sharded over the N GPUs (the strong reading of the "
@@ -507,10 +508,13 @@ def main():
     d.reset_stats()
     fence()
     t0 = time.perf_counter()
+    step_marks = [t0]
     for _ in range(a.steps):
         step()
+        step_marks.append(time.perf_counter())      # (the call returns the turns, i.e. it has synchronised: a timestamp, no extra fence inside the bracket)
     fence()
     dt = time.perf_counter() - t0
+    step_ms = sorted((step_marks[i + 1] - step_marks[i]) * 1e3 for i in range(a.steps))
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -684,7 +688,7 @@ def main():
             """the same job `steps` times with ecapa_precision = opt; its own roofline (the wide kernel of the mode against the fp16 MFMA peak) and the
             cosine distances of its REAL embeddings to the f32 ones"""
             d.set_option("ecapa_precision", opt)
-            d.set_option("seg_precision", 3 if opt == 3 else 0)        # x3 = the split MFMA operands in both networks (ECAPA conv layers, PyanNet's LSTM)
+            d.set_option("seg_precision", -1)        # auto (the library's default): any fp16-pipe mode of ECAPA takes the split-operand LSTM too (round 6; before: x3 only)
             d.set_option("profile", 1)
             step()
             d.reset_stats()
@@ -711,7 +715,7 @@ def main():
                 gpu_sync()
                 em = emb_t.cpu().numpy().astype(np.float64)
                 d.set_option("ecapa_precision", 0)
-                d.set_option("seg_precision", 0)
+                d.set_option("seg_precision", -1)
                 d.shard_infer_dev(d_pcm.data_ptr(), 0, n_total, n_total, 0, C, seg_t.data_ptr(), emb_t.data_ptr())
                 gpu_sync()
                 e32 = emb_t.cpu().numpy().astype(np.float64)
@@ -724,7 +728,7 @@ def main():
                 cosd = {"items": int(lv.sum()), "max": float("%.3g" % cd.max()), "q99": float("%.3g" % np.quantile(cd, 0.99)), "median": float("%.3g" % np.median(cd)),
                         "above_1e-3": int((cd > 1e-3).sum()), "same_nan_rows": same_nan}
             d.set_option("ecapa_precision", 0)
-            d.set_option("seg_precision", 0)
+            d.set_option("seg_precision", -1)
             tf = wm["flops"] / max(wm["ms"], 1e-9) / 1e9
             rl = {"bound": "mfma", "kernel": kernel, "achieved": round(tf * mfma_per_flop, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": round(tf * mfma_per_flop / F16_MFMA_PEAK_TFLOPS, 4), "kernel_ms_per_step": round(wm["ms"] / steps, 2), "launches_per_step": wm["launches"] // steps,
@@ -785,6 +789,30 @@ def main():
                                                "fp16 MFMA with f32 accumulation -- f32-grade scores and embeddings (see the cosine distances) from the fp16 matrix pipe; opt-in, not "
                                                "the headline value", 3)
 
+    # ---- what the headline depends on: the same pipeline on the RAW outputs of the random-weight networks -- every item live and full length
+    # (14 382 of them at 1 h, K = 1) -- i.e. SURVEY 8(d)'s nominal FLOPs with no dead rows to skip, against the planted hour's live, partly filled items
+    raw_line = None
+    if world == 1 and not use_dist and planted and a.raw_steps > 0 and a.hours_per_gpu <= 2.0:
+        try:
+            d.set_option("profile", 0)
+            d.set_planted(0, 0, 0, 0)
+            d.diarize_dev(d_pcm.data_ptr(), n_total)
+            gpu_sync()
+            tr = []
+            for _ in range(a.raw_steps):
+                t1 = time.perf_counter()
+                turns_raw = d.diarize_dev(d_pcm.data_ptr(), n_total)
+                tr.append((time.perf_counter() - t1) * 1e3)
+            st_r = d.stage_ms()
+            raw_line = {"value": round(audio_s / (sorted(tr)[len(tr) // 2] / 1e3), 2), "unit": "x real-time", "ms_per_step_median": round(sorted(tr)[len(tr) // 2], 2),
+                        "ms_per_step_min_max": [round(min(tr), 2), round(max(tr), 2)], "steps": a.raw_steps, "turns": len(turns_raw),
+                        "stage_ms_last_step": {"segmentation": round(st_r[0], 1), "embedding": round(st_r[1], 1), "finalize": round(st_r[2], 1)},
+                        "what": "the same call on the raw outputs of the random-weight networks: every embedding item live and full length (no dead rows to skip), nearly all "
+                                "of them exact duplicates for the clustering (K = 1): the nominal per-item work of SURVEY 8(d); `value` above is the planted hour"}
+        except Exception as e:
+            raw_line = {"error": str(e)[:300]}
+        finally:
+            d.set_planted(d_ps.data_ptr(), d_pe.data_ptr(), lo, hi - lo)
     if rank == 0:
         ach = cg["flops"] / max(cg["ms"], 1e-9) / 1e9      # TFLOP/s
         peak = F32_MFMA_PEAK_TFLOPS if a.precision == "f32" else F16_MFMA_PEAK_TFLOPS
@@ -812,6 +840,7 @@ def main():
             "unit": "x real-time",
             "n_gpus": world, "rccl_ranks": d.comm_info()[1], "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 2),
+            "ms_per_step_min_median_max": [round(step_ms[0], 2), round(step_ms[len(step_ms) // 2], 2), round(step_ms[-1], 2)] if step_ms else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 tensors; MFMA operands split into hi + lo fp16 halves (x3)" if a.precision == "x3" else a.precision, "data": "dry-run (stand-in for the library, no GPU work)" if dry else "synthetic",
             "config": {"workload": "%g h synthetic 16 kHz mono per GPU (%g h total), full pipeline: PyanNet segmentation + post-seg + STFT/fbank + "
@@ -879,6 +908,15 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["config"]["rank0_share"] = share_note
+        # the headline's dependence on the workload, in the line itself: executed MFMA work of the step against SURVEY 8(d)'s nominal 57.66 GFLOP per chunk
+        nominal_gflop = 57.66 * C
+        exec_gflop = cg_all["flops"] / (3.0 if a.precision == "x3" else 1.0) / max(a.steps, 1) / 1e9
+        out["workload_dependence"] = {"executed_fraction_of_nominal_flops": round(exec_gflop / nominal_gflop, 4), "executed_gflop_per_step": round(exec_gflop, 1),
+                                      "nominal_gflop_per_step": round(nominal_gflop, 1), "live_items": int(round(live_total)), "embedding_items": 3 * C,
+                                      "value_raw_workload": raw_line,
+                                      "what": "`value` is measured on the planted hour: dead items (no active speaker: the reference's NaN rows) and the frames beyond an item's "
+                                              "last valid one are not computed (exact: tests/test_gpu_parity.py::test_ecapa_dead_row_skipping_is_invisible), so the step executes this "
+                                              "fraction of SURVEY 8(d)'s nominal FLOPs; `value_raw_workload` is the same call with nothing to skip"}
         out.update(extra_lines)
         if world > 1:
             out["multi_gpu_note"] = ("no N > 1 number has been measured by the builder: the container has no GPU and gpurun boxes have one; the RCCL path has run as a "
@@ -891,12 +929,19 @@ def main():
     if use_dist and a.strong_steps > 0:
         import threading
 
+        line_lock = threading.Lock()
+        printed = [False]
+
         def bail(reason):
-            if rank == 0:
-                out["strong_scaling_reading"] = {"error": reason}
-                print(json.dumps(out), flush=True)
+            # the line first (every other number is complete), then a NON-ZERO exit on every rank: a hung collective or an exception must not read as success
+            # to torchrun / CI.  The lock keeps the watchdog thread and the main thread from both printing the line.
+            with line_lock:
+                if rank == 0 and not printed[0]:
+                    printed[0] = True
+                    out["strong_scaling_reading"] = {"error": reason}
+                    print(json.dumps(out), flush=True)
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)
+            os._exit(3)
         wd = threading.Timer(float(a.strong_timeout), bail, args=("the strong-scaling leg did not finish within %d s; every other number of the line is complete" % a.strong_timeout,))
         wd.daemon = True
         wd.start()
@@ -908,7 +953,13 @@ def main():
     if rank == 0:
         if use_dist:
             out["strong_scaling_reading"] = strong
-        print(json.dumps(out), flush=True)
+        if use_dist and a.strong_steps > 0:
+            with line_lock:
+                if not printed[0]:
+                    printed[0] = True
+                    print(json.dumps(out), flush=True)
+        else:
+            print(json.dumps(out), flush=True)
         os.dup2(2, 1)          # the JSON line stays the last thing on stdout: whatever a library printf()s at teardown goes to stderr
     d.close()
     if world > 1:

@@ -9,6 +9,8 @@
 
 static std::string g_create_err;
 
+int seg_prec(const sd_ctx* c) { return c->seg_precision >= 0 ? c->seg_precision : (c->ecapa_precision != 0 ? 3 : 0); }
+
 extern "C" const char* sd_create_error(void) { return g_create_err.c_str(); }
 extern "C" const char* sd_last_error(const sd_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
@@ -130,7 +132,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "seg_wide_ih") c->seg_wide_ih = v != 0;
     else if (k == "conv_w256_kmin") c->conv_w256_kmin = (int)v;
     else if (k == "conv_pn128") c->conv_pn128 = (int)v;
-    else if (k == "seg_precision") { if (v != 0 && v != 3) SD_FAIL(c, SD_ERR_ARG, "seg_precision must be 0 (f32) or 3 (split fp16 operands for the LSTM)"); c->seg_precision = (int)v; }
+    else if (k == "seg_precision") { if (v != 0 && v != 3 && v != -1) SD_FAIL(c, SD_ERR_ARG, "seg_precision must be 0 (f32), 3 (split fp16 operands for the LSTM) or -1 (auto: 3 whenever ecapa_precision is not 0)"); c->seg_precision = (int)v; }
     else if (k == "ecapa_precision") { if (v < 0 || v > 3) SD_FAIL(c, SD_ERR_ARG, "ecapa_precision must be 0 (f32), 1 (fp16), 2 (fp16, hi + lo weight planes) or 3 (f32 tensors, split fp16 operands on the wide layers)");
                                         if (hipSetDevice(c->device) != hipSuccess) SD_FAIL(c, SD_ERR_HIP, "hipSetDevice failed");
                                         const int rcw = ensure_ecapa_mode_weights(c, (int)v); if (rcw) return rcw;      // fp16 weight forms: built on first use of the mode

@@ -1106,7 +1106,7 @@ int linkage_rg_slot_granules();
 // linkage_hx.hip
 bool linkage_hx_fits(int64_t N, int workers);
 int linkage_hx_run(sd_ctx* c, bool onex, int workers, double* D, int64_t N, int* cid, int* size, int* tyv, int* nb, double* md, double* d_Z, bool* stopped,
-                   double stop_above = (double)INFINITY, int64_t* merges_done = nullptr);
+                   double stop_above = (double)INFINITY, int64_t* merges_done = nullptr, bool* launched = nullptr);
 
 int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
 {
@@ -1133,7 +1133,7 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     // boxes disagree, 256 wins on two of three; all XCDs 128 x 512 0.99 s at N = 100 174 (128 x 256: 1.10 s)
     // one XCD, larger N: 512 threads (N = 18 867: 121 ms against 126; N = 25 274: 170 against 179; N = 50 158: 384 against 465)
     if (TH <= 0) TH = auto_onex ? (N >= 16000 ? 512 : 256) : N >= 8000 ? 512 : 256;
-    TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : TH >= 256 ? 256 : TH >= 128 ? 128 : 64;
+    TH = TH >= 1024 ? 1024 : TH >= 512 ? 512 : TH >= 256 ? 256 : 128;      // (not below 128: the kernels fill their G <= 128 candidate slots with `tid < G`)
     if (G <= 1) {
         WS(c, double, D, "cl_D", m);
         if ((rc = linkage_prepare(c, d_X, N, d, D, size, cid, nb, md, md2))) return rc;
@@ -1269,8 +1269,9 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
                     untouched = false;
                     hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, tyv, -1, N, 0);
                     KCHECK(c);
-                    bool stopped = false; int64_t k_done = 0;
-                    if ((rc = linkage_hx_run(c, z_onex, z_workers, D, N, cid, size, tyv, nb, md, d_Z, &stopped, 0.0, &k_done))) return rc;
+                    bool stopped = false, launched = false; int64_t k_done = 0;
+                    if ((rc = linkage_hx_run(c, z_onex, z_workers, D, N, cid, size, tyv, nb, md, d_Z, &stopped, 0.0, &k_done, &launched))) return rc;
+                    if (!launched) untouched = true;      // a refused launch has not touched matrix, bounds or ids: the next attempt needs no second pdist
                     if (stopped) {
                         if (!z_onex) break;
                         z_onex = false; z_workers = N >= 60000 ? 127 : 63;
@@ -1307,8 +1308,9 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
                 untouched = false;
                 hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, tyv, -1, N, 0);
                 KCHECK(c);
-                bool stopped = false;
-                if ((rc = linkage_hx_run(c, hx_onex, workers, D, N, cid, size, tyv, nb, md, d_Z, &stopped))) return rc;
+                bool stopped = false, launched = false;
+                if ((rc = linkage_hx_run(c, hx_onex, workers, D, N, cid, size, tyv, nb, md, d_Z, &stopped, (double)INFINITY, nullptr, &launched))) return rc;
+                if (!launched) { untouched = true; c->stats["linkage_hx_refused"].launches += 1; }
                 if (!stopped) { c->stats["linkage_hx_jobs"].launches += 1; return SD_OK; }
                 if (!hx_onex) break;
                 hx_onex = false;                 // one XCD refused or too few workgroups arrived there: all XCDs

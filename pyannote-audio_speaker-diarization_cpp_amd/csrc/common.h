@@ -162,7 +162,7 @@ struct sd_ctx {
     int64_t seg_batch_chunks = 4096;           // 128 LSTM workgroups per direction: one full wave of CUs
     int num_clusters = -1, min_clusters = -1, max_clusters = -1;   // optional constraints for the whole-path entry points
     int ecapa_precision = 0;                    // 0 = f32 MFMA (default, the measured configuration), 1 = fp16 MFMA with f32 accumulation, 2 = the same with hi + lo fp16 weight planes, 3 = f32 tensors, hi + lo split of BOTH operands on the fp16 MFMA (wide layers; the others stay f32)
-    int seg_precision = 0;                      // 0 = f32 MFMA; 3 = PyanNet's LSTM (input projections of layers 1-3 and the recurrence) with both MFMA operands split into hi + lo fp16 halves
+    int seg_precision = -1;                     // -1 = auto: 3 whenever ecapa_precision != 0 (an fp16-pipe mode was asked for), else 0 (round 6; seg_prec() below); 0 = f32 MFMA; 3 = PyanNet's LSTM (input projections of layers 1-3 and the recurrence) with both MFMA operands split into hi + lo fp16 halves
     bool diag_res2_single = false;              // TIMING diagnostics only (results are garbage): the Res2Net convolutions read t1_i alone, without r_(i-1) -- what a pre-added input would save at most
     bool ecapa_keep_cat = false;                // diagnostics: f32 mode keeps the block outputs (the logits get their own buffer)
     int ecapa_f16_hp = 0;                       // fp16 mode: bit 0 = MFA output / pooling inputs in f32, bit 1 = attention branch on the f32 MFMA
@@ -242,6 +242,9 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- conv_gemm_h.hip (fp16 mode, Cout >= 256: 256 x 256 tile; returns 1 = not applicable)
 int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- conv_gemm_g.hip (fp16 mode, Cout >= 256: the same tile with LDS-DMA staging; returns 1 = not applicable)
+// the precision PyanNet's LSTM runs in: the option, or -- left at auto -- the split-operand form whenever the caller selected an fp16-pipe mode for ECAPA
+// (scores within 1e-6 of the f32 path's, identical turns: tests/test_gpu_parity.py, tests/test_planted.py; 86 -> 60 ms per hour)
+int seg_prec(const sd_ctx* c);
 int launch_conv_gemm_g256(sd_ctx* c, const ConvArgs& a, const char* tag);
 int launch_conv_gemm_pp(sd_ctx* c, const ConvArgs& a, const char* tag);      // conv_gemm_p.hip
 // ---- conv_narrow.hip (f32, Cout <= 96, "valid" convs of SincNet: tile as wide as the layer; returns 1 = not applicable)

@@ -414,15 +414,20 @@ bool linkage_hx_fits(int64_t N, int workers)
 }
 // D: full N x N matrix, nb / md: exact nearest neighbours above each row (k_pdist_sq + k_row_nn); size = 1, cid = iota, tyv = -1
 int linkage_hx_run(sd_ctx* c, bool onex, int workers, double* D, int64_t N, int* cid, int* size, int* tyv, int* nb, double* md, double* d_Z, bool* stopped,
-                   double stop_above, int64_t* merges_done)
+                   double stop_above, int64_t* merges_done, bool* launched)
 {
     *stopped = false;
     if (merges_done) *merges_done = 0;
+    if (launched) *launched = false;
     const int G = workers;
     const int cap = (int)((N + G - 1) / G);
     // dynamic LDS: 16-bit keys and positions of all entries (n <= 65 535) + as many heap values as fit beside them, at most levels 0-12
-    const bool s16 = N <= 65535 && !c->linkage_hx_wide;          // (option linkage_hx_wide: the 32-bit key / position form, which jobs above 65 535 rows take, on any size -- tests)
+    // (option linkage_hx_wide: the 32-bit key / position form, which jobs above 65 535 rows take, on any size -- tests)
+    // The 16-bit form keeps 4 N bytes of keys and positions in LDS beside ~27 KB of static LDS: it is taken only while those leave room for at least
+    // 1 024 heap values inside the budget (N <= 31 232); from there to 65 535 rows the request would exceed the CU's 160 KB and every cooperative launch
+    // would be refused (a 4-hour job with ties fell through to the one-workgroup heap kernel) -- those sizes take the 32-bit form.
     const size_t budget = 130 * 1024;
+    const bool s16 = N <= 65535 && !c->linkage_hx_wide && (size_t)4 * N + 8 * 1024 <= budget;
     const size_t kp_bytes = s16 ? (size_t)4 * N : 0;
     int64_t lc64 = kp_bytes < budget ? (int64_t)((budget - kp_bytes) / 8) : 0;
     if (lc64 > HX_LDS_HEAP) lc64 = HX_LDS_HEAP;
@@ -451,6 +456,7 @@ int linkage_hx_run(sd_ctx* c, bool onex, int workers, double* D, int64_t N, int*
         le = hipLaunchCooperativeKernel(f, dim3(onex ? 8 * (G + 1) : G + 1), dim3(HX_T), args, dyn, c->stream);
     }
     if (le != hipSuccess) { (void)hipGetLastError(); *stopped = true; return SD_OK; }
+    if (launched) *launched = true;
     unsigned h[8] = {0};
     HIPCHK(c, hipMemcpyAsync(h, sync, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -491,13 +491,13 @@ static int seg_batch(sd_ctx* c, const float* d_wav, int64_t n, int64_t first_chu
                     KCHECK(c);
                 }
                 a.rowtab = dense_tab; a.pad_mode = 0; a.Tin = 512; a.T = 512; a.TpIn = a.TpOut = 512; a.in_rows = (int)(CB * F);
-                if (c->seg_precision == 3 && S.lstm_ih[l].W16x) { a.prec = 3; a.W16x = S.lstm_ih[l].W16x; a.acc_scale = S.lstm_ih[l].w16x_inv; }   // split operands (conv_gemm_h.hip P = 3)
+                if (seg_prec(c) == 3 && S.lstm_ih[l].W16x) { a.prec = 3; a.W16x = S.lstm_ih[l].W16x; a.acc_scale = S.lstm_ih[l].w16x_inv; }   // split operands (conv_gemm_h.hip P = 3)
             }
             if ((rc = launch_conv_gemm(c, a, "lstm_ih"))) return rc;
         }
         {
             ProfScope ps(c, "lstm_rec", 2.0 * CB * F * 2 * 512 * 128, 0);
-            if (c->seg_precision == 3 && S.lstm_hh_x[l][0] && S.lstm_hh_x[l][1])
+            if (seg_prec(c) == 3 && S.lstm_hh_x[l][0] && S.lstm_hh_x[l][1])
                 hipLaunchKernelGGL(k_lstm_rec_x3, dim3((unsigned)((CB + 31) / 32), 2), dim3(512), 0, st, G, (const _Float16*)S.lstm_hh_x[l][0], (const _Float16*)S.lstm_hh_x[l][1],
                                    S.lstm_hh_inv[l][0], S.lstm_hh_inv[l][1], hout, (int)CB, F);
             else

@@ -60,7 +60,7 @@ def test_segmentation_with_split_lstm_operands_holds_the_f32_bars(diarizer, weig
         sx = diarizer.segment(wav)
         short = diarizer.segment(wav[:47011])
     finally:
-        diarizer.set_option("seg_precision", 0)
+        diarizer.set_option("seg_precision", -1)
     assert not np.array_equal(sx, s32) and np.abs(sx - s32).max() <= 2e-6, np.abs(sx - s32).max()
     nc, last = orc.num_chunks(n)
     net = nn.PyanNetOracle(weights[2])
@@ -83,8 +83,38 @@ def test_option_keys_are_validated(diarizer):
         with pytest.raises(sdhip.SdError) as e:
             diarizer.set_option(key, val)
         assert e.value.code == 1 and frag in str(e.value), (key, val, str(e.value))
-    for key, val in (("ecapa_precision", 3), ("ecapa_precision", 0), ("seg_precision", 3), ("seg_precision", 0)):
+    for key, val in (("ecapa_precision", 3), ("ecapa_precision", 0), ("seg_precision", 3), ("seg_precision", 0), ("seg_precision", -1)):
         diarizer.set_option(key, val)
+
+
+def test_segmentation_precision_follows_the_embedding_mode_when_left_at_auto(diarizer, golden_dir):
+    """seg_precision = -1 (the default since round 6): PyanNet's LSTM takes the split-operand form whenever an fp16-pipe mode is selected for ECAPA
+    (ecapa_precision 1, 2 or 3) and the f32 MFMA otherwise -- bit for bit the scores of the explicit settings -- and the recording of BASELINE configs[0]
+    (multi-speaker_1min.wav) comes out with the same turns in fp16 mode whichever form the segmentation ran in."""
+    import sdhip
+    rng = np.random.default_rng(92)
+    n = 80000 + 8000 * 7 + 1234
+    wav = (0.05 * rng.standard_normal(n)).astype(np.float32) * (1 + np.sin(np.arange(n) / 1500.0)).astype(np.float32)
+    try:
+        diarizer.set_option("seg_precision", 0); s_f32 = diarizer.segment(wav)
+        diarizer.set_option("seg_precision", 3); s_x3 = diarizer.segment(wav)
+        diarizer.set_option("seg_precision", -1)
+        assert np.array_equal(diarizer.segment(wav), s_f32)
+        for mode in (1, 2, 3):
+            diarizer.set_option("ecapa_precision", mode)
+            assert np.array_equal(diarizer.segment(wav), s_x3), mode
+        diarizer.set_option("ecapa_precision", 0)
+        assert np.array_equal(diarizer.segment(wav), s_f32)
+        assert not np.array_equal(s_f32, s_x3) and np.abs(s_f32 - s_x3).max() <= 2e-6
+        pcm = sdhip.read_wav(os.path.join(golden_dir, "multi-speaker_1min.wav"))[0]
+        diarizer.set_option("ecapa_precision", 1)
+        t_auto = diarizer.diarize(pcm)
+        diarizer.set_option("seg_precision", 0)
+        t_f32seg = diarizer.diarize(pcm)
+        assert len(t_auto) > 0 and t_auto == t_f32seg
+    finally:
+        diarizer.set_option("seg_precision", -1)
+        diarizer.set_option("ecapa_precision", 0)
 
 
 def test_segmentation_shared_conv0_equals_per_chunk_conv0(diarizer, weights):

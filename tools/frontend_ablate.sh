@@ -3,9 +3,9 @@
 # without its FFT arithmetic (make libsdhip_feabl1.so libsdhip_feabl2.so first).  Prints other_kernels.stft_mel of three short bench runs.
 cd "$(dirname "$0")/.."
 P=$PWD/pyannote-audio_speaker-diarization_cpp_amd
-for lib in libsdhip.so libsdhip_feabl1.so libsdhip_feabl2.so; do
+for lib in $P/libsdhip.so tools/bin/libsdhip_feabl1.so tools/bin/libsdhip_feabl2.so; do
   echo "== $lib"
-  SDHIP_LIB=$P/$lib python bench.py --steps 2 --warmup 1 --fp16-steps 0 --x3-steps 0 --cpu-seconds 0 --ref-finalize 0 2>/dev/null | python -c "
+  SDHIP_LIB=$(realpath $lib) python bench.py --steps 2 --warmup 1 --fp16-steps 0 --x3-steps 0 --cpu-seconds 0 --ref-finalize 0 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

@@ -3,7 +3,7 @@
 # layer times of the x3 wide kernel with parts of its K-step removed (results are garbage, times are not) -- where the kernel's time goes
 cd "$GRAFT_REPO_ROOT"
 for v in "" 1 2 3; do
-  lib=pyannote-audio_speaker-diarization_cpp_amd/libsdhip${v:+_x3abl$v}.so
+  lib=pyannote-audio_speaker-diarization_cpp_amd/libsdhip.so; [ -n "$v" ] && lib=tools/bin/libsdhip_x3abl$v.so
   echo "== ${v:-product build} ($lib)"
   SDHIP_LIB=$PWD/$lib OPTS=ecapa_precision=3 python3 tools/layer_profile.py planted 1 f32 2>&1 | grep "block0\|tdnn\|mfa \|asp_conv"
 done
