@@ -1200,6 +1200,11 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
             (void)hipGetLastError();
         }
         if (use_rg) {
+            // "has the kernel written anything?" is read from Z itself: row 0 is zeroed here and written (size field >= 2) right behind the first merge's
+            // stores into D, before any later exit (linkage_rg.hip: write_Z follows the column pass, the row-tie check comes behind it).  Round 5 kept a
+            // merge counter in sync[28] instead; those two stores in the kernel's exit paths changed its register allocation and cost 9 ms per hour
+            // (profiles/r06_linkage_ab.txt: 76.2 -> 85.7 ms on one box, one process, interleaved).
+            HIPCHK(c, hipMemsetAsync(d_Z, 0, 4 * sizeof(double), c->stream));
             if (onex) {
                 le = linkage_rg_launch(c, true, G, TH, D, n_i, cid, nb, md, md2, d_Z, gran, sync, cap, (int)c->linkage_prefetch);
                 if (le != hipSuccess) { (void)hipGetLastError(); onex = false; }
@@ -1248,8 +1253,13 @@ int run_linkage(sd_ctx* c, const double* d_X, int64_t N, int d, double* d_Z)
     if (c->profile_detail) fprintf(stderr, "linkage: %s at N = %lld -> heap replay\n", why, (long long)N);
     // the reference's heap replayed with the row work spread over worker workgroups (k_linkage_hx) on the square matrix, where it fits
     // matrix, bounds and ids are still as linkage_prepare left them when nothing ran (forced replay, refused launch) or k_linkage_rg stopped in front of its
-    // first merge (sync[28] = merges made; with two pairs of duplicates: always): the replay starts from them, no second pdist
-    bool untouched = c->linkage_force_heap != 0 || launch_refused || (use_rg && h[5] && !h[1] && h[28] == 0);
+    // first merge (Z's row 0, zeroed before the launch, is still zero; with two pairs of duplicates: always): the replay starts from them, no second pdist
+    bool untouched = c->linkage_force_heap != 0 || launch_refused;
+    if (!untouched && use_rg && h[5] && !h[1]) {
+        double z03 = 1.0;
+        HIPCHK(c, hipMemcpy(&z03, d_Z + 3, sizeof(double), hipMemcpyDeviceToHost));
+        untouched = z03 == 0.0;
+    }
     if (square && c->linkage_tie_kernel != 0) {
         bool hx_onex = c->linkage_one_xcd != 0 && c->num_cu >= 256 && linkage_hx_fits(N, 31);
         int workers = hx_onex ? 31 : (N >= 60000 ? 127 : 63);

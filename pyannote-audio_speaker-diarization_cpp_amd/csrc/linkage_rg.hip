@@ -488,7 +488,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
             RSTAMP(4);
         }
         if (best.fl & CAND_TIE) {      // the closest pair is not unique: the heap decides (run_linkage); the height of the tie goes along
-            if (g == 0 && tid == 0) { sync[5] = 1; sync[26] = lo32(best.v); sync[27] = hi32(best.v); sync[28] = (unsigned)k; }      // (k: merges made -- 0 = nothing was written yet)
+            if (g == 0 && tid == 0) { sync[5] = 1; sync[26] = lo32(best.v); sync[27] = hi32(best.v); }
             return;
         }
         // ---- merge (x, y) at height dist; everything about the pair came with the candidate
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(TB) void k_linkage_rg(double* D, int n, int* cid, c
         digest(0, s_L[lp], s_Lty[lp], s_Lsz[lp], true);
         RSTAMP(3);
         par ^= 1;
-        if (d_rowtie) { if (g == 0 && tid == 0) { sync[5] = 1; sync[26] = lo32(dist); sync[27] = hi32(dist); sync[28] = (unsigned)k + 1u; } return; }     // (this merge's stores into row y are out: the matrix is not what linkage_prepare left)
+        if (d_rowtie) { if (g == 0 && tid == 0) { sync[5] = 1; sync[26] = lo32(dist); sync[27] = hi32(dist); } return; }     // (this merge's stores into row y are out, and so is row k of Z: run_linkage reads from Z's row 0 whether the matrix is still what linkage_prepare left)
         best = d_best;
         const RQ nn = d_nn;
         // row y: exact by construction (cl.cpp:395-404).  Without an active column above it the row has no pair left, now or later
