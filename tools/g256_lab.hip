@@ -755,6 +755,173 @@ __global__ __launch_bounds__(512) void k_pp3(Args a)
 }
 
 
+
+// ---- k_w4: 4 waves (one per SIMD) x 128 x 128 outputs, accumulators 256 registers per lane; no ping-pong: a wave interleaves its own fragment reads and
+// LDS-DMAs with its MFMAs, two barriers per K-tile.  Buffer b = T & 1 holds K-tile T ([A 256 rows | B 256 rows] x 128 B).  Per K-tile:
+//   phase X: 64 MFMAs on k-group 0 | reads of k-group 1 (buffer b) | the 8 B pieces of K-tile T + 1 -> buffer b ^ 1 (groups 0 - 3, two each)
+//   lgkmcnt(0), barrier B1: every wave has read buffer b out
+//   phase Y: 64 MFMAs on k-group 1 | the 8 A pieces of K-tile T + 2 -> buffer b (groups 0 - 3) | vmcnt(8), barrier B2 behind group 5 | reads of k-group 0 of T + 1 (groups 6, 7)
+template <int VAR>
+__global__ __launch_bounds__(256) void k_w4(Args a)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int w = blockIdx.x, G = gridDim.x;
+    const int xcd = w & 7, wl = w >> 3, wpx = G >> 3;
+    const int mx = (a.m_tiles - xcd + 7) >> 3;
+    const int PN = a.n_tiles < a.pnmax ? a.n_tiles : a.pnmax;
+    const int PM = wpx / PN > 0 ? wpx / PN : 1;
+    const int pm = wl / PN, pn = wl - pm * PN;
+    if (pm >= PM) return;
+    const int n_groups = (a.n_tiles + PN - 1) / PN, m_groups = (mx + PM - 1) / PM;
+    const int sb_end = n_groups * m_groups;
+    auto sb_valid = [&](int sb, int& j, int& nt) -> bool {
+        const int mg = sb / n_groups, ng = sb - mg * n_groups;
+        j = mg * PM + pm; nt = ng * PN + pn;
+        return j < mx && nt < a.n_tiles;
+    };
+    auto next_sb = [&](int sb) -> int {
+        int j, nt;
+        for (++sb; sb < sb_end; ++sb) if (sb_valid(sb, j, nt)) return sb;
+        return sb_end;
+    };
+    const int q0 = next_sb(-1);
+    if (q0 >= sb_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int S = a.K / 64;
+    const unsigned lds0 = (unsigned)(size_t)(lds_char*)lds;
+
+    // loader: wave `wid` stages LDS rows 64 wid + 8 p + (lane >> 3), p = 0 .. 7, of the A region and of the B region
+    const int prow = lane >> 3;
+    const unsigned ch0 = (unsigned)(((lane & 7) ^ ((prow >> 1) & 7)) * 16), ch1 = (unsigned)(((lane & 7) ^ (((8 + prow) >> 1) & 7)) * 16);      // chunk by row parity class: p even / odd
+    // A: row r of the tile;  B: LDS row 32 grp + 16 jj + rho holds channel 32 grp + 8 (rho >> 2) + 4 jj + (rho & 3)
+    unsigned voA[2], voB[2][2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        voA[pp] = (unsigned)(64 * wid + 8 * pp + prow) * (unsigned)a.K * 2u + (pp ? ch1 : ch0);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int rho = 8 * pp + prow;
+            voB[jj][pp] = (unsigned)(64 * wid + 8 * (rho >> 2) + 4 * jj + (rho & 3)) * (unsigned)a.K * 2u + (pp ? ch1 : ch0);      // + 32 grp rows by the piece's scalar offset
+        }
+    }
+    struct Cur { int sb; int t; int m0, n0; };
+    auto cur_set = [&](Cur& c) { int j, nt; (void)sb_valid(c.sb, j, nt); c.m0 = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * 256); c.n0 = __builtin_amdgcn_readfirstlane(nt * 256); };
+    auto cur_adv = [&](Cur& c) {
+        if (++c.t < S) return;
+        c.t = 0;
+        const int nq = next_sb(c.sb);
+        if (nq < sb_end) { c.sb = nq; cur_set(c); }
+    };
+    // piece p (0 .. 7) of the wave's 64 A rows: rows 8 p .. 8 p + 7
+    auto dmaA = [&](const Cur& c, int buf, int p) {
+        const v4i rs = make_rsrc((const char*)a.X + ((size_t)(c.m0 + 16 * (p >> 1)) * a.K + (size_t)c.t * 64) * 2);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * BUF_BYTES + (64 * wid + 8 * p) * 128));
+        lds_dma_b128(rs, dst, voA[p & 1], 0);
+    };
+    // piece p of the wave's 64 B rows: LDS rows 8 p .. + 7 of the wave's share = group grp = p >> 2 (of the wave's two 32-row groups), jj = (p >> 1) & 1, half pp = p & 1
+    auto dmaB = [&](const Cur& c, int buf, int p) {
+        const v4i rs = make_rsrc((const char*)a.W + ((size_t)(c.n0 + 32 * (p >> 2)) * a.K + (size_t)c.t * 64) * 2);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * BUF_BYTES + 32768 + (64 * wid + 8 * p) * 128));
+        lds_dma_b128(rs, dst, voB[(p >> 1) & 1][p & 1], 0);
+    };
+
+    const int sw = (l15 >> 1) & 7;
+    const int c0 = (l4 ^ sw) * 16, c1 = ((4 + l4) ^ sw) * 16;
+    const char* const Afr = lds + (128 * wr + l15) * 128;                 // + i * 2048 + c{ks}
+    const char* const Bfr = lds + 32768 + (128 * wc + l15) * 128;         // + j * 2048 + c{ks}
+    f32x4 fa[2][8], fb[2][8];
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto rdA = [&](int buf, int ks, int i) { fa[ks][i] = *(const f32x4*)(Afr + buf * BUF_BYTES + i * 2048 + (ks ? c1 : c0)); };
+    auto rdB = [&](int buf, int ks, int j) { fb[ks][j] = *(const f32x4*)(Bfr + buf * BUF_BYTES + j * 2048 + (ks ? c1 : c0)); };
+    // hipcc (ROCm 7.2) does not turn this into a spill-free kernel: with the builtin it keeps part of the 256 accumulator registers in VGPRs and some
+    // fragments in AGPRs and spills 84 - 166 registers into the loop; with the MFMA written as inline assembly and its accumulator pinned to the AGPR
+    // file ("+a") it spills 194 (its VGPR -> AGPR spill slots collide with the pinned accumulators).  The tiling needs hand-written assembly; the
+    // kernel stays here as the record of the attempt (VERDICT r05 #1 asked for it) -- correct, slow.
+    auto mma_row = [&](int ks, int i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fb[ks][j]), __builtin_bit_cast(half8, fa[ks][i]), acc[i][j], 0, 0, 0);
+    };
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+    Cur cc; cc.sb = q0; cc.t = 0; cur_set(cc);
+    Cur c1_ = cc, c2_ = cc;
+    // prologue: K-tile 0 whole -> buffer 0, A pieces of K-tile 1 -> buffer 1
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { dmaA(cc, 0, p); dmaB(cc, 0, p); }
+    cur_adv(c1_); c2_ = c1_;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dmaA(c1_, 1, p);
+    cur_adv(c2_);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { rdA(0, 0, i); rdB(0, 0, i); }
+
+    int q = q0, t = 0, buf = 0;
+    int m0c = cc.m0, n0c = cc.n0;
+    unsigned long long t_start = 0;
+    if (a.clk) t_start = __builtin_amdgcn_s_memtime();
+    while (true) {
+        // ---- phase X
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W4_FENCE();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            rdA(buf, 1, i); rdB(buf, 1, i);
+            if (i < 4) { dmaB(c1_, buf ^ 1, 2 * i); dmaB(c1_, buf ^ 1, 2 * i + 1); }
+            mma_row(0, i);
+            W4_FENCE();
+        }
+        cur_adv(c1_);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W4_FENCE(); __builtin_amdgcn_s_barrier(); W4_FENCE();
+        // ---- phase Y
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < 4) { dmaA(c2_, buf, 2 * i); dmaA(c2_, buf, 2 * i + 1); }
+            if (i == 6) {
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                W4_FENCE(); __builtin_amdgcn_s_barrier(); W4_FENCE();
+            }
+            if (i >= 6) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { rdA(buf ^ 1, 0, 4 * (i - 6) + r); rdB(buf ^ 1, 0, 4 * (i - 6) + r); }
+            }
+            mma_row(1, i);
+            W4_FENCE();
+        }
+        cur_adv(c2_);
+        buf ^= 1;
+        if (t == S - 1) {
+            // lab epilogue: all four waves at once, plain conversion (the product form would carry it in chunks as k_pp2 does)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    const int row = m0c + 128 * wr + 16 * i + l15;
+                    const int col = n0c + 128 * wc + 32 * grp + 8 * l4;
+                    half8 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { hv[e] = (_Float16)acc[i][2 * grp + (e >> 2)][e & 3]; acc[i][2 * grp + (e >> 2)][e & 3] = 0.0f; }
+                    *(half8*)(a.Y + (size_t)row * a.N + col) = hv;
+                }
+            q = next_sb(q);
+            if (q >= sb_end) break;
+            { int j_, nt_; (void)sb_valid(q, j_, nt_); m0c = __builtin_amdgcn_readfirstlane((xcd + 8 * j_) * 256); n0c = __builtin_amdgcn_readfirstlane(nt_ * 256); }
+            t = 0;
+        } else ++t;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.clk && tid == 0) a.clk[blockIdx.x] = __builtin_amdgcn_s_memtime() - t_start;
+}
+
 // ---- reference: selected rows, f32 accumulation in k order (any order is within the check's tolerance)
 __global__ void k_ref_rows(const _Float16* X, const _Float16* W, const int* rows, float* out, int N, int K, const float* P)
 {
@@ -799,10 +966,11 @@ int main(int argc, char** argv)
     printf("%s, %d CUs, rows %d\n", prop.name, cus, M);
     const int shapes[2][2] = {{1024, 1024}, {3072, 3072}};
     typedef void (*kern_t)(Args);
-    struct V { const char* name; kern_t k; int check; int pn; int gdiv = 1; int skew = 0; };          // check: 0 none, 1 plain product, 2 with the k_pp2 epilogue
+    struct V { const char* name; kern_t k; int check; int pn; int gdiv = 1; int skew = 0; };
+    auto threads_of = [&](const V& v) { return strncmp(v.name, "W4", 2) == 0 ? 256 : 512; };          // check: 0 none, 1 plain product, 2 with the k_pp2 epilogue
     const V vars[] = {{"PP2 nv6", k_pp2<6, 0>, 2, 4}, {"PP2 dma first", k_pp2<6, 32>, 2, 4}, {"PP2 dma split", k_pp2<6, 64>, 2, 4}, 
                       {"PP3 nv6", k_pp3<6, 0>, 2, 4}, {"DMA only", k_pp<4 | 16>, 0, 4}, {"reg loads only", k_pp<4 | 16 | 128>, 0, 4},
-                      {"PP3 g1 dma first", k_pp3<6, 32>, 2, 4}, {"PP3 both dma first", k_pp3<6, 32 | 64>, 2, 4}, {"PP3 g0 dma first", k_pp3<6, 64>, 2, 4}};
+                      {"W4", k_w4<0>, 1, 4}};
     const int vmask = argc > 2 ? (int)strtol(argv[2], nullptr, 0) : 0x7fffffff;
     const int rounds = argc > 3 ? atoi(argv[3]) : 3;
     const size_t lds_bytes = 2 * BUF_BYTES + 8 * 2048;
@@ -843,7 +1011,7 @@ int main(int argc, char** argv)
             for (int r = -1; r < reps; ++r) {
                 if (r == 0) CK(hipEventRecord(e0, 0));
                 a.clk = (r == reps - 1) ? clk : nullptr;
-                hipLaunchKernelGGL(v.k, dim3(grid), dim3(512), lds_bytes, 0, a);
+                hipLaunchKernelGGL(v.k, dim3(grid), dim3(threads_of(v)), lds_bytes, 0, a);
             }
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
             float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
