@@ -1,34 +1,37 @@
-// conv_gemm_p.hip -- the fp16 mode's wide layers (Cout >= 256) as a two-group "ping-pong" kernel (round 6).
+// conv_gemm_p.hip -- the fp16 mode's wide layers (Cout >= 256, K >= 1 024) with a load stream that is never drained (round 6).
 //
-// conv_gemm_g.hip (round 4) stages a whole K-step per barrier and drains its LDS-DMA queue in front of every barrier; it runs at the rate at which a
+// conv_gemm_g.hip (round 4) stages a whole K-step per barrier and empties its LDS-DMA queue in front of every barrier: it runs at the rate at which a
 // 64 KB burst lands.  Round 6 measured the pieces one by one in a stand-alone loop (tools/g256_lab.hip, profiles/r06_g256_lab.txt): a CU takes in
 // 24 - 27 bytes per clock whichever way the bytes are requested (LDS-DMA or register loads, 4 or 8 waves issuing, 64 / 128 / 256 workgroups on the
-// chip), i.e. 2 400 - 2 700 cycles for the 64 KB a 256 x 256 x 64 K-tile needs, against 2 048 for its MFMAs -- the tile is bound by the CU's ingest,
-// and what a kernel can lose on top is the time in which nothing is being requested.  This kernel keeps the queue fed all the time:
+// chip), i.e. 2 400 - 2 700 cycles for the 64 KB a 256 x 256 x 64 K-tile needs, against 2 048 for its MFMAs: the tile is bound by the CU's ingest,
+// and what a kernel loses on top is the time in which nothing is being requested.  Two loop structures were built on that:
+//   * "ping-pong" (k_pp2 in the lab; this file's first form, commit 3c2c29b): two wave groups half a phase apart, one multiplies while the other reads
+//     fragments and issues DMAs, half-tiles released phase by phase: 3 184 cycles per K-tile = 2 624 (its DMAs' issue time) + 8 barriers of ~ 70;
+//   * what is here (k_w8 in the lab): NO roles -- every wave interleaves its own fragment reads and LDS-DMAs with its MFMAs, the two waves of a SIMD
+//     cover each other's DMA-issue stalls, two barriers per K-tile: 3 010 cycles per K-tile on MFA (1 220 TF in the lab against 1 142), 3 450 against
+//     3 820 on tdnn.
 //
-//  * 8 waves = 2 groups (row halves) x 4 (column quarters); a wave owns 128 x 64 outputs as four 64 x 32 quadrants (16 v_mfma_f32_16x16x32_f16 each).
-//    A K-tile is four phases, one per quadrant; a phase = load segment | barrier | MFMA segment | barrier, and group 1 runs one barrier behind group 0:
-//    on every SIMD one wave multiplies while its partner reads fragments and issues LDS-DMAs (cdna_hip_programming.md, "The 256^2 8-phase template";
-//    MI355X_MICROARCH.md, "Two waves per SIMD").
-//  * LDS: 2 buffers x {A half 0, A half 1, B half 0, B half 1} x 128 rows x 128 B.  A half h holds the tile rows BOTH groups read in the same phase
-//    (group g's quadrant rows mh are tile rows 128 mh + 64 g .. + 63; B likewise by column quarter), so a half-tile is free two phases after its last
-//    read and is refilled for the K-tile after next while this one is still being multiplied.  Every phase stages one half-tile (2 LDS-DMAs per wave)
-//    and waits with vmcnt(6): three half-tiles (48 KB) are in flight per CU at any time and no wait empties the queue.
-//      phase 0: reads B half 0 + A half 0, stages B half 1 of K-tile T + 1      phase 2: reads A half 1, stages A half 0 of T + 2
-//      phase 1: reads B half 1,            stages A half 1 of T + 1             phase 3: (B half 0 stays in registers), stages B half 0 of T + 2
-//    (a half-tile staged in phase P is waited for in phase P + 3 by every wave and first read in phase P + 4 or later, behind the barriers in between;
-//    it is restaged no earlier than two phases after its last read: "Read a staged buffer one phase AFTER the wait that retires it").
+//  * 256 x 256 tile, K-tile of 64 halves, 8 waves = 2 (row groups) x 4 (column quarters); a wave owns 128 x 64 outputs = 8 row blocks x 4 column blocks
+//    of 16 x 16 (v_mfma_f32_16x16x32_f16, 128 accumulator registers), multiplied k-group by k-group (32 halves each): sub-group s = row blocks 2 s, 2 s + 1.
+//  * LDS: 2 buffers x {A half 0, A half 1, B half 0, B half 1} x 128 rows x 128 B (unpadded, 16-byte chunk c of row R at c ^ ((R >> 1) & 7): conflict-free
+//    ds_read_b128, as in conv_gemm_g.hip).  Buffer b = T & 1 holds K-tile T.  Per K-tile and wave: 64 MFMAs, 24 fragment reads, 8 LDS-DMAs (1 KB each):
+//      phase X: 32 MFMAs on k-group 0 | the 12 fragment reads of k-group 1 (buffer b) | the 4 B pieces of K-tile T + 1 -> buffer b ^ 1, one behind every sub-group
+//      lgkmcnt(0), barrier B1: every wave has read buffer b out
+//      phase Y: 32 MFMAs on k-group 1 | the 4 A pieces of K-tile T + 2 -> buffer b, one behind every sub-group | in front of sub-group 3: vmcnt(3) (all of
+//               K-tile T + 1 has landed: its A pieces went out a K-tile ago, its B pieces in phase X), barrier B2, the 12 reads of k-group 0 of T + 1
+//    Eight DMAs per wave are in flight at any time, no wait ever empties the queue, the activation rows (HBM) have more than a K-tile to land, the weights
+//    (L2) half of one.
 //  * Output: the weight fragment is the MFMA's first operand, so a lane holds four consecutive channels of one row per 16 x 16 block; the loader
 //    permutes which weight row goes to which LDS row (LDS row 16 j + rho of a wave's 32 channels holds channel 8 (rho >> 2) + 4 j + (rho & 3)), so
-//    blocks j = 0, 1 together give a lane EIGHT consecutive channels = one 16-byte store, no cross-lane transposes, no LDS strip.
-//  * Epilogue in 16 chunks (quadrant x 16 rows = 8 values per lane: bias, activation, BatchNorm, one store) that ride behind the MFMAs of the
-//    segments around the tile boundary: quadrant (0,0) is final after phase 0 of the tile's last K-tile and goes out in its phases 1 - 2, (0,1) in
-//    phases 2 - 3, (1,1) and (1,0) in phases 0 - 2 of the NEXT tile's first K-tile (a chunk zeroes what it has read).  The load stream never stops
-//    for a tile boundary.  Parameters of the wave's 64 channels come through a wave-private LDS area (three small LDS-DMAs per tile, two areas by
+//    column blocks 2 nh, 2 nh + 1 together give a lane EIGHT consecutive channels = one 16-byte store, no cross-lane transposes, no LDS strip.
+//  * Epilogue in 16 chunks (row block x column pair = 8 values per lane: bias, activation, BatchNorm, one store; a chunk zeroes what it has read), run
+//    in front of the NEXT tile's first MFMAs (in a basic block of their own: in one block with MFMAs hipcc spills 217 registers); the load stream never
+//    stops for a tile boundary.  Parameters of the wave's 64 channels come through a wave-private LDS area (three small LDS-DMAs per tile, two areas by
 //    tile parity), the row table entries of the rows a wave stages through another (one LDS-DMA per tile, one tile ahead): no compiler-visible
 //    vector-memory load sits in the loop, so hipcc's own vmcnt waits never drain the DMA queue.
 //
-// Same products in the same order as k_conv_gemm_g256<2> (K-groups of 32 ascending, one 16x16x32 MFMA per group and block), operands swapped.
+// Same products in the same order as k_conv_gemm_g256<2> (K-groups of 32 ascending, one 16x16x32 MFMA per group and block), operands swapped: the two
+// kernels are compared bit for bit (tests/test_gpu_parity.py::test_ecapa_fp16_ping_pong_kernel_gives_the_same_bits).
 // Takes fp16 tensors only (prec 1), row-table layers without second input / per-item bias / residual / second activation; everything else stays
 // with conv_gemm_g.hip / conv_gemm_h.hip.
 #include "common.h"
@@ -117,20 +120,20 @@ __global__ __launch_bounds__(512) void k_conv_gemm_pp(ConvArgs a)
     const unsigned par0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(P_PAR + wid * 2048));
     const v4i rTab = pp_rsrc(a.rowtab, (size_t)a.M * 8);      // rows >= M read as {0, 0}: any valid address will do, their outputs are never stored
 
-    // A cursor walks the workgroup's stream of K-tiles: (tile, tap kk, channel chunk kc).  c1 = the K-tile after the one being multiplied (it stages
-    // A half 1 and B half 1), c2 = the one after that (A half 0, B half 0).  Each keeps the row offsets of the A rows it stages.
+    // Two cursors walk the workgroup's stream of K-tiles (tile, tap kk, channel chunk kc): cB = the K-tile after the one being multiplied (its B pieces
+    // go out in phase X), cA = the one after that (its A pieces go out in phase Y; it keeps the row offsets of the A rows this wave stages).
     struct Cur {
         int sb, kk, kc, m0, n0, base, tiles;         // base: first input row of the tile's first item (the buffer descriptor starts there)
-        int rr[2], yy[2];                            // per piece: input row of the item's frame 0 minus base; packed frame / last stored frame
-        unsigned vo[2];
+        int rr[4], yy[4];                            // cA, per piece q = 2 h + p: input row of the item's frame 0 minus base; packed frame / last stored frame
+        unsigned vo[4];
     };
     auto tile_of = [&](int sb, int& m0, int& n0) { int j, nt; (void)sb_valid(sb, j, nt); m0 = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * 256); n0 = __builtin_amdgcn_readfirstlane(nt * 256); };
     auto table_dma = [&](int m0, int slot) {         // this wave's 32 rows of tile m0: lanes 0-7 rows 16 wid .. + 15 of half 0 (two entries each), lanes 8-15 of half 1
         const unsigned dst = __builtin_amdgcn_readfirstlane(tab0 + (unsigned)(slot * 256));
         if (lane < 16) pp_dma_b128(rTab, dst, (unsigned)(m0 + 128 * (lane >> 3) + 16 * wid + 2 * (lane & 7)) * 8u);
     };
-    auto cur_rows = [&](Cur& c, int h) {             // entries of the tile the cursor has just entered (its table slot was filled a tile ago)
-        const int2* const tb = (const int2*)(lds + P_TAB + wid * 512 + (c.tiles & 1) * 256) + h * 16;
+    auto cur_rows = [&](Cur& c) {                    // entries of the tile the cursor has just entered (its table slot was filled a tile ago)
+        const int2* const tb = (const int2*)(lds + P_TAB + wid * 512 + (c.tiles & 1) * 256);
         const int m0c = c.m0 < a.M ? c.m0 : a.M - 1;
         {   // rowtab[m0c].x by a scalar load written out by hand: hipcc takes the address for divergent and emits a global_load + vmcnt(0), which would drain the DMA queue
             const unsigned long long ad = (unsigned long long)(a.rowtab + m0c);
@@ -141,45 +144,43 @@ __global__ __launch_bounds__(512) void k_conv_gemm_pp(ConvArgs a)
             c.base = bs;
         }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) { const int2 e = tb[p * 8 + prow]; c.rr[p] = e.x - c.base; c.yy[p] = e.y; }
+        for (int q = 0; q < 4; ++q) { const int2 e = tb[(q >> 1) * 16 + (q & 1) * 8 + prow]; c.rr[q] = e.x - c.base; c.yy[q] = e.y; }
     };
     auto cur_tap = [&](Cur& c) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            int qr = ROWTAB_T(c.yy[p]) + ((c.kk >= ktr ? c.kk - ktr : c.kk) - half) * a.dil;
-            const int nd = ROWTAB_LAST(c.yy[p]);
+        for (int q = 0; q < 4; ++q) {
+            int qr = ROWTAB_T(c.yy[q]) + ((c.kk >= ktr ? c.kk - ktr : c.kk) - half) * a.dil;
+            const int nd = ROWTAB_LAST(c.yy[q]);
             if (qr < 0) qr = -qr;
             if (qr >= a.Tin) qr = 2 * (a.Tin - 1) - qr;
             if (qr < 0) qr = 0;
             if (qr > nd) qr = nd;
-            c.vo[p] = (unsigned)(c.rr[p] + qr) * (unsigned)a.x_ld * 2u + chk[p];
+            c.vo[q] = (unsigned)(c.rr[q] + qr) * (unsigned)a.x_ld * 2u + chk[q & 1];
         }
     };
-    // returns true when the cursor has entered a new tile
-    auto cur_adv = [&](Cur& c, int h) -> bool {
+    // next K-tile; IS_A: the cursor that carries the activation rows.  Returns true when it has entered a new tile
+    auto cur_adv = [&](Cur& c, bool is_a) -> bool {
         if (++c.kc < kcs) return false;
         c.kc = 0;
-        if (++c.kk < a.KT) { cur_tap(c); return false; }
+        if (++c.kk < a.KT) { if (is_a) cur_tap(c); return false; }
         c.kk = 0;
         const int nq = next_sb(c.sb);
-        if (nq >= sb_end) { cur_tap(c); return false; }          // past the last tile: the stream re-reads the last tile (never multiplied)
+        if (nq >= sb_end) { if (is_a) cur_tap(c); return false; }          // past the last tile: the stream re-reads the last tile (never multiplied)
         c.sb = nq; ++c.tiles;
         tile_of(nq, c.m0, c.n0);
-        cur_rows(c, h);
-        cur_tap(c);
+        if (is_a) { cur_rows(c); cur_tap(c); }
         return true;
     };
-    auto stageA = [&](const Cur& c, int h, int buf) {
+    // piece q = 0 .. 3 of the wave's share of a K-tile's A (B): half q >> 1, piece q & 1
+    auto dmaA = [&](const Cur& c, int buf, int q) {
         const v4i rs = pp_rsrc(X + ((size_t)c.base * a.x_ld + (size_t)c.kc * 64), (in_rows - (size_t)c.base) * a.x_ld * 2);
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * P_BUF + h * P_HALF) + dstw);
-        pp_dma_b128(rs, dst, c.vo[0]);
-        pp_dma_b128(rs, dst + 1024, c.vo[1]);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * P_BUF + (q >> 1) * P_HALF + (q & 1) * 1024) + dstw);
+        pp_dma_b128(rs, dst, c.vo[q]);
     };
-    auto stageB = [&](const Cur& c, int h, int buf) {
-        const v4i rs = pp_rsrc(W16 + (((size_t)c.kk * a.Cout + c.n0 + 128 * h) * a.w_ld + (size_t)c.kc * 64), 0xffffffffull);
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * P_BUF + (2 + h) * P_HALF) + dstw);
-        pp_dma_b128(rs, dst, voB[0]);
-        pp_dma_b128(rs, dst + 1024, voB[1]);
+    auto dmaB = [&](const Cur& c, int buf, int q) {
+        const v4i rs = pp_rsrc(W16 + (((size_t)c.kk * a.Cout + c.n0 + 128 * (q >> 1)) * a.w_ld + (size_t)c.kc * 64), 0xffffffffull);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * P_BUF + (2 + (q >> 1)) * P_HALF + (q & 1) * 1024) + dstw);
+        pp_dma_b128(rs, dst, voB[q & 1]);
     };
     // parameters of the wave's 64 channels: lane k < 16 of DMA `arr` fetches channels 128 (k >> 3) + 32 wc + 4 (k & 7) .. + 3 -> floats [arr][k][4] of the area
     const unsigned voP = (unsigned)(128 * ((lane & 15) >> 3) + 32 * wc + 4 * (lane & 7)) * 4u;
@@ -198,44 +199,32 @@ __global__ __launch_bounds__(512) void k_conv_gemm_pp(ConvArgs a)
     const int c0 = (l4 ^ sw) * 16, c1 = ((4 + l4) ^ sw) * 16;
     const char* const Afr = lds + (64 * g + l15) * 128;                  // + mh * P_HALF + i * 2048 + c{ks}
     const char* const Bfr = lds + 2 * P_HALF + (32 * wc + l15) * 128;    // + nh * P_HALF + j * 2048 + c{ks}
-    float4 fa[4][2], fb0[2][2], fb1[2][2];
-    f32x4 acc[2][2][4][2];
+    float4 fa[2][8], fb[2][4];          // [k-group][row block R = 4 mh + i], [k-group][column block C = 2 nh + j]
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int l = 0; l < 2; ++l) acc[i][j][k][l] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto readA = [&](int buf, int mh) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fa[i][0] = *(const float4*)(Afr + buf * P_BUF + mh * P_HALF + i * 2048 + c0);
-            fa[i][1] = *(const float4*)(Afr + buf * P_BUF + mh * P_HALF + i * 2048 + c1);
-        }
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto rdA = [&](int buf, int ks, int R) { fa[ks][R] = *(const float4*)(Afr + buf * P_BUF + (R >> 2) * P_HALF + (R & 3) * 2048 + (ks ? c1 : c0)); };
+    auto rdB = [&](int buf, int ks, int C) { fb[ks][C] = *(const float4*)(Bfr + buf * P_BUF + (C >> 1) * P_HALF + (C & 1) * 2048 + (ks ? c1 : c0)); };
+    auto rd_set = [&](int buf, int ks, int part) {         // the 12 reads of a k-group in four parts of three
+        if (part == 0) { rdB(buf, ks, 0); rdB(buf, ks, 1); rdB(buf, ks, 2); }
+        else if (part == 1) { rdB(buf, ks, 3); rdA(buf, ks, 0); rdA(buf, ks, 1); }
+        else if (part == 2) { rdA(buf, ks, 2); rdA(buf, ks, 3); rdA(buf, ks, 4); }
+        else { rdA(buf, ks, 5); rdA(buf, ks, 6); rdA(buf, ks, 7); }
     };
-    auto readB = [&](int buf, int nh, float4 (&fb)[2][2]) {
+    auto mma_sg = [&](int ks, int sg) {                    // sub-group sg: row blocks 2 sg, 2 sg + 1
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            fb[j][0] = *(const float4*)(Bfr + buf * P_BUF + nh * P_HALF + j * 2048 + c0);
-            fb[j][1] = *(const float4*)(Bfr + buf * P_BUF + nh * P_HALF + j * 2048 + c1);
-        }
+        for (int C = 0; C < 4; ++C)
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
+                acc[2 * sg + r2][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fb[ks][C]), __builtin_bit_cast(half8, fa[ks][2 * sg + r2]), acc[2 * sg + r2][C], 0, 0, 0);
     };
-    auto mma = [&](int mh, int nh, const float4 (&fb)[2][2]) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[mh][nh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fb[j][ks]), __builtin_bit_cast(half8, fa[i][ks]), acc[mh][nh][i][j], 0, 0, 0);
-    };
-    // one epilogue chunk: rows 128 mh + 64 g + 16 i + l15, channels 128 nh + 32 wc + 8 l4 .. + 7 of the tile behind `rY` (rows >= M fall outside the descriptor)
+    // one epilogue chunk: row block R (rows 128 (R >> 2) + 64 g + 16 (R & 3) + l15), channels 128 nh + 32 wc + 8 l4 .. + 7 of the tile behind `rY` (rows >= M fall outside the descriptor)
     const float slope = (a.act1 == 1) ? 0.0f : ((a.act1 == 2) ? 0.01f : 1.0f);
     const unsigned ybytes = (unsigned)a.y_ld * 2u;
     const unsigned voY = (unsigned)(64 * g + l15) * ybytes + (unsigned)(32 * wc + 8 * l4) * 2u;
-    auto chunk = [&](int mh, int nh, int i, int par, __amdgpu_buffer_rsrc_t rY) {
+    auto chunk = [&](int R, int nh, int par, __amdgpu_buffer_rsrc_t rY) {
         const float* const pw = (const float*)(lds + P_PAR + wid * 2048 + par * 1024) + (nh * 8 + 2 * l4) * 4;
         half8 hv;
 #pragma unroll
@@ -245,14 +234,14 @@ __global__ __launch_bounds__(512) void k_conv_gemm_pp(ConvArgs a)
             const float bb[4] = {b.x, b.y, b.z, b.w}, ss[4] = {sc.x, sc.y, sc.z, sc.w}, hh[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = acc[mh][nh][i][hf][e] + bb[e];
-                acc[mh][nh][i][hf][e] = 0.0f;
+                float v = acc[R][2 * nh + hf][e] + bb[e];
+                acc[R][2 * nh + hf][e] = 0.0f;
                 v = fmaxf(v, v * slope);
                 hv[4 * hf + e] = (_Float16)(v * ss[e] + hh[e]);
             }
         }
         asm volatile("" ::: "memory");
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, hv), rY, voY + (unsigned)(128 * mh + 16 * i) * ybytes, 256u * nh, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, hv), rY, voY + (unsigned)(128 * (R >> 2) + 16 * (R & 3)) * ybytes, 256u * nh, 0);
     };
     _Float16* const Y = (_Float16*)a.Y;
     auto make_rY = [&](int m0, int n0) {
@@ -260,78 +249,75 @@ __global__ __launch_bounds__(512) void k_conv_gemm_pp(ConvArgs a)
         return __builtin_amdgcn_make_buffer_rsrc((void*)(Y + (size_t)m0 * a.y_ld + n0), 0, (unsigned)((size_t)(rows_left < 256 ? rows_left : 256) * a.y_ld * 2), 0x00020000);
     };
 
-#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PP_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PP_VM6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
-#define PP_MSEG_BEGIN() do { PP_BARRIER(); PP_LGKM0(); __builtin_amdgcn_s_setprio(1); } while (0)
-#define PP_MSEG_END() do { __builtin_amdgcn_s_setprio(0); PP_BARRIER(); } while (0)
+#define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define PP_BARRIER() do { PP_FENCE(); __builtin_amdgcn_s_barrier(); PP_FENCE(); } while (0)
 
-    // ---- prologue: the first tile's row table entries (and the second tile's, one tile ahead), K-tile 0 whole, A half 0 and B half 0 of K-tile 1
-    Cur cc; cc.sb = q0; cc.kk = 0; cc.kc = 0; cc.tiles = 0;
-    tile_of(q0, cc.m0, cc.n0);
-    table_dma(cc.m0, 0);
+    // ---- prologue: the first tile's row table entries (and the second tile's, one tile ahead), K-tile 0 whole -> buffer 0, the A pieces of K-tile 1 -> buffer 1
+    Cur cA; cA.sb = q0; cA.kk = 0; cA.kc = 0; cA.tiles = 0;
+    tile_of(q0, cA.m0, cA.n0);
+    table_dma(cA.m0, 0);
     { const int nq = next_sb(q0); if (nq < sb_end) { int m1, n1; tile_of(nq, m1, n1); table_dma(m1, 1); } }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    Cur c1_ = cc, c2_ = cc;
-    cur_rows(c1_, 1); cur_tap(c1_);
-    cur_rows(c2_, 0); cur_tap(c2_);
-    stageA(c2_, 0, 0); stageB(c2_, 0, 0); stageB(c1_, 1, 0); stageA(c1_, 1, 0);
-    // (a cursor that enters a new tile asks for the row table entries of the tile AFTER it: only c2, the leading one, does)
+    cur_rows(cA); cur_tap(cA);
+    Cur cB = cA;
+    const int m0_first = cA.m0, n0_first = cA.n0;
+    // (the cursor that enters a new tile asks for the row table entries of the tile AFTER it)
     auto lead_adv = [&]() {
-        if (cur_adv(c2_, 0)) { const int nq = next_sb(c2_.sb); if (nq < sb_end) { int m1, n1; tile_of(nq, m1, n1); table_dma(m1, (c2_.tiles + 1) & 1); } }
+        if (cur_adv(cA, true)) { const int nq = next_sb(cA.sb); if (nq < sb_end) { int m1, n1; tile_of(nq, m1, n1); table_dma(m1, (cA.tiles + 1) & 1); } }
     };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { dmaA(cA, 0, q); dmaB(cB, 0, q); }
     lead_adv();
-    stageA(c2_, 0, 1); stageB(c2_, 0, 1);
-    (void)cur_adv(c1_, 1);
+    (void)cur_adv(cB, false);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dmaA(cA, 1, q);
     lead_adv();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // K-tile 0 (and whatever row table went out behind it: older than the four pieces left in flight)
     __builtin_amdgcn_s_barrier();
-    if (g == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind
+#pragma unroll
+    for (int part = 0; part < 4; ++part) rd_set(0, 0, part);
 
     int q = q0, t = 0, buf = 0, par = 0;
     bool have_prev = false;
-    __amdgpu_buffer_rsrc_t rYc = make_rY(cc.m0, cc.n0), rYp = rYc;
-    int n0c = cc.n0;
+    __amdgpu_buffer_rsrc_t rYc = make_rY(m0_first, n0_first), rYp = rYc;
+    int n0c = n0_first;
     while (true) {
-        const bool last = t == S - 1, carry = t == 0 && have_prev;      // the tile's last K-tile carries chunks of quadrants (0,0), (0,1); its first K-tile those of the tile before
-        // phase 0: quadrant (0, 0); stages B half 1 of the next K-tile
-        readB(buf, 0, fb0); __builtin_amdgcn_sched_barrier(0); readA(buf, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        stageB(c1_, 1, buf ^ 1); PP_VM6();
-        PP_MSEG_BEGIN();
-        mma(0, 0, fb0);
-        if (carry) { chunk(1, 1, 0, par ^ 1, rYp); chunk(1, 1, 1, par ^ 1, rYp); chunk(1, 1, 2, par ^ 1, rYp); }
-        PP_MSEG_END();
-        // phase 1: quadrant (0, 1); stages A half 1 of the next K-tile
-        readB(buf, 1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        stageA(c1_, 1, buf ^ 1); PP_VM6();
-        (void)cur_adv(c1_, 1);
-        PP_MSEG_BEGIN();
-        mma(0, 1, fb1);
-        if (last) { chunk(0, 0, 0, par, rYc); chunk(0, 0, 1, par, rYc); }
-        if (carry) { chunk(1, 1, 3, par ^ 1, rYp); chunk(1, 0, 0, par ^ 1, rYp); chunk(1, 0, 1, par ^ 1, rYp); }
-        PP_MSEG_END();
-        // phase 2: quadrant (1, 1); stages A half 0 of the K-tile after next (A half 0 of this one was last read in phase 0)
-        readA(buf, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        stageA(c2_, 0, buf); PP_VM6();
-        PP_MSEG_BEGIN();
-        mma(1, 1, fb1);
-        if (last) { chunk(0, 0, 2, par, rYc); chunk(0, 0, 3, par, rYc); chunk(0, 1, 0, par, rYc); }
-        if (carry) { chunk(1, 0, 2, par ^ 1, rYp); chunk(1, 0, 3, par ^ 1, rYp); }
-        PP_MSEG_END();
-        // phase 3: quadrant (1, 0); stages B half 0 of the K-tile after next (and, in a tile's first K-tile, its parameters)
-        if (t == 0) stageP(n0c, par);
-        stageB(c2_, 0, buf); PP_VM6();
+        // ---- phase X
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PP_FENCE();
+        if (t == 0 && have_prev) {
+            // the first K-tile of a tile: the 16 chunks of the tile before, in a block of their own
+#pragma unroll
+            for (int R = 0; R < 8; ++R) { chunk(R, 0, par ^ 1, rYp); chunk(R, 1, par ^ 1, rYp); }
+        }
+        PP_FENCE();
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            rd_set(buf, 1, sg);
+            mma_sg(0, sg);
+            PP_FENCE();
+            dmaB(cB, buf ^ 1, sg);
+            PP_FENCE();
+        }
+        (void)cur_adv(cB, false);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        // ---- phase Y
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            if (sg == 3) {
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                PP_BARRIER();
+                if (t == 0) stageP(n0c, par);
+                rd_set(buf ^ 1, 0, 0); rd_set(buf ^ 1, 0, 1); rd_set(buf ^ 1, 0, 2); rd_set(buf ^ 1, 0, 3);
+            }
+            mma_sg(1, sg);
+            PP_FENCE();
+            dmaA(cA, buf, sg);
+            PP_FENCE();
+        }
         lead_adv();
-        PP_BARRIER(); __builtin_amdgcn_s_setprio(1);
-        mma(1, 0, fb0);
-        if (last) { chunk(0, 1, 1, par, rYc); chunk(0, 1, 2, par, rYc); chunk(0, 1, 3, par, rYc); }
-        PP_MSEG_END();
-
         buf ^= 1;
-        if (last) {
+        if (t == S - 1) {
             q = next_sb(q);
             rYp = rYc; have_prev = true; par ^= 1;
             if (q >= sb_end) break;
@@ -339,11 +325,9 @@ __global__ __launch_bounds__(512) void k_conv_gemm_pp(ConvArgs a)
             t = 0;
         } else ++t;
     }
-    // the last tile's quadrants (1,1) and (1,0)
+    // the last tile's chunks
 #pragma unroll
-    for (int i = 0; i < 4; ++i) chunk(1, 1, i, par ^ 1, rYp);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) chunk(1, 0, i, par ^ 1, rYp);
+    for (int R = 0; R < 8; ++R) { chunk(R, 0, par ^ 1, rYp); chunk(R, 1, par ^ 1, rYp); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the load stream runs past the last tile: nothing may be in flight when the LDS is given back
 }
 

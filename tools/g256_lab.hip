@@ -922,6 +922,207 @@ __global__ __launch_bounds__(256) void k_w4(Args a)
     if (a.clk && tid == 0) a.clk[blockIdx.x] = __builtin_amdgcn_s_memtime() - t_start;
 }
 
+
+// ---- k_w8: 8 waves, NO ping-pong -- every wave interleaves its own fragment reads and LDS-DMAs with its MFMAs (the two waves of a SIMD cover each other's
+// DMA-issue stalls), two barriers per K-tile, DMAs evenly spread and never drained.  Same wave tile and LDS image as k_pp2 (A half 0 / 1, B half 0 / 1 per
+// buffer), MFMAs ks-major:
+//   phase X: 32 MFMAs on k-group 0 (4 sub-groups of 8 = two row blocks x four column blocks) | the 12 fragment reads of k-group 1 | the 4 B pieces of K-tile T + 1 -> buffer b ^ 1
+//   lgkmcnt(0), barrier B1: buffer b is read out
+//   phase Y: 32 MFMAs on k-group 1 | the 4 A pieces of K-tile T + 2 -> buffer b | behind sub-group 2: vmcnt(3), barrier B2, the 12 reads of k-group 0 of T + 1
+// The epilogue's 16 chunks run in the next tile's first phase X, those of a row block just before that block's first MFMAs.
+template <int VAR>
+__global__ __launch_bounds__(512) void k_w8(Args a)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int w = blockIdx.x, G = gridDim.x;
+    const int xcd = w & 7, wl = w >> 3, wpx = G >> 3;
+    const int mx = (a.m_tiles - xcd + 7) >> 3;
+    const int PN = a.n_tiles < a.pnmax ? a.n_tiles : a.pnmax;
+    const int PM = wpx / PN > 0 ? wpx / PN : 1;
+    const int pm = wl / PN, pn = wl - pm * PN;
+    if (pm >= PM) return;
+    const int n_groups = (a.n_tiles + PN - 1) / PN, m_groups = (mx + PM - 1) / PM;
+    const int sb_end = n_groups * m_groups;
+    auto sb_valid = [&](int sb, int& j, int& nt) -> bool {
+        const int mg = sb / n_groups, ng = sb - mg * n_groups;
+        j = mg * PM + pm; nt = ng * PN + pn;
+        return j < mx && nt < a.n_tiles;
+    };
+    auto next_sb = [&](int sb) -> int {
+        int j, nt;
+        for (++sb; sb < sb_end; ++sb) if (sb_valid(sb, j, nt)) return sb;
+        return sb_end;
+    };
+    const int q0 = next_sb(-1);
+    if (q0 >= sb_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = wid >> 2, wc = wid & 3;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int S = a.K / 64;
+    const unsigned lds0 = (unsigned)(size_t)(lds_char*)lds;
+
+    unsigned voA[2], voB[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = wid * 16 + p * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((r >> 1) & 7);
+        voA[p] = (unsigned)r * (unsigned)a.K * 2u + (unsigned)ch * 16u;
+        const int rho = r & 15;
+        const int col = 32 * (wid >> 1) + 8 * (rho >> 2) + 4 * (wid & 1) + (rho & 3);
+        voB[p] = (unsigned)col * (unsigned)a.K * 2u + (unsigned)ch * 16u;
+    }
+    const unsigned dstw = __builtin_amdgcn_readfirstlane((unsigned)(wid * 2048));
+    struct Cur { int sb; int t; int m0, n0; };
+    auto cur_set = [&](Cur& c) { int j, nt; (void)sb_valid(c.sb, j, nt); c.m0 = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * 256); c.n0 = __builtin_amdgcn_readfirstlane(nt * 256); };
+    auto cur_adv = [&](Cur& c) {
+        if (++c.t < S) return;
+        c.t = 0;
+        const int nq = next_sb(c.sb);
+        if (nq < sb_end) { c.sb = nq; cur_set(c); }
+    };
+    // piece q = 0 .. 3 of the wave's share of A (B): half q >> 1, piece q & 1
+    auto dmaA = [&](const Cur& c, int buf, int q) {
+        const int h = q >> 1;
+        const v4i rs = make_rsrc((const char*)a.X + ((size_t)(c.m0 + 128 * h) * a.K + (size_t)c.t * 64) * 2);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * BUF_BYTES + h * HALF_BYTES + (q & 1) * 1024) + dstw);
+        lds_dma_b128(rs, dst, voA[q & 1], 0);
+    };
+    auto dmaB = [&](const Cur& c, int buf, int q) {
+        const int h = q >> 1;
+        const v4i rs = make_rsrc((const char*)a.W + ((size_t)(c.n0 + 128 * h) * a.K + (size_t)c.t * 64) * 2);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * BUF_BYTES + (2 + h) * HALF_BYTES + (q & 1) * 1024) + dstw);
+        lds_dma_b128(rs, dst, voB[q & 1], 0);
+    };
+    const unsigned par0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(2 * BUF_BYTES + wid * 2048));
+    const unsigned voP = (unsigned)(128 * ((lane & 15) >> 3) + 32 * wc + 4 * (lane & 7)) * 4u;
+    auto stageP = [&](int n0, int par) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(par0 + (unsigned)(par * 1024));
+        const v4i r0 = make_rsrc((const char*)(a.P + n0)), r1 = make_rsrc((const char*)(a.P + (size_t)a.N + n0)), r2 = make_rsrc((const char*)(a.P + (size_t)2 * a.N + n0));
+        if (lane < 16) { lds_dma_b128(r0, dst, voP, 0); lds_dma_b128(r1, dst + 256, voP, 0); lds_dma_b128(r2, dst + 512, voP, 0); }
+    };
+
+    const int sw = (l15 >> 1) & 7;
+    const int c0 = (l4 ^ sw) * 16, c1 = ((4 + l4) ^ sw) * 16;
+    const char* const Afr = lds + (64 * g + l15) * 128;                      // + mh * HALF_BYTES + i * 2048 + c{ks}
+    const char* const Bfr = lds + 2 * HALF_BYTES + (32 * wc + l15) * 128;    // + nh * HALF_BYTES + j * 2048 + c{ks}
+    float4 fa[2][8], fb[2][4];          // [ks][row block R = 4 mh + i], [ks][column block C = 2 nh + j]
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto rdA = [&](int buf, int ks, int R) { fa[ks][R] = *(const float4*)(Afr + buf * BUF_BYTES + (R >> 2) * HALF_BYTES + (R & 3) * 2048 + (ks ? c1 : c0)); };
+    auto rdB = [&](int buf, int ks, int C) { fb[ks][C] = *(const float4*)(Bfr + buf * BUF_BYTES + (C >> 1) * HALF_BYTES + (C & 1) * 2048 + (ks ? c1 : c0)); };
+    auto rd_set = [&](int buf, int ks, int part) {         // the 12 reads of a k-group in four parts of three
+        if (part == 0) { rdB(buf, ks, 0); rdB(buf, ks, 1); rdB(buf, ks, 2); }
+        else if (part == 1) { rdB(buf, ks, 3); rdA(buf, ks, 0); rdA(buf, ks, 1); }
+        else if (part == 2) { rdA(buf, ks, 2); rdA(buf, ks, 3); rdA(buf, ks, 4); }
+        else { rdA(buf, ks, 5); rdA(buf, ks, 6); rdA(buf, ks, 7); }
+    };
+    auto mma_sg = [&](int ks, int s) {                     // sub-group s: row blocks 2 s, 2 s + 1
+#pragma unroll
+        for (int C = 0; C < 4; ++C)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+                acc[2 * s + rr][C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fb[ks][C]), __builtin_bit_cast(half8, fa[ks][2 * s + rr]), acc[2 * s + rr][C], 0, 0, 0);
+    };
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const unsigned nrow16 = __builtin_amdgcn_readfirstlane((unsigned)a.N * 2u * 16u);
+    const unsigned voY = (unsigned)(64 * g + l15) * (unsigned)a.N * 2u + (unsigned)(32 * wc + 8 * l4) * 2u;
+    // chunk of row block R, column pair nh: rows 128 (R >> 2) + 64 g + 16 (R & 3) + l15, columns 128 nh + 32 wc + 8 l4 .. + 7
+    auto chunk = [&](int R, int nh, int par, __amdgpu_buffer_rsrc_t rY) {
+        const float* const pw = (const float*)(lds + 2 * BUF_BYTES + wid * 2048 + par * 1024) + (nh * 8 + 2 * l4) * 4;
+        half8 hv;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            asm volatile("" ::: "memory");
+            const float4 b = *(const float4*)(pw + 4 * hf), sc = *(const float4*)(pw + 64 + 4 * hf), sh = *(const float4*)(pw + 128 + 4 * hf);
+            const float bb[4] = {b.x, b.y, b.z, b.w}, ss[4] = {sc.x, sc.y, sc.z, sc.w}, hh[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[R][2 * nh + hf][e] + bb[e];
+                acc[R][2 * nh + hf][e] = 0.0f;
+                v = fmaxf(v, 0.0f);
+                hv[4 * hf + e] = (_Float16)(v * ss[e] + hh[e]);
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, hv), rY, voY, (unsigned)(8 * (R >> 2) + (R & 3)) * nrow16 + 256u * nh, 0);
+    };
+    auto make_rY = [&](int m0, int n0) { return __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (size_t)m0 * a.N + n0), 0, 0x7fffffff, 0x00020000); };
+#define W8_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+    Cur cc; cc.sb = q0; cc.t = 0; cur_set(cc);
+    Cur c1_ = cc, c2_ = cc;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) { dmaA(cc, 0, qq); dmaB(cc, 0, qq); }
+    cur_adv(c1_); c2_ = c1_;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) dmaA(c1_, 1, qq);
+    cur_adv(c2_);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int part = 0; part < 4; ++part) rd_set(0, 0, part);
+
+    int q = q0, t = 0, buf = 0, par = 0;
+    bool have_prev = false;
+    __amdgpu_buffer_rsrc_t rYc = make_rY(cc.m0, cc.n0), rYp = rYc;
+    int n0c = cc.n0;
+    unsigned long long t_start = 0;
+    if (a.clk) t_start = __builtin_amdgcn_s_memtime();
+    while (true) {
+        const bool carry = t == 0 && have_prev;
+        // ---- phase X
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W8_FENCE();
+        if (carry) {
+            // the first K-tile of a tile: the previous tile's 16 chunks in a block of their own (in one block with the MFMAs hipcc spills 217 registers)
+#pragma unroll
+            for (int R = 0; R < 8; ++R) { chunk(R, 0, par ^ 1, rYp); chunk(R, 1, par ^ 1, rYp); }
+        }
+        W8_FENCE();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            rd_set(buf, 1, s);
+            mma_sg(0, s);
+            W8_FENCE();
+            dmaB(c1_, buf ^ 1, s);
+            W8_FENCE();
+        }
+        cur_adv(c1_);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W8_FENCE(); __builtin_amdgcn_s_barrier(); W8_FENCE();
+        // ---- phase Y
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s == 3) {
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                W8_FENCE(); __builtin_amdgcn_s_barrier(); W8_FENCE();
+                if (t == 0) stageP(n0c, par);
+                rd_set(buf ^ 1, 0, 0); rd_set(buf ^ 1, 0, 1); rd_set(buf ^ 1, 0, 2); rd_set(buf ^ 1, 0, 3);
+            }
+            mma_sg(1, s);
+            W8_FENCE();
+            dmaA(c2_, buf, s);
+            W8_FENCE();
+        }
+        cur_adv(c2_);
+        buf ^= 1;
+        if (t == S - 1) {
+            q = next_sb(q);
+            rYp = rYc; have_prev = true; par ^= 1;
+            if (q >= sb_end) break;
+            { int j_, nt_; (void)sb_valid(q, j_, nt_); n0c = __builtin_amdgcn_readfirstlane(nt_ * 256); rYc = make_rY(__builtin_amdgcn_readfirstlane((xcd + 8 * j_) * 256), n0c); }
+            t = 0;
+        } else ++t;
+    }
+#pragma unroll
+    for (int R = 0; R < 8; ++R) { chunk(R, 0, par ^ 1, rYp); chunk(R, 1, par ^ 1, rYp); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.clk && tid == 0) a.clk[blockIdx.x] = __builtin_amdgcn_s_memtime() - t_start;
+}
+
 // ---- reference: selected rows, f32 accumulation in k order (any order is within the check's tolerance)
 __global__ void k_ref_rows(const _Float16* X, const _Float16* W, const int* rows, float* out, int N, int K, const float* P)
 {
@@ -970,7 +1171,7 @@ int main(int argc, char** argv)
     auto threads_of = [&](const V& v) { return strncmp(v.name, "W4", 2) == 0 ? 256 : 512; };          // check: 0 none, 1 plain product, 2 with the k_pp2 epilogue
     const V vars[] = {{"PP2 nv6", k_pp2<6, 0>, 2, 4}, {"PP2 dma first", k_pp2<6, 32>, 2, 4}, {"PP2 dma split", k_pp2<6, 64>, 2, 4}, 
                       {"PP3 nv6", k_pp3<6, 0>, 2, 4}, {"DMA only", k_pp<4 | 16>, 0, 4}, {"reg loads only", k_pp<4 | 16 | 128>, 0, 4},
-                      {"W4", k_w4<0>, 1, 4}};
+                      {"W4", k_w4<0>, 1, 4}, {"W8", k_w8<0>, 2, 4}, {"W8 pn8", k_w8<0>, 2, 8}};
     const int vmask = argc > 2 ? (int)strtol(argv[2], nullptr, 0) : 0x7fffffff;
     const int rounds = argc > 3 ? atoi(argv[3]) : 3;
     const size_t lds_bytes = 2 * BUF_BYTES + 8 * 2048;
