@@ -122,7 +122,7 @@ extern "C" int sd_set_option(sd_ctx* c, const char* key, int64_t v)
     else if (k == "conv_glds") c->conv_glds = v != 0;
     else if (k == "conv_pp") c->conv_pp = v != 0;
     else if (k == "conv_glds_f32") c->conv_glds_f32 = v != 0;
-    else if (k == "conv_mfma16") { if (v < 0 || v > 1) return SD_ERR_ARG; c->conv_mfma16 = (int)v; }
+    else if (k == "conv_mfma16") { if (v < 0 || v > 2) return SD_ERR_ARG; c->conv_mfma16 = (int)v; }      // 2: k_conv_gemm_g256 takes the 16x16x32 form on short contractions too (the reference the round-6 kernel is compared with bit for bit)
     else if (k == "conv_rot") { if (v < 0 || v > 3) return SD_ERR_ARG; c->conv_rot = (int)v; }
     else if (k == "conv_stagger") { if (v < 0 || v > 2) return SD_ERR_ARG; c->conv_stagger = (int)v; }
     else if (k == "conv_w256_f32") c->conv_w256_f32 = v != 0;

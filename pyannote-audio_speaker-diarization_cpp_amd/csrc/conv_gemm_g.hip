@@ -617,7 +617,7 @@ int launch_conv_gemm_g256(sd_ctx* c, const ConvArgs& in, const char* tag)
         ProfScope ps16(c, h ? "conv_gemm_f16" : "conv_gemm_f32", flops, bytes);
         ProfScope psw(c, h ? "conv_w256_f16" : "conv_w256_f32", flops, bytes);         // this tile form alone (bench.py's roofline object)
         ProfScope pss(c, strcmp(tag, "lstm_ih") == 0 ? "conv_w256_seg" : "conv_w256_ecapa", flops, bytes);
-        if (h && c->conv_mfma16 && (int64_t)a.Cin * a.KT >= 1024) hipLaunchKernelGGL(k_conv_gemm_g256<2>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
+        if (h && c->conv_mfma16 && ((int64_t)a.Cin * a.KT >= 1024 || c->conv_mfma16 == 2)) hipLaunchKernelGGL(k_conv_gemm_g256<2>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
         else if (h) hipLaunchKernelGGL(k_conv_gemm_g256<1>         /* short contractions (block0, K = 640): 523 TF on this form against 486 */, dim3(grid), dim3(512), lds_bytes, c->stream, a);
         else hipLaunchKernelGGL(k_conv_gemm_g256<0>, dim3(grid), dim3(512), lds_bytes, c->stream, a);
     }

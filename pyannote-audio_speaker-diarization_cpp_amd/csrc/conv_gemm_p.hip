@@ -339,9 +339,9 @@ int launch_conv_gemm_pp(sd_ctx* c, const ConvArgs& in, const char* tag)
         a.Cout < 256 || (a.Cout % 256) != 0 || (a.y_ld & 7) || a.Cin % 64 != 0 || a.M < 8 * 256 || (a.x_ld & 7)) return 1;
     if (a.w_ld <= 0) a.w_ld = a.Cin;
     if ((a.w_ld & 7) || (int64_t)a.KT * (a.Cin / 64) < 2) return 1;
-    // contractions below 1 024 (block0: K = 640) stay with k_conv_gemm_g256<1>, as they do there (32x32x16 form): every layer this kernel takes is one that
-    // k_conv_gemm_g256<2> would take, with the same products in the same order -- the two are compared bit for bit (tests/test_gpu_parity.py)
-    if ((int64_t)a.Cin * a.KT < 1024 || !c->conv_mfma16) return 1;
+    // every layer this kernel takes gives the bits of k_conv_gemm_g256<2> (same products, same order) -- the two are compared bit for bit (tests/test_gpu_parity.py);
+    // block0 (K = 5 x 128 = 640, ten K-tiles per tile) is taken too since the load stream is continuous (k_conv_gemm_g256 ran it on its 32x32x16 form: 490 TF)
+    if ((int64_t)a.Cin * a.KT < 512 || !c->conv_mfma16) return 1;
     if (((size_t)a.X & 15) || ((size_t)a.W16 & 15) || ((size_t)a.Y & 15) || ((size_t)a.bias & 15) || ((size_t)a.scale & 15) || ((size_t)a.shift & 15) || ((size_t)a.rowtab & 15)) return 1;
     const unsigned dev_bit = 1u << (c->device & 31);
     if (!(g_attr_pp.load(std::memory_order_acquire) & dev_bit)) {

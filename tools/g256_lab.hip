@@ -1050,9 +1050,35 @@ __global__ __launch_bounds__(512) void k_w8(Args a)
         asm volatile("" ::: "memory");
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, hv), rY, voY, (unsigned)(8 * (R >> 2) + (R & 3)) * nrow16 + 256u * nh, 0);
     };
+    // VAR 1: the same epilogue with the 24 parameters of a column pair read ONCE for the wave's eight row blocks, no fences (the chunk form reads them per chunk,
+    // 96 ds_read_b128 per tile, and waits for them 32 times)
+    auto epilogue2 = [&](int par, __amdgpu_buffer_rsrc_t rY) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            const float* const pw = (const float*)(lds + 2 * BUF_BYTES + wid * 2048 + par * 1024) + (nh * 8 + 2 * l4) * 4;
+            const float4 b0 = *(const float4*)(pw), b1 = *(const float4*)(pw + 4), s0 = *(const float4*)(pw + 64), s1 = *(const float4*)(pw + 68), h0 = *(const float4*)(pw + 128), h1 = *(const float4*)(pw + 132);
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int R = 0; R < 8; ++R) {
+                half8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = acc[R][2 * nh + (e >> 2)][e & 3] + bb[e];
+                    acc[R][2 * nh + (e >> 2)][e & 3] = 0.0f;
+                    v = fmaxf(v, 0.0f);
+                    hv[e] = (_Float16)(v * ss[e] + hh[e]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, hv), rY, voY, (unsigned)(8 * (R >> 2) + (R & 3)) * nrow16 + 256u * nh, 0);
+            }
+        }
+    };
     auto make_rY = [&](int m0, int n0) { return __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (size_t)m0 * a.N + n0), 0, 0x7fffffff, 0x00020000); };
 #define W8_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+    if (VAR & 2) {        // the workgroups start in 16 phases a.skew cycles apart: their epilogues (128 KB of stores each) no longer fall together
+        const unsigned long long ts = __builtin_amdgcn_s_memtime(), wait = (unsigned long long)((wl * 5) % 16) * (unsigned long long)a.skew;
+        while (__builtin_amdgcn_s_memtime() - ts < wait) __builtin_amdgcn_s_sleep(32);
+    }
     Cur cc; cc.sb = q0; cc.t = 0; cur_set(cc);
     Cur c1_ = cc, c2_ = cc;
 #pragma unroll
@@ -1078,8 +1104,11 @@ __global__ __launch_bounds__(512) void k_w8(Args a)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W8_FENCE();
         if (carry) {
             // the first K-tile of a tile: the previous tile's 16 chunks in a block of their own (in one block with the MFMAs hipcc spills 217 registers)
+            if (VAR & 1) epilogue2(par ^ 1, rYp);
+            else {
 #pragma unroll
-            for (int R = 0; R < 8; ++R) { chunk(R, 0, par ^ 1, rYp); chunk(R, 1, par ^ 1, rYp); }
+                for (int R = 0; R < 8; ++R) { chunk(R, 0, par ^ 1, rYp); chunk(R, 1, par ^ 1, rYp); }
+            }
         }
         W8_FENCE();
 #pragma unroll
@@ -1117,8 +1146,11 @@ __global__ __launch_bounds__(512) void k_w8(Args a)
             t = 0;
         } else ++t;
     }
+    if (VAR & 1) epilogue2(par ^ 1, rYp);
+    else {
 #pragma unroll
-    for (int R = 0; R < 8; ++R) { chunk(R, 0, par ^ 1, rYp); chunk(R, 1, par ^ 1, rYp); }
+        for (int R = 0; R < 8; ++R) { chunk(R, 0, par ^ 1, rYp); chunk(R, 1, par ^ 1, rYp); }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.clk && tid == 0) a.clk[blockIdx.x] = __builtin_amdgcn_s_memtime() - t_start;
 }
@@ -1171,7 +1203,7 @@ int main(int argc, char** argv)
     auto threads_of = [&](const V& v) { return strncmp(v.name, "W4", 2) == 0 ? 256 : 512; };          // check: 0 none, 1 plain product, 2 with the k_pp2 epilogue
     const V vars[] = {{"PP2 nv6", k_pp2<6, 0>, 2, 4}, {"PP2 dma first", k_pp2<6, 32>, 2, 4}, {"PP2 dma split", k_pp2<6, 64>, 2, 4}, 
                       {"PP3 nv6", k_pp3<6, 0>, 2, 4}, {"DMA only", k_pp<4 | 16>, 0, 4}, {"reg loads only", k_pp<4 | 16 | 128>, 0, 4},
-                      {"W4", k_w4<0>, 1, 4}, {"W8", k_w8<0>, 2, 4}, {"W8 pn8", k_w8<0>, 2, 8}};
+                      {"W8", k_w8<0>, 2, 4}, {"W8 start skew 1400", k_w8<2>, 2, 4, 1, 1400}, {"W8 start skew 2800", k_w8<2>, 2, 4, 1, 2800}, {"W8 start skew 700", k_w8<2>, 2, 4, 1, 700}};
     const int vmask = argc > 2 ? (int)strtol(argv[2], nullptr, 0) : 0x7fffffff;
     const int rounds = argc > 3 ? atoi(argv[3]) : 3;
     const size_t lds_bytes = 2 * BUF_BYTES + 8 * 2048;
