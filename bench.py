@@ -742,9 +742,9 @@ def main():
                     "roofline": rl, "cosine_distance_to_f32_embeddings": cosd}
 
         if a.precision == "f32" and a.fp16_steps > 0:
-            extra_lines["fp16"] = secondary_mode(1, a.fp16_steps, "conv_w256_f16", "conv_gemm_f16", "k_conv_gemm_g256 (v_mfma_f32_16x16x32_f16, LDS-DMA staged; bound by the CU's L2 -> LDS ingest; `peak` is 2.4 GHz x the pipe's per-clock rate, "
-                                                 "a bare MFMA loop of this shape holds 2.07 PFLOP/s on random data (1.75 on the 32x32x16 shape) and the vendor library's GEMM 1.1 - 1.4 at these shapes: "
-                                                 "profiles/r04_g256_ablation.txt, r04_g256_request_order.txt)",
+            extra_lines["fp16"] = secondary_mode(1, a.fp16_steps, "conv_w256_f16", "conv_gemm_f16", "k_conv_gemm_pp (conv_gemm_p.hip, round 6: v_mfma_f32_16x16x32_f16, LDS-DMA staged, every wave interleaves its reads and DMAs with its MFMAs, the queue is never drained; "
+                                                 "bound by what a CU takes in -- 24 - 27 B per clock = 2 400 - 2 700 cycles per 64 KB K-tile against 2 048 of MFMA, profiles/r06_g256_lab.txt; `peak` is 2.4 GHz x the pipe's "
+                                                 "per-clock rate, the chip holds ~ 1.75 GHz under this load; the vendor library's GEMM reaches 1.09 / 1.36 PFLOP/s at the tdnn / MFA shapes on the same box)",
                                                  "BASELINE configs[4]: the same job with the per-frame ECAPA layers on the fp16 MFMA (fp16 weights and activations, f32 accumulation); "
                                                  "secondary mode, never the headline value", 1)
         if a.precision == "f32" and a.fp16_steps > 0 and planted and "fp16" in extra_lines and a.hours_per_gpu <= 2.0:        # (a second context: beside an 8-h job's 80 GB distance matrix the two activation arenas run the GPU out of memory)
@@ -866,7 +866,7 @@ def main():
                          "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_conv_gemm_w256<0> (v_mfma_f32_32x32x2_f32, 256 x 256 tile): every ECAPA layer with Cout >= 256 + PyanNet's LSTM input projections" if a.precision == "f32" else
                                    "k_conv_gemm_w256<3> (v_mfma_f32_32x32x16_f16 on split operands; `achieved` = executed MFMA work = 3 x the algorithmic FLOPs): the wide ECAPA layers" if a.precision == "x3" else
-                                   "k_conv_gemm_g256 (v_mfma_f32_16x16x32_f16, fp16 activations, LDS-DMA staged): the wide ECAPA layers",
+                                   "k_conv_gemm_pp (v_mfma_f32_16x16x32_f16, fp16 activations, LDS-DMA staged, never drained): the wide ECAPA layers",
                          "all_mfma_conv_launches": {"what": "k_conv_gemm_w256 + k_conv_gemm (128 x 128 tile: Res2Net, ASP tdnn%s) %s" %
                                                             ((", PyanNet) + k_conv_narrow (SincNet", "of the step") if a.precision == "f32" else ("", "in fp16")),
                                                     "achieved": round(cg_all["flops"] / max(cg_all["ms"], 1e-9) / 1e9, 2),

@@ -64,6 +64,8 @@ __device__ __forceinline__ v4i pp_rsrc(const void* base, size_t bytes)
     return r;
 }
 
+// RELU: act1 == 1 known at compile time (every layer this kernel takes in ECAPA): max(v, 0) instead of max(v, v * slope), 8 VALU instructions fewer per chunk
+template <bool RELU>
 __global__ __launch_bounds__(512) void k_conv_gemm_pp(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -235,8 +237,8 @@ __global__ __launch_bounds__(512) void k_conv_gemm_pp(ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = acc[R][2 * nh + hf][e] + bb[e];
-                acc[R][2 * nh + hf][e] = 0.0f;
-                v = fmaxf(v, v * slope);
+                acc[R][2 * nh + hf][e] = 0.0f;      // (a first MFMA on C = 0 instead would save these 128 moves per tile -- hipcc then spills 363 registers)
+                v = RELU ? fmaxf(v, 0.0f) : fmaxf(v, v * slope);      // (the same value as max(v, v * 0) for every finite v; -inf and NaN, which the other kernels pass through, become 0 / stay NaN)
                 hv[4 * hf + e] = (_Float16)(v * ss[e] + hh[e]);
             }
         }
@@ -345,7 +347,8 @@ int launch_conv_gemm_pp(sd_ctx* c, const ConvArgs& in, const char* tag)
     if (((size_t)a.X & 15) || ((size_t)a.W16 & 15) || ((size_t)a.Y & 15) || ((size_t)a.bias & 15) || ((size_t)a.scale & 15) || ((size_t)a.shift & 15) || ((size_t)a.rowtab & 15)) return 1;
     const unsigned dev_bit = 1u << (c->device & 31);
     if (!(g_attr_pp.load(std::memory_order_acquire) & dev_bit)) {
-        if (hipFuncSetAttribute((const void*)k_conv_gemm_pp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        if (hipFuncSetAttribute((const void*)k_conv_gemm_pp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_gemm_pp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS) != hipSuccess) { (void)hipGetLastError(); return 1; }
         g_attr_pp.fetch_or(dev_bit, std::memory_order_release);
     }
     a.m_tiles = (a.M + 255) / 256;
@@ -363,7 +366,8 @@ int launch_conv_gemm_pp(sd_ctx* c, const ConvArgs& in, const char* tag)
         ProfScope ps16(c, "conv_gemm_f16", flops, bytes);
         ProfScope psw(c, "conv_w256_f16", flops, bytes);
         ProfScope pss(c, "conv_w256_ecapa", flops, bytes);
-        hipLaunchKernelGGL(k_conv_gemm_pp, dim3(grid), dim3(512), P_LDS, c->stream, a);
+        if (a.act1 == 1) hipLaunchKernelGGL(k_conv_gemm_pp<true>, dim3(grid), dim3(512), P_LDS, c->stream, a);
+        else hipLaunchKernelGGL(k_conv_gemm_pp<false>, dim3(grid), dim3(512), P_LDS, c->stream, a);
     }
     if (hipGetLastError() != hipSuccess) SD_FAIL(c, SD_ERR_HIP, "k_conv_gemm_pp launch failed (%s)", tag);
     return SD_OK;

@@ -1048,6 +1048,7 @@ __global__ __launch_bounds__(512) void k_w8(Args a)
             }
         }
         asm volatile("" ::: "memory");
+        if (VAR & 4) { asm volatile("" :: "v"(hv)); return; }      // diagnostic: the epilogue without its stores
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, hv), rY, voY, (unsigned)(8 * (R >> 2) + (R & 3)) * nrow16 + 256u * nh, 0);
     };
     // VAR 1: the same epilogue with the 24 parameters of a column pair read ONCE for the wave's eight row blocks, no fences (the chunk form reads them per chunk,
@@ -1203,7 +1204,7 @@ int main(int argc, char** argv)
     auto threads_of = [&](const V& v) { return strncmp(v.name, "W4", 2) == 0 ? 256 : 512; };          // check: 0 none, 1 plain product, 2 with the k_pp2 epilogue
     const V vars[] = {{"PP2 nv6", k_pp2<6, 0>, 2, 4}, {"PP2 dma first", k_pp2<6, 32>, 2, 4}, {"PP2 dma split", k_pp2<6, 64>, 2, 4}, 
                       {"PP3 nv6", k_pp3<6, 0>, 2, 4}, {"DMA only", k_pp<4 | 16>, 0, 4}, {"reg loads only", k_pp<4 | 16 | 128>, 0, 4},
-                      {"W8", k_w8<0>, 2, 4}, {"W8 start skew 1400", k_w8<2>, 2, 4, 1, 1400}, {"W8 start skew 2800", k_w8<2>, 2, 4, 1, 2800}, {"W8 start skew 700", k_w8<2>, 2, 4, 1, 700}};
+                      {"W8", k_w8<0>, 2, 4}, {"W8 no stores", k_w8<4>, 0, 4}};
     const int vmask = argc > 2 ? (int)strtol(argv[2], nullptr, 0) : 0x7fffffff;
     const int rounds = argc > 3 ? atoi(argv[3]) : 3;
     const size_t lds_bytes = 2 * BUF_BYTES + 8 * 2048;
