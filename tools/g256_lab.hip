@@ -1051,6 +1051,24 @@ __global__ __launch_bounds__(512) void k_w8(Args a)
         if (VAR & 4) { asm volatile("" :: "v"(hv)); return; }      // diagnostic: the epilogue without its stores
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, hv), rY, voY, (unsigned)(8 * (R >> 2) + (R & 3)) * nrow16 + 256u * nh, 0);
     };
+    // VAR 16: chunk with whole-tuple reads and zeroing (can it share a basic block with MFMAs?)
+    auto chunk3 = [&](int R, int nh, int par, __amdgpu_buffer_rsrc_t rY) {
+        const float* const pw = (const float*)(lds + 2 * BUF_BYTES + wid * 2048 + par * 1024) + (nh * 8 + 2 * l4) * 4;
+        const f32x4 x0 = acc[R][2 * nh], x1 = acc[R][2 * nh + 1];
+        {   // zeros the compiler cannot fold into the next MFMA's C operand (an MFMA on an inline-constant C is not tied to its accumulator registers any more: 217 spills)
+            f32x4 z0, z1;
+            asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0[0]), "=v"(z0[1]), "=v"(z0[2]), "=v"(z0[3]));
+            asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z1[0]), "=v"(z1[1]), "=v"(z1[2]), "=v"(z1[3]));
+            acc[R][2 * nh] = z0; acc[R][2 * nh + 1] = z1;
+        }
+        const float4 b0 = *(const float4*)(pw), b1 = *(const float4*)(pw + 4), s0 = *(const float4*)(pw + 64), s1 = *(const float4*)(pw + 68), h0 = *(const float4*)(pw + 128), h1 = *(const float4*)(pw + 132);
+        half8 hv;
+        hv[0] = (_Float16)(fmaxf(x0[0] + b0.x, 0.f) * s0.x + h0.x); hv[1] = (_Float16)(fmaxf(x0[1] + b0.y, 0.f) * s0.y + h0.y);
+        hv[2] = (_Float16)(fmaxf(x0[2] + b0.z, 0.f) * s0.z + h0.z); hv[3] = (_Float16)(fmaxf(x0[3] + b0.w, 0.f) * s0.w + h0.w);
+        hv[4] = (_Float16)(fmaxf(x1[0] + b1.x, 0.f) * s1.x + h1.x); hv[5] = (_Float16)(fmaxf(x1[1] + b1.y, 0.f) * s1.y + h1.y);
+        hv[6] = (_Float16)(fmaxf(x1[2] + b1.z, 0.f) * s1.z + h1.z); hv[7] = (_Float16)(fmaxf(x1[3] + b1.w, 0.f) * s1.w + h1.w);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, hv), rY, voY, (unsigned)(8 * (R >> 2) + (R & 3)) * nrow16 + 256u * nh, 0);
+    };
     // VAR 1: the same epilogue with the 24 parameters of a column pair read ONCE for the wave's eight row blocks, no fences (the chunk form reads them per chunk,
     // 96 ds_read_b128 per tile, and waits for them 32 times)
     auto epilogue2 = [&](int par, __amdgpu_buffer_rsrc_t rY) {
@@ -1103,6 +1121,33 @@ __global__ __launch_bounds__(512) void k_w8(Args a)
         const bool carry = t == 0 && have_prev;
         // ---- phase X
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W8_FENCE();
+        if (VAR & 32) {
+            // ONE copy of phase X; the chunks of a sub-group's row blocks under a branch of their own in front of it
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (carry) { chunk(2 * s, 0, par ^ 1, rYp); chunk(2 * s, 1, par ^ 1, rYp); chunk(2 * s + 1, 0, par ^ 1, rYp); chunk(2 * s + 1, 1, par ^ 1, rYp); }
+                W8_FENCE();
+                rd_set(buf, 1, s);
+                mma_sg(0, s);
+                W8_FENCE();
+                dmaB(c1_, buf ^ 1, s);
+                W8_FENCE();
+            }
+            goto phase_x_done;
+        }
+        if (carry && (VAR & 16)) {
+            // chunks of a row block in ONE block with the MFMAs, just in front of that block's first products (whole-tuple form)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                chunk3(2 * s, 0, par ^ 1, rYp); chunk3(2 * s, 1, par ^ 1, rYp); chunk3(2 * s + 1, 0, par ^ 1, rYp); chunk3(2 * s + 1, 1, par ^ 1, rYp);
+                rd_set(buf, 1, s);
+                mma_sg(0, s);
+                W8_FENCE();
+                dmaB(c1_, buf ^ 1, s);
+                W8_FENCE();
+            }
+            goto phase_x_done;
+        }
         if (carry) {
             // the first K-tile of a tile: the previous tile's 16 chunks in a block of their own (in one block with the MFMAs hipcc spills 217 registers)
             if (VAR & 1) epilogue2(par ^ 1, rYp);
@@ -1120,6 +1165,7 @@ __global__ __launch_bounds__(512) void k_w8(Args a)
             dmaB(c1_, buf ^ 1, s);
             W8_FENCE();
         }
+    phase_x_done:
         cur_adv(c1_);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W8_FENCE(); __builtin_amdgcn_s_barrier(); W8_FENCE();
@@ -1204,7 +1250,7 @@ int main(int argc, char** argv)
     auto threads_of = [&](const V& v) { return strncmp(v.name, "W4", 2) == 0 ? 256 : 512; };          // check: 0 none, 1 plain product, 2 with the k_pp2 epilogue
     const V vars[] = {{"PP2 nv6", k_pp2<6, 0>, 2, 4}, {"PP2 dma first", k_pp2<6, 32>, 2, 4}, {"PP2 dma split", k_pp2<6, 64>, 2, 4}, 
                       {"PP3 nv6", k_pp3<6, 0>, 2, 4}, {"DMA only", k_pp<4 | 16>, 0, 4}, {"reg loads only", k_pp<4 | 16 | 128>, 0, 4},
-                      {"W8", k_w8<0>, 2, 4}, {"W8 no stores", k_w8<4>, 0, 4}};
+                      {"W8", k_w8<0>, 2, 4}, {"W8 no stores", k_w8<4>, 0, 4}, {"W8 chunks split", k_w8<32>, 2, 4}};
     const int vmask = argc > 2 ? (int)strtol(argv[2], nullptr, 0) : 0x7fffffff;
     const int rounds = argc > 3 ? atoi(argv[3]) : 3;
     const size_t lds_bytes = 2 * BUF_BYTES + 8 * 2048;
