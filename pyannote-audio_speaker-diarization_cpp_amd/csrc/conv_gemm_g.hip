@@ -48,11 +48,11 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // kernel exists for.  The waits that order these DMAs against the fragment reads are the explicit ones at the barrier (see the loop).
 __device__ __forceinline__ void lds_dma_b32(v4i rs, unsigned ldsaddr, unsigned vo)       // 64 x 4 bytes -> 256 bytes of LDS
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(ldsaddr), "v"(vo), "s"(rs) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(ldsaddr), "v"(vo), "s"(rs) : "memory");
 }
 __device__ __forceinline__ void lds_dma_b128(v4i rs, unsigned ldsaddr, unsigned vo, unsigned so)
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(ldsaddr), "v"(vo), "s"(rs), "s"(so) : "memory");      // (m0 is reserved: the compiler does not keep values in it across statements)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(ldsaddr), "v"(vo), "s"(rs), "s"(so) : "memory");      // (m0 is reserved: the compiler does not keep values in it across statements)
 }
 
 // P = 1: fp16 tensors (v_mfma_f32_32x32x16_f16, a K-step is 64 halves).  P = 0: f32 tensors (v_mfma_f32_32x32x2_f32 over the k pairs (k, k + 16)

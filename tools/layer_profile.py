@@ -29,7 +29,7 @@ d.diarize_dev(d_pcm.data_ptr(), n)
 d.set_option("profile", 2); d.reset_stats()
 d.diarize_dev(d_pcm.data_ptr(), n)
 names = ["chunk_norm", "pool_norm", "lstm_rec", "classifier", "stft_mel", "fbank_norm", "masked_mean", "se_mean", "se_apply", "copy_slice", "asp_stats", "asp_pool", "pdist", "linkage", "linkage_heap", "row_nn",
-         "cluster_means", "assign", "mask_prefix", "wav_lens", "compact_active", "scatter_emb", "binarize_masks", "count", "activations", "topk"]
+         "cluster_means", "assign", "mask_prefix", "wav_lens", "compact_active", "scatter_emb", "binarize_masks", "count", "activations", "topk", "conv_w256_x3", "conv_w256_f16", "x3_overflow_fallbacks"]
 tags = ["sinc0", "sinc1", "sinc2", "lstm_ih", "lin0", "lin1", "block0", "tdnn1", "tdnn2", "res2net", "se1", "se2", "mfa", "asp_tdnn", "asp_tdnn_ms", "asp_conv", "fc", "asp_ms"]
 tot = 0
 print("workload %s, skip_dead_rows %d, precision %s" % (workload, skip, prec))
