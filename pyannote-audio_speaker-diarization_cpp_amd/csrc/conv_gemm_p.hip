@@ -475,7 +475,7 @@ __global__ __launch_bounds__(512) void k_conv_gemm_px(ConvArgs a)
     const int c0 = ((2 * l4) ^ sw) * 16, c1 = ((2 * l4 + 1) ^ sw) * 16;
     const char* const Afr = lds + (64 * g + l15) * 128;                  // + mh * P_HALF + i * 2048 + c0 / c1
     const char* const Bfr = lds + 2 * P_HALF + (32 * wc + l15) * 128;    // + nh * P_HALF + j * 2048 + c0 (hi) / c1 (lo)
-    f32x4 fa[2][4][2];                  // [row half][row block i][raw: channels 0-3, 4-7 of the lane's eight | split: hi, lo]
+    f32x4 fa[2][4][2];                  // [row half][row block i][hi, lo]
     f32x4 fb[4][2];                     // [column block C = 2 nh + j][hi, lo]
     f32x4 acc[8][4];
 #pragma unroll
@@ -486,12 +486,30 @@ __global__ __launch_bounds__(512) void k_conv_gemm_px(ConvArgs a)
         fa[mh][i][0] = *(const f32x4*)(Afr + buf * P_BUF + mh * P_HALF + i * 2048 + c0);
         fa[mh][i][1] = *(const f32x4*)(Afr + buf * P_BUF + mh * P_HALF + i * 2048 + c1);
     };
-    auto splitA = [&](int mh, int i) {          // eight f32 -> [8 hi halves | 8 lo halves], in place
+    // The split of A, once per workgroup: every wave splits the rows IT staged (its own vmcnt is enough, no barrier), in place -- the eight f32 of a
+    // chunk pair become [8 hi halves | 8 lo halves] in the same 32 bytes, so the fragment reads above find hi in the first chunk's place and lo in the
+    // second's.  Round j = the wave's 16 rows of row half j: lane -> row (lane >> 2), chunk pair (lane & 3); 16 lanes = 4 rows x 4 pairs, rows r and r + 2
+    // on the same banks hold their pairs at swapped chunk positions: conflict-free.  (Before: every wave split its own fragments, each row four times.)
+    const int sr = wid * 16 + (lane >> 2), ssw = (sr >> 1) & 5, sk = lane & 3;
+    char* const Spl = lds + sr * 128;
+    const int sc0 = ((2 * sk) ^ ssw) * 16, sc1 = ((2 * sk + 1) ^ ssw) * 16;
+    f32x4 sraw[2][2];                   // [round j][first, second chunk of the pair]: read a phase ahead of the arithmetic
+    auto coop_read = [&](int buf) {
         if (SD_PX_ABLATE & 1) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char* const q = Spl + buf * P_BUF + j * P_HALF;
+            sraw[j][0] = *(const f32x4*)(q + sc0); sraw[j][1] = *(const f32x4*)(q + sc1);
+        }
+    };
+    auto coop_write = [&](int buf, int j) {
+        if (SD_PX_ABLATE & 1) return;
+        char* const q = Spl + buf * P_BUF + j * P_HALF;
         half8 hi, lo;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = fa[mh][i][e >> 2][e & 3]; hi[e] = (_Float16)f; lo[e] = (_Float16)(f - (float)hi[e]); }
-        fa[mh][i][0] = __builtin_bit_cast(f32x4, hi); fa[mh][i][1] = __builtin_bit_cast(f32x4, lo);
+        for (int e = 0; e < 8; ++e) { const float f = sraw[j][e >> 2][e & 3]; hi[e] = (_Float16)f; lo[e] = (_Float16)(f - (float)hi[e]); }
+        *(f32x4*)(q + sc0) = __builtin_bit_cast(f32x4, hi);
+        *(f32x4*)(q + sc1) = __builtin_bit_cast(f32x4, lo);
     };
     auto rdB = [&](int buf, int C) {
         fb[C][0] = *(const f32x4*)(Bfr + buf * P_BUF + (C >> 1) * P_HALF + (C & 1) * 2048 + c0);
@@ -546,67 +564,64 @@ __global__ __launch_bounds__(512) void k_conv_gemm_px(ConvArgs a)
     { const int nq = next_sb(q0); if (nq < sb_end) { int m1, n1; tile_of(nq, m1, n1); table_dma(m1, 1); } }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     cur_rows(cA); cur_tap(cA);
-    Cur cB = cA;
     const int m0_first = cA.m0, n0_first = cA.n0;
     auto lead_adv = [&]() {
         if (cur_adv(cA, true)) { const int nq = next_sb(cA.sb); if (nq < sb_end) { int m1, n1; tile_of(nq, m1, n1); table_dma(m1, (cA.tiles + 1) & 1); } }
     };
+    // one cursor: the A AND the B pieces of K-tile T + 2 are requested in phase Y of K-tile T (both buffer halves of T are free once the barrier behind
+    // phase X is passed: the weight fragments of T have been in registers since phase Y of T - 1), a phase and a quarter before their barrier
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { dmaA(cA, 0, q); dmaB(cB, 0, q); }
+    for (int q = 0; q < 4; ++q) { dmaA(cA, 0, q); dmaB(cA, 0, q); }
     lead_adv();
-    (void)cur_adv(cB, false);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dmaA(cA, 1, q);
+    for (int q = 0; q < 4; ++q) { dmaA(cA, 1, q); dmaB(cA, 1, q); }
     lead_adv();
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    coop_read(0); coop_write(0, 0); coop_write(0, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int C = 0; C < 4; ++C) rdB(0, C);
 #pragma unroll
     for (int i = 0; i < 4; ++i) rdA(0, 0, i);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) splitA(0, i);
 
     int q = q0, t = 0, buf = 0, par = 0;
     bool have_prev = false;
     __amdgpu_buffer_rsrc_t rYc = make_rY(m0_first, n0_first), rYp = rYc;
     int n0c = n0_first;
     while (true) {
-        // ---- phase X: row blocks 0-3
+        // ---- phase X: row blocks 0-3 | the fragments of row blocks 4-7 | behind column 2: the wave reads its rows of A(T + 1) for the split (its own
+        //      pieces, requested a phase ago: vmcnt(1) leaves the last weight piece in flight)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PP_FENCE();
         if (t == 0 && have_prev) epilogue(par ^ 1, rYp);
         PP_FENCE();
 #pragma unroll
         for (int C = 0; C < 4; ++C) {
-            if (!(SD_PX_ABLATE & 4)) rdA(buf, 1, C);                          // the raw fragments of row block 4 + C
-            if (C >= 2) { splitA(1, 2 * (C - 2)); splitA(1, 2 * (C - 2) + 1); }      // blocks 0, 1 behind column 2's MFMAs, 2, 3 behind column 3's
+            if (!(SD_PX_ABLATE & 4)) rdA(buf, 1, C);
+            if (C == 3) { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); coop_read(buf ^ 1); }
             mma_col(0, C);
             PP_FENCE();
-            if (!(SD_PX_ABLATE & 2)) dmaB(cB, buf ^ 1, C);
-            PP_FENCE();
         }
-        (void)cur_adv(cB, false);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PP_BARRIER();
-        // ---- phase Y: row blocks 4-7
+        // ---- phase Y: row blocks 4-7 | columns 0, 1: the split of A(T + 1), written back in place | the 8 pieces of T + 2 | behind column 1: vmcnt(4) +
+        //      barrier, then the next K-tile's fragments
 #pragma unroll
         for (int C = 0; C < 4; ++C) {
+            if (C < 2) coop_write(buf ^ 1, C);
             if (C == 2) {
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
                 PP_BARRIER();
                 if (t == 0) stageP(n0c, par);
                 if (!(SD_PX_ABLATE & 4)) { rdB(buf ^ 1, 0); rdB(buf ^ 1, 1); rdA(buf ^ 1, 0, 0); rdA(buf ^ 1, 0, 1); }
             }
-            if (C == 3) { if (!(SD_PX_ABLATE & 4)) { rdB(buf ^ 1, 2); rdA(buf ^ 1, 0, 2); rdA(buf ^ 1, 0, 3); } splitA(0, 0); splitA(0, 1); }
+            if (C == 3 && !(SD_PX_ABLATE & 4)) { rdB(buf ^ 1, 2); rdA(buf ^ 1, 0, 2); rdA(buf ^ 1, 0, 3); }
             mma_col(1, C);
             PP_FENCE();
-            if (!(SD_PX_ABLATE & 2)) dmaA(cA, buf, C);
+            if (!(SD_PX_ABLATE & 2)) { dmaA(cA, buf, C); dmaB(cA, buf, C); }
             PP_FENCE();
         }
         if (!(SD_PX_ABLATE & 4)) rdB(buf ^ 1, 3);
-        asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); PP_FENCE();      // (everything but the last weight fragment, which column 3 of the next phase needs)
-        splitA(0, 2); splitA(0, 3);
         lead_adv();
         buf ^= 1;
         if (t == S - 1) {
