@@ -27,7 +27,7 @@ inline std::atomic<long long> g_ws_alloc_us{0}, g_ws_free_us{0};
 inline std::atomic<size_t> g_ws_alloc_bytes{0}, g_ws_allocs{0};
 inline std::atomic<size_t> g_ws_limit{0};          // test hook (option ws_limit_mb): a workspace request above this many bytes fails like an exhausted GPU; 0 = off
 // per-device "dynamic-LDS attribute set" masks of the wide conv kernels (the attribute belongs to the device's code object, the launch to a context)
-inline std::atomic<unsigned> g_attr_w256{0}, g_attr_g256{0}, g_attr_pp{0}, g_attr_px{0};
+inline std::atomic<unsigned> g_attr_w256{0}, g_attr_g256{0}, g_attr_pp{0};
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int reserve(size_t bytes) {
@@ -247,7 +247,6 @@ int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& a, const char* tag);
 int seg_prec(const sd_ctx* c);
 int launch_conv_gemm_g256(sd_ctx* c, const ConvArgs& a, const char* tag);
 int launch_conv_gemm_pp(sd_ctx* c, const ConvArgs& a, const char* tag);      // conv_gemm_p.hip
-int launch_conv_gemm_px(sd_ctx* c, const ConvArgs& a, const char* tag);      // conv_gemm_p.hip, the x3 form
 // ---- conv_narrow.hip (f32, Cout <= 96, "valid" convs of SincNet: tile as wide as the layer; returns 1 = not applicable)
 int launch_conv_narrow(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- weights.cpp

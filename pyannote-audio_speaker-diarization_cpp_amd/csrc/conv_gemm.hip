@@ -641,7 +641,6 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& in, const char* tag)
     // LDS-DMA staged form (conv_gemm_g.hip): the default for fp16; for f32 it measured 5 % SLOWER than the register-staged, pinned kernel
     // (MFA 147 -> 140 TF, tdnn 140 -> 131: profiles/r04_g256_ablation.txt) and is only taken with option conv_glds_f32 = 1
     if (f16 && c->conv_h256 && c->conv_pp) { const int r = launch_conv_gemm_pp(c, a, tag); if (r != 1) return r; }
-    if (a.prec == 3 && c->conv_pp) { const int r = launch_conv_gemm_px(c, a, tag); if (r != 1) return r; }      // round 6: the ping-pong form (conv_gemm_p.hip)
     if ((f16 && c->conv_h256 && c->conv_glds) || (!f16 && a.prec == 0 && c->conv_w256_f32 && c->conv_glds_f32)) { const int r = launch_conv_gemm_g256(c, a, tag); if (r != 1) return r; }
     if ((f16 && c->conv_h256) || (!f16 && c->conv_w256_f32) || a.prec == 3) { const int r = launch_conv_gemm_h256(c, a, tag); if (r != 1) return r; }
     const bool x3 = a.prec == 3 && a.W16x != nullptr;      // a layer the wide kernel does not take (X2, per-item bias, Cout = 128): the 128 x 128 form of the split

@@ -65,10 +65,10 @@ __device__ __forceinline__ v4i pp_rsrc(const void* base, size_t bytes)
 }
 
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
-// Behind every 16-byte store of the epilogues: with an SGPR soffset hipcc leaves NO wait state between the store and a VALU write of its first data register
-// (its hazard rule is gfx9's: the store-data hazard needs an immediate soffset).  On gfx950 such a store now and then sent the overwritten value for lanes
-// 12-15 of each row of 16 -- 4 x 4 patches of wrong outputs that moved from run to run (k_conv_gemm_px; tools/x3_batch_debug3.py found them).  Two wait
-// states, fenced so that nothing is scheduled between the store and them.
+// Behind every 16-byte store of the epilogue: with an SGPR soffset (this kernel's stores have one for nh = 1) hipcc leaves NO wait state between the store
+// and a VALU write of its first data register -- its hazard rule is gfx9's, where the store-data hazard needs an immediate soffset.  On gfx950 such a
+// store now and then sent the overwritten value for lanes 12-15 of each row of 16: 4 x 4 patches of wrong outputs that moved from run to run, seen in an
+// x3 form of this kernel that was measured and not kept (profiles/r06_px_attempt.txt).  Two wait states, fenced so that nothing is scheduled in between.
 #define PP_STORE_PAD() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 1"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_BARRIER() do { PP_FENCE(); __builtin_amdgcn_s_barrier(); PP_FENCE(); } while (0)
 
@@ -339,303 +339,6 @@ __global__ __launch_bounds__(512) void k_conv_gemm_pp(ConvArgs a)
 }
 
 
-// ---------------------------------------------------------------- x3 form (ecapa_precision = 3: f32 tensors, both MFMA operands split into hi + lo fp16 halves)
-// The same never-drained load stream for the split-operand mode.  A K-tile is 32 channels: 128 bytes of an f32 activation row and 128 bytes of a split
-// weight row ([hi 0..7 | lo 0..7 | hi 8..15 | ...], weights.cpp), so stages, pieces and the DMA schedule are those of the fp16 kernel above.  The activation
-// fragments are read as f32 (two ds_read_b128 per 16 x 32 block: the lane's eight channels) and split IN REGISTERS, hi = fp16(a), lo = fp16(a - hi) -- the
-// arithmetic of conv_gemm_h.hip's staging split, done by the four waves that read a row block instead of once per workgroup (20 vector instructions per block
-// beside 12 MFMAs); a block pair runs Whi * Ahi + Whi * Alo + Wlo * Ahi on v_mfma_f32_16x16x32_f16 (one instruction per 32 channels; conv_gemm_h.hip: two
-// 32x32x16 per product, so the f32 sums are grouped differently and the last bits differ from that kernel's; both stay within 1e-7 of the f32 path).
-// LDS swizzle: a lane reads chunks 2 (l >> 4) and 2 (l >> 4) + 1 of its row, so the chunk position is c ^ ((R >> 1) & 5) here (conflict-free for that pattern).
-// Phases by ROW half, column-major inside (12 MFMAs per column block): phase X = row blocks 0-3 | reads + split of row blocks 4-7 | the 4 B pieces of T + 1;
-// barrier; phase Y = row blocks 4-7 | the 4 A pieces of T + 2 | behind column 1: vmcnt(2) + barrier, then the next K-tile's weight fragments column by column as
-// this K-tile's columns finish, and its row blocks 0-3 (read + split).  f32 epilogue: (acc / weight scale + bias) -> activation -> BatchNorm, 16-byte stores.
-#ifndef SD_PX_ABLATE
-#define SD_PX_ABLATE 0         // timing builds only (Makefile: libsdhip_pxabl<bits>.so): 1 = no operand split, 2 = no DMAs in the loop, 4 = no fragment reads in the loop
-#endif
-template <bool RELU>
-__global__ __launch_bounds__(512) void k_conv_gemm_px(ConvArgs a)
-{
-    extern __shared__ __attribute__((aligned(1024))) char lds[];
-    const int w = blockIdx.x, G = gridDim.x;
-    const int xcd = w & 7, wl = w >> 3, wpx = G >> 3;
-    const int mx = (a.m_tiles - xcd + 7) >> 3;
-    const int pnmax = a.sched > 0 ? a.sched : 4;
-    const int PN = a.n_tiles < pnmax ? a.n_tiles : pnmax;
-    const int PM = wpx / PN > 0 ? wpx / PN : 1;
-    const int pm = wl / PN, pn = wl - pm * PN;
-    if (pm >= PM) return;
-    const int n_groups = (a.n_tiles + PN - 1) / PN, m_groups = (mx + PM - 1) / PM;
-    const int sb_end = n_groups * m_groups;
-    auto sb_valid = [&](int sb, int& j, int& nt) -> bool {
-        const int mg = sb / n_groups, ng = sb - mg * n_groups;
-        j = mg * PM + pm; nt = ng * PN + pn;
-        return j < mx && nt < a.n_tiles;
-    };
-    auto next_sb = [&](int sb) -> int {
-        int j, nt;
-        for (++sb; sb < sb_end; ++sb) if (sb_valid(sb, j, nt)) return sb;
-        return sb_end;
-    };
-    const int q0 = next_sb(-1);
-    if (q0 >= sb_end) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g = wid >> 2, wc = wid & 3;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int kcs = a.Cin / 32;                      // K-tiles per tap
-    const int S = a.KT * kcs;                        // K-tiles per output tile (>= 2)
-    const int half = a.KT / 2;
-    const size_t in_rows = (size_t)(a.in_rows > 0 ? a.in_rows : a.M);
-    const unsigned lds0 = (unsigned)(size_t)(lds_char*)lds;
-    const _Float16* const Wx = (const _Float16*)a.W16x;
-
-    const int prow = lane >> 3;
-    unsigned chk[2], voB[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int r = wid * 16 + p * 8 + prow;
-        chk[p] = (unsigned)(((lane & 7) ^ ((r >> 1) & 5)) * 16);
-        voB[p] = (unsigned)r * (unsigned)a.w_ld * 2u + chk[p];
-    }
-    const unsigned dstw = __builtin_amdgcn_readfirstlane((unsigned)(wid * 2048));
-    const unsigned tab0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(P_TAB + wid * 512));
-    const unsigned par0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(P_PAR + wid * 2048));
-    const v4i rTab = pp_rsrc(a.rowtab, (size_t)a.M * 8);
-    struct Cur {
-        int sb, kk, kc, m0, n0, base, tiles;
-        unsigned vo[4];
-    };
-    auto tile_of = [&](int sb, int& m0, int& n0) { int j, nt; (void)sb_valid(sb, j, nt); m0 = __builtin_amdgcn_readfirstlane((xcd + 8 * j) * 256); n0 = __builtin_amdgcn_readfirstlane(nt * 256); };
-    auto table_dma = [&](int m0, int slot) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(tab0 + (unsigned)(slot * 256));
-        if (lane < 16) pp_dma_b128(rTab, dst, (unsigned)(m0 + 128 * (lane >> 3) + 16 * wid + 2 * (lane & 7)) * 8u);
-    };
-    auto cur_rows = [&](Cur& c) {
-        const int m0c = c.m0 < a.M ? c.m0 : a.M - 1;
-        {
-            const unsigned long long ad = (unsigned long long)(a.rowtab + m0c);
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ad), hi = __builtin_amdgcn_readfirstlane((unsigned)(ad >> 32));
-            const unsigned long long ads = ((unsigned long long)hi << 32) | lo;
-            int bs;
-            asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bs) : "s"(ads) : "memory");
-            c.base = bs;
-        }
-    };
-    auto cur_tap = [&](Cur& c) {
-        const int2* const tb = (const int2*)(lds + P_TAB + wid * 512 + (c.tiles & 1) * 256);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int2 e = tb[(q >> 1) * 16 + (q & 1) * 8 + prow];
-            int qr = ROWTAB_T(e.y) + (c.kk - half) * a.dil;
-            const int nd = ROWTAB_LAST(e.y);
-            if (qr < 0) qr = -qr;
-            if (qr >= a.Tin) qr = 2 * (a.Tin - 1) - qr;
-            if (qr < 0) qr = 0;
-            if (qr > nd) qr = nd;
-            c.vo[q] = (unsigned)(e.x - c.base + qr) * (unsigned)a.x_ld * 4u + chk[q & 1];
-        }
-    };
-    auto cur_adv = [&](Cur& c, bool is_a) -> bool {
-        if (++c.kc < kcs) return false;
-        c.kc = 0;
-        if (++c.kk < a.KT) { if (is_a) cur_tap(c); return false; }
-        c.kk = 0;
-        const int nq = next_sb(c.sb);
-        if (nq >= sb_end) { if (is_a) cur_tap(c); return false; }
-        c.sb = nq; ++c.tiles;
-        tile_of(nq, c.m0, c.n0);
-        if (is_a) { cur_rows(c); cur_tap(c); }
-        return true;
-    };
-    auto dmaA = [&](const Cur& c, int buf, int q) {
-        const v4i rs = pp_rsrc(a.X + ((size_t)c.base * a.x_ld + (size_t)c.kc * 32), (in_rows - (size_t)c.base) * a.x_ld * 4);
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * P_BUF + (q >> 1) * P_HALF + (q & 1) * 1024) + dstw);
-        pp_dma_b128(rs, dst, c.vo[q]);
-    };
-    auto dmaB = [&](const Cur& c, int buf, int q) {
-        const v4i rs = pp_rsrc(Wx + (((size_t)c.kk * a.Cout + c.n0 + 128 * (q >> 1)) * a.w_ld + (size_t)c.kc * 64), 0xffffffffull);
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * P_BUF + (2 + (q >> 1)) * P_HALF + (q & 1) * 1024) + dstw);
-        pp_dma_b128(rs, dst, voB[q & 1]);
-    };
-    // parameters of the wave's 64 channels: lane k < 16 of DMA `arr` fetches channels 128 (k >> 3) + 32 wc + 4 (k & 7) .. + 3 -> floats [arr][k][4] of the area
-    const unsigned voP = (unsigned)(128 * ((lane & 15) >> 3) + 32 * wc + 4 * (lane & 7)) * 4u;
-    auto stageP = [&](int n0, int par) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(par0 + (unsigned)(par * 1024));
-        const v4i rb = pp_rsrc(a.bias + n0, (size_t)(a.Cout - n0) * 4), rc = pp_rsrc(a.scale + n0, (size_t)(a.Cout - n0) * 4), rh = pp_rsrc(a.shift + n0, (size_t)(a.Cout - n0) * 4);
-        if (lane < 16) {
-            pp_dma_b128(rb, dst, voP);
-            pp_dma_b128(rc, dst + 256, voP);
-            pp_dma_b128(rh, dst + 512, voP);
-        }
-    };
-
-    // ---- fragments.  Lane l owns channels 8 (l >> 4) .. + 7 of the K-tile: chunks 2 (l >> 4), 2 (l >> 4) + 1 of row l & 15 of a block
-    const int sw = (l15 >> 1) & 5;
-    const int c0 = ((2 * l4) ^ sw) * 16, c1 = ((2 * l4 + 1) ^ sw) * 16;
-    const char* const Afr = lds + (64 * g + l15) * 128;                  // + mh * P_HALF + i * 2048 + c0 / c1
-    const char* const Bfr = lds + 2 * P_HALF + (32 * wc + l15) * 128;    // + nh * P_HALF + j * 2048 + c0 (hi) / c1 (lo)
-    f32x4 fa[2][4][2];                  // [row half][row block i][hi, lo]
-    f32x4 fb[4][2];                     // [column block C = 2 nh + j][hi, lo]
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto rdA = [&](int buf, int mh, int i) {
-        fa[mh][i][0] = *(const f32x4*)(Afr + buf * P_BUF + mh * P_HALF + i * 2048 + c0);
-        fa[mh][i][1] = *(const f32x4*)(Afr + buf * P_BUF + mh * P_HALF + i * 2048 + c1);
-    };
-    // The split of A, once per workgroup: every wave splits the rows IT staged (its own vmcnt is enough, no barrier), in place -- the eight f32 of a
-    // chunk pair become [8 hi halves | 8 lo halves] in the same 32 bytes, so the fragment reads above find hi in the first chunk's place and lo in the
-    // second's.  Round j = the wave's 16 rows of row half j: lane -> row (lane >> 2), chunk pair (lane & 3); 16 lanes = 4 rows x 4 pairs, rows r and r + 2
-    // on the same banks hold their pairs at swapped chunk positions: conflict-free.  (Before: every wave split its own fragments, each row four times.)
-    const int sr = wid * 16 + (lane >> 2), ssw = (sr >> 1) & 5, sk = lane & 3;
-    char* const Spl = lds + sr * 128;
-    const int sc0 = ((2 * sk) ^ ssw) * 16, sc1 = ((2 * sk + 1) ^ ssw) * 16;
-    f32x4 sraw[2][2];                   // [round j][first, second chunk of the pair]: read a phase ahead of the arithmetic
-    auto coop_read = [&](int buf) {
-        if (SD_PX_ABLATE & 1) return;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const char* const q = Spl + buf * P_BUF + j * P_HALF;
-            sraw[j][0] = *(const f32x4*)(q + sc0); sraw[j][1] = *(const f32x4*)(q + sc1);
-        }
-    };
-    auto coop_write = [&](int buf, int j) {
-        if (SD_PX_ABLATE & 1) return;
-        char* const q = Spl + buf * P_BUF + j * P_HALF;
-        half8 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = sraw[j][e >> 2][e & 3]; hi[e] = (_Float16)f; lo[e] = (_Float16)(f - (float)hi[e]); }
-        *(f32x4*)(q + sc0) = __builtin_bit_cast(f32x4, hi);
-        *(f32x4*)(q + sc1) = __builtin_bit_cast(f32x4, lo);
-    };
-    auto rdB = [&](int buf, int C) {
-        fb[C][0] = *(const f32x4*)(Bfr + buf * P_BUF + (C >> 1) * P_HALF + (C & 1) * 2048 + c0);
-        fb[C][1] = *(const f32x4*)(Bfr + buf * P_BUF + (C >> 1) * P_HALF + (C & 1) * 2048 + c1);
-    };
-    auto mma_col = [&](int mh, int C) {         // column block C x the four row blocks of half mh: 12 MFMAs
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 v = acc[4 * mh + i][C];
-            v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fb[C][0]), __builtin_bit_cast(half8, fa[mh][i][0]), v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fb[C][0]), __builtin_bit_cast(half8, fa[mh][i][1]), v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fb[C][1]), __builtin_bit_cast(half8, fa[mh][i][0]), v, 0, 0, 0);
-            acc[4 * mh + i][C] = v;
-        }
-    };
-    // epilogue chunk: row block R x column block C = 4 values per lane (rows 128 (R >> 2) + 64 g + 16 (R & 3) + l15, channels 128 (C >> 1) + 32 wc + 16 (C & 1) + 4 l4 .. + 3)
-    const float slope = (a.act1 == 1) ? 0.0f : ((a.act1 == 2) ? 0.01f : 1.0f);
-    const float as = a.acc_scale;
-    const unsigned ybytes = (unsigned)a.y_ld * 4u;
-    const unsigned voY = (unsigned)(64 * g + l15) * ybytes + (unsigned)(32 * wc + 4 * l4) * 4u;
-    auto epilogue = [&](int par, __amdgpu_buffer_rsrc_t rY) {
-#pragma unroll
-        for (int C = 0; C < 4; ++C) {
-            const float* const pw = (const float*)(lds + P_PAR + wid * 2048 + par * 1024) + ((C >> 1) * 8 + (C & 1) * 4 + l4) * 4;
-            asm volatile("" ::: "memory");
-            const float4 b = *(const float4*)(pw), sc = *(const float4*)(pw + 64), sh = *(const float4*)(pw + 128);
-            const float bb[4] = {b.x, b.y, b.z, b.w}, ss[4] = {sc.x, sc.y, sc.z, sc.w}, hh[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-            for (int R = 0; R < 8; ++R) {
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[R][C][e] * as + bb[e];
-                    acc[R][C][e] = 0.0f;
-                    v = fmaxf(v, v * (RELU ? 0.0f : slope));      // (NaN stays NaN: the overflow check of the mode depends on it)
-                    o[e] = v * ss[e] + hh[e];
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rY, voY + (unsigned)(128 * (R >> 2) + 16 * (R & 3)) * ybytes, (unsigned)(512 * (C >> 1) + 64 * (C & 1)), 0);
-                PP_STORE_PAD();
-            }
-        }
-    };
-    auto make_rY = [&](int m0, int n0) {
-        const int rows_left = a.M - m0;
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (size_t)m0 * a.y_ld + n0), 0, (unsigned)((size_t)(rows_left < 256 ? rows_left : 256) * a.y_ld * 4), 0x00020000);
-    };
-
-    // ---- prologue
-    Cur cA; cA.sb = q0; cA.kk = 0; cA.kc = 0; cA.tiles = 0;
-    tile_of(q0, cA.m0, cA.n0);
-    table_dma(cA.m0, 0);
-    { const int nq = next_sb(q0); if (nq < sb_end) { int m1, n1; tile_of(nq, m1, n1); table_dma(m1, 1); } }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    cur_rows(cA); cur_tap(cA);
-    const int m0_first = cA.m0, n0_first = cA.n0;
-    auto lead_adv = [&]() {
-        if (cur_adv(cA, true)) { const int nq = next_sb(cA.sb); if (nq < sb_end) { int m1, n1; tile_of(nq, m1, n1); table_dma(m1, (cA.tiles + 1) & 1); } }
-    };
-    // one cursor: the A AND the B pieces of K-tile T + 2 are requested in phase Y of K-tile T (both buffer halves of T are free once the barrier behind
-    // phase X is passed: the weight fragments of T have been in registers since phase Y of T - 1), a phase and a quarter before their barrier
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { dmaA(cA, 0, q); dmaB(cA, 0, q); }
-    lead_adv();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { dmaA(cA, 1, q); dmaB(cA, 1, q); }
-    lead_adv();
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    coop_read(0); coop_write(0, 0); coop_write(0, 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int C = 0; C < 4; ++C) rdB(0, C);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rdA(0, 0, i);
-
-    int q = q0, t = 0, buf = 0, par = 0;
-    bool have_prev = false;
-    __amdgpu_buffer_rsrc_t rYc = make_rY(m0_first, n0_first), rYp = rYc;
-    int n0c = n0_first;
-    while (true) {
-        // ---- phase X: row blocks 0-3 | the fragments of row blocks 4-7 | behind column 2: the wave reads its rows of A(T + 1) for the split (its own
-        //      pieces, requested a phase ago: vmcnt(1) leaves the last weight piece in flight)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PP_FENCE();
-        if (t == 0 && have_prev) epilogue(par ^ 1, rYp);
-        PP_FENCE();
-#pragma unroll
-        for (int C = 0; C < 4; ++C) {
-            if (!(SD_PX_ABLATE & 4)) rdA(buf, 1, C);
-            if (C == 3) { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); coop_read(buf ^ 1); }
-            mma_col(0, C);
-            PP_FENCE();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        PP_BARRIER();
-        // ---- phase Y: row blocks 4-7 | columns 0, 1: the split of A(T + 1), written back in place | the 8 pieces of T + 2 | behind column 1: vmcnt(4) +
-        //      barrier, then the next K-tile's fragments
-#pragma unroll
-        for (int C = 0; C < 4; ++C) {
-            if (C < 2) coop_write(buf ^ 1, C);
-            if (C == 2) {
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-                PP_BARRIER();
-                if (t == 0) stageP(n0c, par);
-                if (!(SD_PX_ABLATE & 4)) { rdB(buf ^ 1, 0); rdB(buf ^ 1, 1); rdA(buf ^ 1, 0, 0); rdA(buf ^ 1, 0, 1); }
-            }
-            if (C == 3 && !(SD_PX_ABLATE & 4)) { rdB(buf ^ 1, 2); rdA(buf ^ 1, 0, 2); rdA(buf ^ 1, 0, 3); }
-            mma_col(1, C);
-            PP_FENCE();
-            if (!(SD_PX_ABLATE & 2)) { dmaA(cA, buf, C); dmaB(cA, buf, C); }
-            PP_FENCE();
-        }
-        if (!(SD_PX_ABLATE & 4)) rdB(buf ^ 1, 3);
-        lead_adv();
-        buf ^= 1;
-        if (t == S - 1) {
-            q = next_sb(q);
-            rYp = rYc; have_prev = true; par ^= 1;
-            if (q >= sb_end) break;
-            { int m0n; tile_of(q, m0n, n0c); rYc = make_rY(m0n, n0c); }
-            t = 0;
-        } else ++t;
-    }
-    epilogue(par ^ 1, rYp);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 // returns 1 when the layer does not fit this kernel (the caller then uses conv_gemm_g.hip / conv_gemm_h.hip)
 int launch_conv_gemm_pp(sd_ctx* c, const ConvArgs& in, const char* tag)
 {
@@ -673,43 +376,5 @@ int launch_conv_gemm_pp(sd_ctx* c, const ConvArgs& in, const char* tag)
         else hipLaunchKernelGGL(k_conv_gemm_pp<false>, dim3(grid), dim3(512), P_LDS, c->stream, a);
     }
     if (hipGetLastError() != hipSuccess) SD_FAIL(c, SD_ERR_HIP, "k_conv_gemm_pp launch failed (%s)", tag);
-    return SD_OK;
-}
-
-// the x3 form: returns 1 when the layer does not fit (the caller then uses k_conv_gemm_w256<3>).  Every batch size is taken, as there: the arithmetic of a
-// layer must not depend on how many items share a batch
-int launch_conv_gemm_px(sd_ctx* c, const ConvArgs& in, const char* tag)
-{
-    ConvArgs a = in;
-    if (a.prec != 3 || !a.rowtab || !a.W16x || a.X2 || a.item_bias || a.R || a.act2 || a.pad_mode != 0 || !a.bias || !a.scale || !a.shift || a.kt_real > 0 ||
-        a.Cout < 256 || (a.Cout % 256) != 0 || (a.y_ld & 3) || a.Cin % 32 != 0 || (a.x_ld & 3) || (int64_t)a.KT * (a.Cin / 32) < 2 || !c->conv_pp) return 1;
-    if (c->conv_w256_kmin > 0 && (int64_t)a.Cin * a.KT < c->conv_w256_kmin) return 1;      // (tuning / debugging: which layers take this form)
-    if (((size_t)a.X & 15) || ((size_t)a.W16x & 15) || ((size_t)a.Y & 15) || ((size_t)a.bias & 15) || ((size_t)a.scale & 15) || ((size_t)a.shift & 15) || ((size_t)a.rowtab & 15)) return 1;
-    const unsigned dev_bit = 1u << (c->device & 31);
-    if (!(g_attr_px.load(std::memory_order_acquire) & dev_bit)) {
-        if (hipFuncSetAttribute((const void*)k_conv_gemm_px<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_conv_gemm_px<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS) != hipSuccess) { (void)hipGetLastError(); return 1; }
-        g_attr_px.fetch_or(dev_bit, std::memory_order_release);
-    }
-    a.w_ld = 2 * a.Cin;                      // halves: eight hi, eight lo, eight hi, ... (weights.cpp)
-    a.m_tiles = (a.M + 255) / 256;
-    a.n_tiles = a.Cout / 256;
-    a.sched = c->conv_pn;
-    int grid = (c->num_cu / 8) * 8;
-    if (grid < 8) grid = 8;
-    const int lx_max = ((a.m_tiles + 7) / 8) * a.n_tiles;
-    if (grid / 8 > lx_max) grid = lx_max * 8;
-    const int cin = a.cin_real > 0 ? a.cin_real : a.Cin;
-    const double flops = 2.0 * (double)a.M * a.Cout * cin * a.KT;
-    const double bytes = 4.0 * ((double)a.M * cin + (double)a.M * a.Cout + (double)a.Cout * cin * a.KT);
-    {
-        ProfScope ps(c, c->profile_detail ? std::string("conv_gemm:") + tag : std::string("conv_gemm"), flops, bytes);
-        ProfScope ps16(c, "conv_gemm_x3", flops, bytes);
-        ProfScope psw(c, "conv_w256_x3", flops, bytes);
-        ProfScope pss(c, "conv_w256_ecapa", flops, bytes);
-        if (a.act1 == 1) hipLaunchKernelGGL(k_conv_gemm_px<true>, dim3(grid), dim3(512), P_LDS, c->stream, a);
-        else hipLaunchKernelGGL(k_conv_gemm_px<false>, dim3(grid), dim3(512), P_LDS, c->stream, a);
-    }
-    if (hipGetLastError() != hipSuccess) SD_FAIL(c, SD_ERR_HIP, "k_conv_gemm_px launch failed (%s)", tag);
     return SD_OK;
 }
