@@ -207,6 +207,7 @@ struct sd_ctx {
     std::string dump_dir;                       // sd_set_dump_dir: the next finalize writes the reference's WRITE_DATA items there
     int dump_level = 0;
     StepStash stash;
+    std::string ws_failed;                      // ws_get: name of the workspace whose allocation failed last ("" = none); the embedding stage's retry reads it
     const float* planted_scores = nullptr;      // sd_set_planted: measurement / test hook
     const float* planted_emb = nullptr;
     int64_t planted_lo = 0, planted_n = 0;
@@ -219,7 +220,7 @@ struct sd_ctx {
 // workspace helper
 template <class T> inline T* ws_get(sd_ctx* c, const char* name, size_t count) {
     DevBuf& b = c->ws[name];
-    if (b.reserve(count * sizeof(T))) return nullptr;
+    if (b.reserve(count * sizeof(T))) { c->ws_failed = name; return nullptr; }
     return b.as<T>();
 }
 #define WS(ctx, T, var, name, count) T* var = ws_get<T>(ctx, name, (size_t)(count)); if (!var) SD_FAIL(ctx, SD_ERR_HIP, "hipMalloc of workspace %s (%zu bytes) failed", name, (size_t)(count) * sizeof(T))

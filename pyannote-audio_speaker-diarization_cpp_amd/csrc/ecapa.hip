@@ -469,6 +469,7 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
             return actual > 0.0 ? ideal / actual : 0.0;
         };
         const int64_t n_batches = (rows_all + cap_rows - 1) / cap_rows;
+        c->ws_failed.clear();
         rc = ecapa_run_batches(c, [&]() -> int {
         int rc = SD_OK;
         for (int64_t a0 = 0, k = 1; a0 < n_active; ++k) {
@@ -494,10 +495,13 @@ int run_embed(sd_ctx* c, const float* d_wav, int64_t n, const float* d_masks, in
         }
         return rc;
         });
-        if (rc == SD_ERR_HIP && nb > 96 && c->err.find("hipMalloc of workspace") != std::string::npos) {
+        // out of memory in the activation arena (a workspace named ec_*, recorded by ws_get -- not recognised by the wording of the message): every
+        // ec_* buffer is released and the batches are made smaller.  A failure of any other workspace is not retried
+        if (rc == SD_ERR_HIP && nb > 96 && c->ws_failed.rfind("ec_", 0) == 0) {
             (void)hipStreamSynchronize(c->stream);
             (void)hipGetLastError();
-            for (const char* k : {"ec_x0", "ec_tr", "ec_t2", "ec_cat", "ec_mfa", "ec_hid", "ec_logits", "ec_mfa32", "ec_hid32", "ec_feats16"}) { auto it = c->ws.find(k); if (it != c->ws.end()) it->second.release(); }
+            for (auto& kv : c->ws) if (kv.first.rfind("ec_", 0) == 0) kv.second.release();
+            c->ws_failed.clear();
             nb = nb > 768 ? 768 : 96;
             c->stats["emb_arena_retries"].launches += 1;
             c->err.clear();

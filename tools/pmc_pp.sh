@@ -9,7 +9,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES" "SQ_WAVE
   rocprofv3 --pmc $set --output-format csv -d $out/p$i -o p -- python3 tools/layer_profile.py planted 1 f16 > $out/p$i.log 2> $out/p$i.err
   f=$(find $out/p$i -name "*counter_collection.csv" | head -1)
   echo "== $set"
-  if [ -n "$f" ]; then python3 tools/pmc_kernel_fold.py $f k_conv_gemm_pp; python3 tools/pmc_kernel_fold.py $f k_conv_gemm_g256; else tail -3 $out/p$i.err; fi
+  if [ -n "$f" ]; then python3 tools/pmc_kernel_fold.py $f k_conv_gemm_pp; else tail -3 $out/p$i.err; fi
 done
 grep -E "conv_gemm:(tdnn1|tdnn2|mfa|block0)" $out/p$i.log
 rm -rf $out/p*/
