@@ -24,9 +24,9 @@ def _run(tool, seconds, seed, min_runs):
 
 @pytest.mark.gpu
 def test_linkage_fuzz_slice():
-    """35 s of tools/linkage_fuzz.py, seed 7: every kernel route of run_linkage (k_linkage_rg, k_linkage_mw, the zero phase, k_linkage_hx in its 16- and
+    """25 s of tools/linkage_fuzz.py, seed 7: every kernel route of run_linkage (k_linkage_rg, k_linkage_mw, the zero phase, k_linkage_hx in its 16- and
     32-bit forms, k_linkage_heap) is taken at least once"""
-    text = _run("linkage_fuzz.py", 35, 7, 60)
+    text = _run("linkage_fuzz.py", 25, 7, 40)
     counts = {k: int(v) for k, v in re.findall(r"^(linkage_\w+) (\d+)$", text, re.M)}
     assert counts.get("linkage_rg_launches", 0) > 0 and counts.get("linkage_hx_jobs", 0) > 0 and counts.get("linkage_tie_fallbacks", 0) > 0, counts
     assert counts.get("linkage_hx_failed", 0) == 0, counts
@@ -34,8 +34,8 @@ def test_linkage_fuzz_slice():
 
 @pytest.mark.gpu
 def test_stage_fuzz_slice():
-    """20 s of tools/stage_fuzz.py, seed 7: post-segmentation, clustering (NaN rows, duplicates, too few live rows) and reconstruction + annotation"""
-    _run("stage_fuzz.py", 20, 7, 25)
+    """14 s of tools/stage_fuzz.py, seed 7: post-segmentation, clustering (NaN rows, duplicates, too few live rows) and reconstruction + annotation"""
+    _run("stage_fuzz.py", 14, 7, 16)
 
 
 @pytest.mark.gpu
