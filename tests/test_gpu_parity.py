@@ -439,11 +439,12 @@ def test_ecapa_fp16_lds_dma_staged_kernel_gives_the_same_bits(diarizer):
 
 
 def test_ecapa_fp16_ping_pong_kernel_gives_the_same_bits(diarizer):
-    """fp16 mode: the two-group ping-pong kernel of the wide layers (conv_gemm_p.hip, round 6: half-tiles staged and released phase by phase,
-    weights as the MFMA's first operand, 16-byte stores straight from the accumulators, the epilogue in chunks behind the MFMAs of the next
-    K-tiles) against the kernel it replaces (conv_gemm_g.hip, 16x16x32 form): the same products in the same order, so the embeddings must be
-    bit-identical -- on ragged items (row tables with cross-space layers, clamped frames, a partly filled last tile, several tiles per
-    workgroup), run three times (a half-tile read before its DMA has landed, or overwritten before its last read, shows as a difference)."""
+    """fp16 mode: the round-6 kernel of the wide layers (conv_gemm_p.hip: a load stream that is never drained, every wave interleaves its
+    fragment reads and LDS-DMAs with its MFMAs, weights as the MFMA's first operand, 16-byte stores straight from the accumulators, the epilogue
+    in chunks in front of the next tile's first MFMAs) against the kernel it replaces (conv_gemm_g.hip, 16x16x32 form): the same products in the
+    same order, so the embeddings must be bit-identical -- on ragged items (row tables with cross-space layers, clamped frames, a partly filled
+    last tile, several tiles per workgroup), run three times (a half-tile read before its DMA has landed, or overwritten before its last read,
+    or a store whose data register was rewritten too early, shows as a difference)."""
     rng = np.random.default_rng(37)
     lens = np.array([1.0, 0.5, 0.25, 0.9, 0.7, 0.33, 1.0, 0.6, 0.8, 0.45, 0.12, 1.0, 0.77, 0.05, 0.95, 0.5, 0.61, 1.0, 0.29, 0.83] * 3, np.float32)
     feats = (3.0 * rng.standard_normal((len(lens), 501, 80))).astype(np.float32)
@@ -463,6 +464,31 @@ def test_ecapa_fp16_ping_pong_kernel_gives_the_same_bits(diarizer):
         assert np.isfinite(e).all()
         bad = np.flatnonzero((e != e_g).any(axis=1))
         assert bad.size == 0, ("items that differ", bad[:10], np.abs(e - e_g).max())
+
+
+@pytest.mark.parametrize("n_items,seed", [(7, 1), (9, 2), (23, 3), (131, 4)])
+def test_ecapa_fp16_wide_kernel_same_bits_over_batch_geometries(diarizer, n_items, seed):
+    """the same comparison over batch geometries the hour does not produce: just above the kernel's 2 048-row minimum (9 - 10 row panels: one or two per
+    XCD, most workgroups of the grid without a tile), a handful of panels per XCD with a ragged last one, and ~ 170 panels (several super-block rounds per
+    workgroup, the last round partly filled).  Two runs each."""
+    rng = np.random.default_rng(100 + seed)
+    lens = rng.choice(np.array([1.0, 0.97, 0.5, 0.26, 0.81, 0.07, 0.64], np.float32), size=n_items).astype(np.float32)
+    lens[:5] = 1.0          # >= 2 500 rows: the kernel takes the layers (M >= 2 048)
+    feats = (3.0 * rng.standard_normal((n_items, 501, 80))).astype(np.float32)
+    diarizer.set_option("ecapa_precision", 1)
+    try:
+        diarizer.set_option("conv_pp", 1)
+        e_pp = [diarizer.ecapa(feats, lens) for _ in range(2)]
+        diarizer.set_option("conv_pp", 0)
+        diarizer.set_option("conv_mfma16", 2)
+        e_g = diarizer.ecapa(feats, lens)
+    finally:
+        diarizer.set_option("conv_pp", 1)
+        diarizer.set_option("conv_mfma16", 1)
+        diarizer.set_option("ecapa_precision", 0)
+    assert np.isfinite(e_g).all()
+    for e in e_pp:
+        assert np.array_equal(e, e_g), ("items that differ", np.flatnonzero((e != e_g).any(axis=1))[:10], np.abs(e - e_g).max())
 
 
 def test_ecapa_bits_do_not_depend_on_how_many_items_share_a_batch(diarizer):
