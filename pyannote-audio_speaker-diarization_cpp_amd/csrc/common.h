@@ -179,7 +179,7 @@ struct sd_ctx {
     int conv_rot = 3;                           // LDS-DMA wide kernel: the workgroups that share a row panel request its quarters in rotated order (conv_gemm_g.hip); tuning
     int conv_stagger = 0;                       // 128 x 128 f32 kernel: start half of the workgroups half a tile late (0 off, 1 odd, 2 upper half); tuning
     bool conv_glds_f32 = false;                 // f32: the LDS-DMA staged form of the wide tile (conv_gemm_g.hip, P = 0): bit-identical, measured slower; A-B only
-    bool conv_pp = true;                        // fp16 mode: the two-group ping-pong kernel for the wide layers (conv_gemm_p.hip, round 6); 0 = conv_gemm_g.hip; A-B
+    bool conv_pp = true;                        // fp16 mode: the never-drained kernel for the wide layers (conv_gemm_p.hip, round 6); 0 = conv_gemm_g.hip; A-B
     bool conv_glds = true;                      // fp16 mode: ... staged by LDS-DMA (conv_gemm_g.hip) instead of through registers; tuning / A-B
     bool skip_dead_rows = true;                 // ECAPA: skip row panels beyond nvalid + receptive field
     int64_t linkage_wgs = -1;                  // -1 auto, 0/1 single workgroup, else cooperative workgroups
@@ -243,11 +243,12 @@ int launch_conv_gemm(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- conv_gemm_h.hip (fp16 mode, Cout >= 256: 256 x 256 tile; returns 1 = not applicable)
 int launch_conv_gemm_h256(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- conv_gemm_g.hip (fp16 mode, Cout >= 256: the same tile with LDS-DMA staging; returns 1 = not applicable)
-// the precision PyanNet's LSTM runs in: the option, or -- left at auto -- the split-operand form whenever the caller selected an fp16-pipe mode for ECAPA
-// (scores within 1e-6 of the f32 path's, identical turns: tests/test_gpu_parity.py, tests/test_planted.py; 86 -> 60 ms per hour)
-int seg_prec(const sd_ctx* c);
 int launch_conv_gemm_g256(sd_ctx* c, const ConvArgs& a, const char* tag);
-int launch_conv_gemm_pp(sd_ctx* c, const ConvArgs& a, const char* tag);      // conv_gemm_p.hip
+// ---- conv_gemm_p.hip (fp16 mode, Cout % 256 == 0, K >= 512, M >= 2 048: the never-drained form of round 6; returns 1 = not applicable)
+int launch_conv_gemm_pp(sd_ctx* c, const ConvArgs& a, const char* tag);
+// ---- api.cpp: the precision PyanNet's LSTM runs in: the option, or -- left at auto -- the split-operand form whenever the caller selected an fp16-pipe
+// mode for ECAPA (scores within 1e-6 of the f32 path's, identical turns: tests/test_gpu_parity.py, tests/test_planted.py; 86 -> 58 ms per hour)
+int seg_prec(const sd_ctx* c);
 // ---- conv_narrow.hip (f32, Cout <= 96, "valid" convs of SincNet: tile as wide as the layer; returns 1 = not applicable)
 int launch_conv_narrow(sd_ctx* c, const ConvArgs& a, const char* tag);
 // ---- weights.cpp

@@ -46,6 +46,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // `ldsaddr`.  Written as inline assembly on purpose: hipcc's waitcnt pass treats an LDS-DMA it knows about as a pending LDS store that ANY later
 // ds_read may alias and puts `s_waitcnt vmcnt(0)` in front of the next fragment read -- which would serialise exactly the overlap this
 // kernel exists for.  The waits that order these DMAs against the fragment reads are the explicit ones at the barrier (see the loop).
+// (`s_nop 4`: the descriptor words often come straight from v_readfirstlane, and an SGPR written by the vector ALU needs five wait states before a
+// vector-memory instruction reads it; hipcc counts them for its own instructions, not inside an asm string.)
 __device__ __forceinline__ void lds_dma_b32(v4i rs, unsigned ldsaddr, unsigned vo)       // 64 x 4 bytes -> 256 bytes of LDS
 {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(ldsaddr), "v"(vo), "s"(rs) : "memory");
