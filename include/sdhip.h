@@ -237,8 +237,9 @@ int sd_stage_ms(const sd_ctx*, double* ms4);
  *   the LSTM gates through v_exp_f32 + v_rcp_f32, the softmax of the attentive pooling through v_exp_f32 / v_rcp_f32 (each <= 1 ulp of
  *   the f32 result, i.e. ~1e-7 relative -- three orders below the parity tolerance rtol 1e-3 / atol 1e-4, and below what a different
  *   summation order already moves); "f32 = the reference's precision" means that class of result, not libm-bit-identical.
- * "seg_precision" (0 = f32 MFMA (default); 3 = the same operand split for PyanNet's LSTM: input projections of layers 1-3 and the recurrence;
- *   scores within 1e-6 of mode 0),
+ * "seg_precision" (-1 = auto (default): 3 whenever "ecapa_precision" is not 0 -- a caller who asked for an fp16-pipe mode gets it in both networks --
+ *   else 0; 0 = f32 MFMA; 3 = the same operand split for PyanNet's LSTM: input projections of layers 1-3 and the recurrence; scores within 2e-6 of
+ *   mode 0, identical turns on the planted hour and on the reference's 1-min wav),
  * "rank0_permille" (sd_diarize_sharded: share of the chunks rank 0 infers itself, -1 = equal),
  * "comm_timeout_ms" (deadline of the exchange step of a sharded job, default 600 000).
  * Test and tuning keys are listed in sdhip_test.h.  An unknown key returns SD_ERR_ARG. */

@@ -41,7 +41,9 @@ int sd_test_pack_split_weights(const float* w, int K, int Cout, int CinPad, int 
  * "conv_h256" / "conv_w256_f32" (256 x 256 tile for the wide ECAPA layers in fp16 / f32), "conv_glds" (fp16: that tile staged by LDS-DMA,
  * conv_gemm_g.hip, instead of through registers; same bits; default 1), "conv_glds_f32" (the same for f32: same bits, measured 5 % slower, default 0), "conv_rot" (LDS-DMA kernel, bit 0: the workgroups that
  * share a row / column panel request its four quarters in rotated order; bit 1: a wave's DMA pieces pair up inside one quarter; same bits; default 3), "conv_mfma16" (that kernel on
- * v_mfma_f32_16x16x32_f16 instead of 32x32x16: the chip holds a higher clock on it; default 1), "conv_stagger" (128 x 128 f32 kernel: half of
+ * v_mfma_f32_16x16x32_f16 instead of 32x32x16: the chip holds a higher clock on it; default 1; 2 = on short contractions (block0) too: the form the round-6
+ * kernel is compared with bit for bit), "conv_pp" (fp16: the wide layers with K >= 512 and M >= 2 048 on the never-drained kernel of round 6, conv_gemm_p.hip;
+ * same bits as "conv_glds"; default 1), "conv_stagger" (128 x 128 f32 kernel: half of
  * the workgroups start half a tile late; 0 off (default, no effect measured), 1 / 2), "conv_w256_kmin" (shortest contraction that tile
  * takes), "conv_pn" / "conv_pn128" (column tiles per super-block), "ecapa_ld_pad" (elements added to the activation rows, multiple of 8),
  * "seg_shared_conv0" (1 = SincNet's first convolution once over the waveform instead of once per overlapping chunk), "seg_wide_ih" (1 = LSTM input
