@@ -12,7 +12,7 @@
 //   --rttm FILE     also write the turns as RTTM
 //   --precision P   f32 (default: f32 MFMA, the reference's ORT precision) | f16 (fp16 ECAPA layers, BASELINE configs[4]) | x3 (f32 tensors, both
 //                   MFMA operands split into hi + lo fp16 halves in the ECAPA conv layers and PyanNet's LSTM: f32-grade results from the fp16 matrix
-//                   pipe) = sd_set_option "ecapa_precision" (+ "seg_precision" = 3 for x3)
+//                   pipe) = sd_set_option "ecapa_precision"; PyanNet's LSTM follows ("seg_precision" is left at auto for f16, set to 3 for x3: the same thing)
 //   --resample      a wav whose sample rate is not 16 000 Hz is resampled on the GPU first (sd_resample; the dormant Resampler of the reference,
 //                   frontend/resampler.cc:19-36).  WITHOUT it such a file is refused: the reference reads the rate and ignores it (sd.cpp:2940-2942),
 //                   i.e. silently diarizes at the wrong speed
